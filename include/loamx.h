@@ -1,0 +1,218 @@
+/* loamx.h — C ABI of libloamx.so, the MI355X (gfx950) implementation of the two hot paths of
+ * DanMcGann/loam: loam::extractFeatures and loam::registerFeatures.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types. The C++ header
+ * shim (the headers under include/loam/), the pybind11 module and bench.py all call through it. Each entry point
+ * cites the reference interface it replaces (paths relative to the reference repo root).
+ *
+ * There is NO CPU fallback: every compute entry point returns LOAMX_ERR_NO_DEVICE / LOAMX_ERR_HIP
+ * when no gfx950 device is usable.
+ *
+ * Conventions
+ *   - points: row-major N x 3 FP64 (x,y,z), the layout the reference's Accessors read one by one
+ *     (loam/include/loam/common.h:55-78).
+ *   - pose: double[7] = {qx, qy, qz, qw, tx, ty, tz}  (Eigen coefficient order, geometry.h:27-31).
+ *   - "host" entry points take host pointers and return host results (one scan / one pair);
+ *     "_dev" entry points take device pointers, run on the context's stream and do not synchronise.
+ */
+#ifndef LOAMX_H_
+#define LOAMX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct loamx_ctx loamx_ctx;
+
+enum {
+  LOAMX_OK = 0,
+  LOAMX_ERR_SCAN_SIZE = 1,   /* scan size != scan_lines * points_per_line (common.h:104-113) */
+  LOAMX_ERR_BAD_PARAM = 2,
+  LOAMX_ERR_HIP = 3,
+  LOAMX_ERR_CAPACITY = 4,    /* caller-provided output capacity too small */
+  LOAMX_ERR_UNSUPPORTED = 5, /* parameter combination outside what the kernels implement */
+  LOAMX_ERR_NO_DEVICE = 6
+};
+
+/* loam::LidarParams (loam/include/loam/common.h:29-41) */
+typedef struct {
+  uint64_t scan_lines;
+  uint64_t points_per_line;
+  double min_range;
+  double max_range;
+} loamx_lidar_params;
+
+/* loam::FeatureExtractionParams (loam/include/loam/features.h:37-66): same order, same defaults */
+typedef struct {
+  uint64_t neighbor_points;             /* 3 */
+  uint64_t number_sectors;              /* 6 */
+  uint64_t max_edge_feats_per_sector;   /* 10 */
+  uint64_t max_planar_feats_per_sector; /* 50 */
+  double edge_feat_threshold;           /* 100.0 */
+  double planar_feat_threshold;         /* 1.0 */
+  double occlusion_thresh;              /* 0.5 */
+  double parallel_thresh;               /* 1.0 */
+} loamx_fe_params;
+
+/* loam::RegistrationParams (loam/include/loam/registration.h:40-75): same order, same defaults */
+typedef struct {
+  uint64_t num_edge_neighbors;        /* 5 */
+  double max_edge_neighbor_dist;      /* 1.0 */
+  uint64_t min_line_fit_points;       /* 3 */
+  double min_line_condition_number;   /* 10 */
+  uint64_t num_plane_neighbors;       /* 5 */
+  double max_plane_neighbor_dist;     /* 2.0 */
+  uint64_t min_plane_fit_points;      /* 4 */
+  double max_avg_point_plane_dist;    /* 0.1 */
+  uint64_t max_iterations;            /* 10 */
+  double rotation_convergence_thresh; /* 1e-3 */
+  double position_convergence_thresh; /* 1e-2 */
+  uint64_t min_associations;          /* 100 */
+} loamx_reg_params;
+
+/* loam::RegistrationDetail::TerminationType (registration.h:83) */
+enum { LOAMX_CONVERGED = 0, LOAMX_MAX_ITER = 1, LOAMX_INSUFFICIENT_ASSOCIATIONS = 2 };
+
+/* Result of one registration: the returned Pose3d (registration.h:128-131) plus the termination
+ * type and the number of ICF iterations executed. 64 bytes; this is the record gathered across
+ * ranks in multi-GPU batch mode. */
+typedef struct {
+  double pose[7];
+  uint32_t termination;
+  uint32_t iterations;
+} loamx_reg_result;
+
+/* One RegistrationDetail::IterationInfo (registration.h:86-104) without the pair lists. */
+typedef struct {
+  double target_T_source_init[7];
+  double estimate_update[7];
+  uint32_t n_edge_associations;
+  uint32_t n_plane_associations;
+} loamx_iter_info;
+
+/* Optional detail capture for loamx_register_features (RegistrationDetail, registration.h:79-109).
+ * iter_info: capacity >= params.max_iterations. Association pair lists [source idx, nearest target
+ * idx] are written for iteration `pairs_iteration` only (set pairs capacity to 0 to skip). */
+typedef struct {
+  loamx_iter_info* iter_info;
+  uint32_t n_iter_info; /* out */
+  uint32_t pairs_iteration;
+  uint32_t* edge_pairs; /* 2 * edge_pairs_cap uint32 */
+  size_t edge_pairs_cap;
+  size_t n_edge_pairs; /* out */
+  uint32_t* plane_pairs;
+  size_t plane_pairs_cap;
+  size_t n_plane_pairs; /* out */
+} loamx_reg_detail;
+
+void loamx_default_fe_params(loamx_fe_params* p);
+void loamx_default_reg_params(loamx_reg_params* p);
+const char* loamx_status_string(int status);
+const char* loamx_last_error(const loamx_ctx* ctx);
+
+/* Context = one device + one stream + grow-on-demand device workspace. Thread-safe per context. */
+int loamx_ctx_create(int device, loamx_ctx** out);
+void loamx_ctx_destroy(loamx_ctx* ctx);
+/* Use an external hipStream_t (e.g. torch's current stream); NULL restores the context's own. */
+int loamx_ctx_set_stream(loamx_ctx* ctx, void* hip_stream);
+int loamx_ctx_synchronize(loamx_ctx* ctx);
+
+/* ---- host entry points (one scan / one pair; H2D, kernels, D2H, synchronous) ------------------ */
+
+/* loam::computeCurvature (features.h:119-122, features-inl.h:53-87): curvature_out[n_points] */
+int loamx_compute_curvature(loamx_ctx* ctx, const double* xyz, size_t n_points, const loamx_lidar_params* lidar,
+                            const loamx_fe_params* fe, double* curvature_out);
+/* loam::computeValidPoints (features.h:166-169, features-inl.h:90-124): mask_out[n_points] in {0,1} */
+int loamx_compute_valid_points(loamx_ctx* ctx, const double* xyz, size_t n_points,
+                               const loamx_lidar_params* lidar, const loamx_fe_params* fe, uint8_t* mask_out);
+/* loam::extractFeatures (features.h:108-111, features-inl.h:11-50). Writes the indices of the edge
+ * and planar feature points in the reference's output order; the caller copies the points
+ * (the C++ shim does, reproducing LoamFeatures). Capacity needed: scan_lines * number_sectors *
+ * (max_*_feats_per_sector + 1). */
+int loamx_extract_features(loamx_ctx* ctx, const double* xyz, size_t n_points, const loamx_lidar_params* lidar,
+                           const loamx_fe_params* fe, uint32_t* edge_idx, size_t edge_cap, size_t* n_edge,
+                           uint32_t* planar_idx, size_t planar_cap, size_t* n_planar);
+/* loam::registerFeatures (registration.h:128-131, registration-inl.h:11-78). detail may be NULL. */
+int loamx_register_features(loamx_ctx* ctx, const double* src_edge, size_t n_src_edge, const double* src_planar,
+                            size_t n_src_planar, const double* tgt_edge, size_t n_tgt_edge,
+                            const double* tgt_planar, size_t n_tgt_planar, const double init_pose[7],
+                            const loamx_reg_params* reg, loamx_reg_result* result, loamx_reg_detail* detail);
+
+/* ---- device-resident batch entry points (asynchronous on the context stream) ------------------ */
+
+/* Feature buffers of scan s live at base + s * stride with
+ *   edge stride   = loamx_edge_capacity(lidar, fe)   entries,
+ *   planar stride = loamx_planar_capacity(lidar, fe) entries. */
+size_t loamx_edge_capacity(const loamx_lidar_params* lidar, const loamx_fe_params* fe);
+size_t loamx_planar_capacity(const loamx_lidar_params* lidar, const loamx_fe_params* fe);
+
+/* extractFeatures over n_scans scans stored back to back (d_xyz: n_scans x N x 3 doubles).
+ * d_*_idx: uint32 indices into the scan; d_*_xyz: copies of the points (may be NULL);
+ * d_n_edge / d_n_planar: one uint32 count per scan. */
+int loamx_extract_features_batch_dev(loamx_ctx* ctx, const double* d_xyz, size_t n_scans,
+                                     const loamx_lidar_params* lidar, const loamx_fe_params* fe,
+                                     uint32_t* d_edge_idx, uint32_t* d_n_edge, double* d_edge_xyz,
+                                     uint32_t* d_planar_idx, uint32_t* d_n_planar, double* d_planar_xyz);
+
+/* registerFeatures over n_pairs independent pairs. Feature set f of pair p: points at
+ * d_*[p * stride * 3], count d_n_*[p]. d_init: n_pairs x 7 doubles or NULL (identity). */
+int loamx_register_features_batch_dev(loamx_ctx* ctx, size_t n_pairs, const double* d_src_edge,
+                                      const uint32_t* d_n_src_edge, const double* d_src_planar,
+                                      const uint32_t* d_n_src_planar, const double* d_tgt_edge,
+                                      const uint32_t* d_n_tgt_edge, const double* d_tgt_planar,
+                                      const uint32_t* d_n_tgt_planar, size_t edge_stride, size_t planar_stride,
+                                      const double* d_init, const loamx_reg_params* reg,
+                                      loamx_reg_result* d_results);
+
+/* The north-star unit: one scan-pair registration = extractFeatures(target scan), extractFeatures(
+ * source scan), registerFeatures(source, target, identity). d_xyz holds n_pairs x 2 scans, target
+ * scan first. Results are device resident. */
+int loamx_register_scan_pairs_dev(loamx_ctx* ctx, const double* d_xyz, size_t n_pairs,
+                                  const loamx_lidar_params* lidar, const loamx_fe_params* fe,
+                                  const loamx_reg_params* reg, loamx_reg_result* d_results);
+
+/* ---- per-kernel timing (hipEvents on the context stream), for bench.py's roofline object ------- */
+enum {
+  LOAMX_K_CURVATURE = 0, /* curvature + validity, 33 B/point algorithmic */
+  LOAMX_K_SELECT = 1,    /* per-sector greedy selection */
+  LOAMX_K_COMPACT = 2,   /* feature gather */
+  LOAMX_K_GRID = 3,      /* target spatial index build */
+  LOAMX_K_ASSOC = 4,     /* kNN + line/plane fit */
+  LOAMX_K_SWEEP = 5,     /* residual / Jacobian / normal equations, 56 B per plane + 72 B per edge slot */
+  LOAMX_K_LM = 6,        /* per-pair trust-region bookkeeping */
+  LOAMX_K_COUNT = 7
+};
+typedef struct {
+  uint64_t launches;
+  double total_ms;
+  double algorithmic_bytes; /* summed over launches */
+} loamx_kernel_stat;
+int loamx_ctx_enable_kernel_timing(loamx_ctx* ctx, int enable);
+int loamx_ctx_reset_kernel_stats(loamx_ctx* ctx);
+/* synchronises the stream, resolves pending events, fills stats[LOAMX_K_COUNT] */
+int loamx_ctx_get_kernel_stats(loamx_ctx* ctx, loamx_kernel_stat* stats);
+const char* loamx_kernel_name(int kernel_id);
+
+/* ---- synthetic workload generator (tests and bench only) ------------------------- */
+/* ground-truth target_T_source of pair `pair_id` */
+void loamx_synth_pair_pose(uint64_t seed, uint64_t pair_id, double pose_out[7]);
+/* host generation of one scan (which: 0 = target scan A, 1 = source scan B) */
+void loamx_synth_scan_host(uint64_t seed, uint64_t pair_id, uint32_t which, uint32_t scan_lines,
+                           uint32_t points_per_line, double sigma, double* xyz_out);
+/* device generation of n_pairs x 2 scans (target first), bit-identical to the host generator */
+int loamx_synth_scan_pairs_dev(loamx_ctx* ctx, uint64_t seed, uint64_t first_pair, size_t n_pairs,
+                               uint32_t scan_lines, uint32_t points_per_line, double sigma, double* d_xyz);
+
+/* raw device memory helpers so that hosts without torch can drive the _dev entry points */
+int loamx_dev_alloc(loamx_ctx* ctx, size_t bytes, void** d_ptr);
+int loamx_dev_free(loamx_ctx* ctx, void* d_ptr);
+int loamx_copy_to_device(loamx_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int loamx_copy_to_host(loamx_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOAMX_H_ */

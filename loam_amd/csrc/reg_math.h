@@ -1,0 +1,836 @@
+// reg_math.h — per-thread math of the registration kernels: pose algebra, exact k-NN over the
+// uniform grid index, line / plane fits, residual + Jacobian rows, and the per-pair trust-region
+// (Levenberg-Marquardt) state machine. Everything is FP64.
+//
+// The functions are __host__ __device__ so that tests/hostcheck can run the very same code on the
+// CPU (serial loops in place of kernels) and compare it with the oracle without a GPU. The product
+// only ever calls them from HIP kernels (register_kernels.hip); there is no CPU execution path in
+// libloamx.so.
+//
+// Reference behaviour restated here (paths relative to the reference repo):
+//   loam/src/geometry.cpp:10-29, :42-73        Pose3d algebra, fitLine, fitPlane
+//   loam/include/loam/geometry-inl.h:21-33     point-to-line / point-to-plane distance
+//   loam/src/kdtree.cpp:10-28                  k-NN contract (exact, ascending, strict radius)
+//   loam/src/registration.cpp:23-103           association guards
+//   loam/include/loam/registration-inl.h:28-77 outer ICF loop, Ceres solve, compose, convergence
+// Ceres 2.2.0 / Eigen / nanoflann semantics follow SURVEY.md appendices A-C.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define LOAMX_HD __host__ __device__ __forceinline__
+#else
+#include <math.h>
+#define LOAMX_HD inline
+#endif
+
+namespace loamx {
+
+constexpr int kMaxK = 8;          // upper bound on num_*_neighbors the kernels keep in registers
+constexpr double kDblMin = 2.2250738585072014e-308;
+constexpr double kDblMax = 1.7976931348623157e308;
+constexpr double kDblEps = 2.220446049250313e-16;
+
+struct Vec3 {
+  double x, y, z;
+};
+LOAMX_HD Vec3 v3(double x, double y, double z) { return Vec3{x, y, z}; }
+LOAMX_HD Vec3 vadd(Vec3 a, Vec3 b) { return Vec3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+LOAMX_HD Vec3 vsub(Vec3 a, Vec3 b) { return Vec3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+LOAMX_HD Vec3 vscale(double s, Vec3 a) { return Vec3{s * a.x, s * a.y, s * a.z}; }
+LOAMX_HD Vec3 vcross(Vec3 a, Vec3 b) {
+  return Vec3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+LOAMX_HD double vdot(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+LOAMX_HD double vnorm(Vec3 a) { return sqrt(vdot(a, a)); }
+
+// q = (x,y,z,w). Eigen: v + w*(2 u x v) + u x (2 u x v)
+LOAMX_HD Vec3 quat_rotate(const double q[4], Vec3 v) {
+  const Vec3 u = v3(q[0], q[1], q[2]);
+  Vec3 uv = vcross(u, v);
+  uv = vadd(uv, uv);
+  return vadd(vadd(v, vscale(q[3], uv)), vcross(u, uv));
+}
+LOAMX_HD void quat_mul(const double a[4], const double b[4], double o[4]) {
+  const double x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  const double y = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+  const double z = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+  const double w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+  o[0] = x, o[1] = y, o[2] = z, o[3] = w;
+}
+// Pose3d::act (geometry.cpp:21)
+LOAMX_HD Vec3 pose_act(const double P[7], Vec3 p) { return vadd(quat_rotate(P, p), v3(P[4], P[5], P[6])); }
+// Pose3d::compose (geometry.cpp:16-18): out = a (+) b
+LOAMX_HD void pose_compose(const double a[7], const double b[7], double out[7]) {
+  double q[4];
+  quat_mul(a, b, q);
+  const Vec3 t = vadd(v3(a[4], a[5], a[6]), quat_rotate(a, v3(b[4], b[5], b[6])));
+  out[0] = q[0], out[1] = q[1], out[2] = q[2], out[3] = q[3];
+  out[4] = t.x, out[5] = t.y, out[6] = t.z;
+}
+// rotation.angularDistance(Identity) (registration-inl.h:68): 2*atan2(|vec|, |w|)
+LOAMX_HD double quat_angle_to_identity(const double q[4]) {
+  return 2.0 * atan2(sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]), fabs(q[3]));
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Uniform grid index over one target feature set (replaces the nanoflann KD-tree of kdtree.h:24-41;
+ * same contract: exact k-NN). Points are stored cell by cell (x fastest), cell_start has
+ * nx*ny*nz + 1 entries.
+ * ---------------------------------------------------------------------------------------------- */
+struct GridDesc {
+  double ox, oy, oz;  // origin = bbox min
+  double h, inv_h;    // cell edge
+  int32_t nx, ny, nz;
+  uint32_t n_points;
+};
+
+LOAMX_HD int32_t grid_cell_coord(double v, double origin, double inv_h) {
+  double c = floor((v - origin) * inv_h);
+  if (c < -1048576.0) c = -1048576.0;
+  if (c > 1048576.0) c = 1048576.0;
+  return (int32_t)c;
+}
+LOAMX_HD int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// cell of a target point at build time (always inside the grid)
+LOAMX_HD uint32_t grid_cell_of_point(const GridDesc& g, Vec3 p) {
+  const int32_t ix = clampi(grid_cell_coord(p.x, g.ox, g.inv_h), 0, g.nx - 1);
+  const int32_t iy = clampi(grid_cell_coord(p.y, g.oy, g.inv_h), 0, g.ny - 1);
+  const int32_t iz = clampi(grid_cell_coord(p.z, g.oz, g.inv_h), 0, g.nz - 1);
+  return (uint32_t)((iz * g.ny + iy) * g.nx + ix);
+}
+
+constexpr uint32_t kGridCellsCap = 32768;  // cell table of one target set lives in LDS while it is built
+
+// Chooses the cell edge and grid dimensions for a target set with bounding box [lo, hi].
+// Cell edge: a quarter of the search radius, shrunk for dense sets (aim <= ~8 points per occupied
+// cell assuming surface-like data), then grown until the table fits cells_cap.
+LOAMX_HD void grid_choose(GridDesc& g, Vec3 lo, Vec3 hi, uint32_t n, double max_dist, uint32_t cells_cap) {
+  g.n_points = n;
+  if (n == 0) {
+    g.ox = g.oy = g.oz = 0.0;
+    g.h = 1.0, g.inv_h = 1.0;
+    g.nx = g.ny = g.nz = 1;
+    return;
+  }
+  const double ex = hi.x - lo.x, ey = hi.y - lo.y, ez = hi.z - lo.z;
+  const double area = 2.0 * (ex * ey + ey * ez + ex * ez);
+  double h = max_dist > 0.0 ? 0.25 * max_dist : 0.0;
+  const double h_dense = sqrt(8.0 * area / (double)n);
+  if (h_dense > 0.0 && (h <= 0.0 || h_dense < h)) h = h_dense;
+  if (!(h > 0.0)) h = 1.0;
+  if (max_dist > 0.0 && h < 1e-3 * max_dist) h = 1e-3 * max_dist;
+  int32_t nx = 1, ny = 1, nz = 1;
+  for (int it = 0; it < 400; it++) {
+    const double fx = floor(ex / h), fy = floor(ey / h), fz = floor(ez / h);
+    if (fx < 1e6 && fy < 1e6 && fz < 1e6) {
+      nx = (int32_t)fx + 1, ny = (int32_t)fy + 1, nz = (int32_t)fz + 1;
+      if ((double)nx * (double)ny * (double)nz <= (double)cells_cap) break;
+    }
+    h *= 1.1;
+  }
+  g.ox = lo.x, g.oy = lo.y, g.oz = lo.z;
+  g.h = h, g.inv_h = 1.0 / h;
+  g.nx = nx, g.ny = ny, g.nz = nz;
+}
+
+// k best neighbours, ascending by (squared distance, original index): a strict total order, so
+// the result does not depend on the storage order inside a cell.
+struct KnnResult {
+  double d2[kMaxK];
+  uint32_t pos[kMaxK];   // position in the cell-sorted arrays
+  uint32_t orig[kMaxK];  // index in the caller's target array
+  double worst;          // d2 of the k-th best once k are held, else DBL_MAX
+  int count;
+};
+
+LOAMX_HD void knn_insert(KnnResult& r, int k, double d2, uint32_t pos, uint32_t orig) {
+  // find insertion slot: first j with (d2, orig) < (r.d2[j], r.orig[j]) among the filled ones
+  int slot = r.count;
+#pragma unroll
+  for (int j = kMaxK - 1; j >= 0; j--) {
+    if (j < r.count && (d2 < r.d2[j] || (d2 == r.d2[j] && orig < r.orig[j]))) slot = j;
+  }
+  if (slot >= k) return;
+#pragma unroll
+  for (int j = kMaxK - 1; j >= 1; j--) {
+    if (j > slot && j < k) {
+      r.d2[j] = r.d2[j - 1];
+      r.pos[j] = r.pos[j - 1];
+      r.orig[j] = r.orig[j - 1];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kMaxK; j++) {
+    if (j == slot) {
+      r.d2[j] = d2;
+      r.pos[j] = pos;
+      r.orig[j] = orig;
+    }
+  }
+  if (r.count < k) r.count++;
+  if (r.count == k) {
+#pragma unroll
+    for (int j = 0; j < kMaxK; j++)
+      if (j == k - 1) r.worst = r.d2[j];
+  }
+}
+
+LOAMX_HD void knn_scan_range(KnnResult& r, int k, Vec3 q, const double* __restrict__ sx, const uint32_t* __restrict__ sorig,
+                             uint32_t begin, uint32_t end) {
+  for (uint32_t p = begin; p < end; p++) {
+    const double dx = q.x - sx[3 * p], dy = q.y - sx[3 * p + 1], dz = q.z - sx[3 * p + 2];
+    const double d2 = dx * dx + dy * dy + dz * dz;  // nanoflann L2_Simple: ((dx^2 + dy^2) + dz^2)
+    if (d2 <= r.worst) knn_insert(r, k, d2, p, sorig[p]);
+  }
+}
+
+// Exact k-NN of q among the indexed points, then the strict radius filter of kdtree.cpp:25
+// (max_dist <= 0 disables it). Returns the number of neighbours kept (prefix of r).
+LOAMX_HD int knn_search(const GridDesc& g, const uint32_t* __restrict__ cell_start, const double* __restrict__ sx,
+                        const uint32_t* __restrict__ sorig, Vec3 q, int k, double max_dist, KnnResult& r) {
+  r.count = 0;
+  r.worst = kDblMax;
+#pragma unroll
+  for (int j = 0; j < kMaxK; j++) {
+    r.d2[j] = kDblMax;
+    r.pos[j] = 0;
+    r.orig[j] = 0xFFFFFFFFu;
+  }
+  if (g.n_points == 0 || k <= 0) return 0;
+  const int32_t cx = grid_cell_coord(q.x, g.ox, g.inv_h);
+  const int32_t cy = grid_cell_coord(q.y, g.oy, g.inv_h);
+  const int32_t cz = grid_cell_coord(q.z, g.oz, g.inv_h);
+  // Chebyshev distance (in cells) from the query cell to the grid box
+  int32_t out = 0;
+  {
+    const int32_t ex = cx < 0 ? -cx : (cx > g.nx - 1 ? cx - (g.nx - 1) : 0);
+    const int32_t ey = cy < 0 ? -cy : (cy > g.ny - 1 ? cy - (g.ny - 1) : 0);
+    const int32_t ez = cz < 0 ? -cz : (cz > g.nz - 1 ? cz - (g.nz - 1) : 0);
+    out = ex > ey ? ex : ey;
+    out = out > ez ? out : ez;
+  }
+  // every point is at least (out-1)*h away: nothing can pass the radius filter
+  if (max_dist > 0.0 && out >= 1 && (double)(out - 1) * g.h >= max_dist) return 0;
+  int32_t w = out > 1 ? out : 1;
+  bool first = true;
+  for (;;) {
+    // scan the cells at Chebyshev distance <= w (first round) or == w (later rounds)
+    const int32_t z0 = clampi(cz - w, 0, g.nz - 1), z1 = clampi(cz + w, 0, g.nz - 1);
+    const int32_t y0 = clampi(cy - w, 0, g.ny - 1), y1 = clampi(cy + w, 0, g.ny - 1);
+    const int32_t x0 = cx - w, x1 = cx + w;
+    const bool z_hit = (cz + w >= 0) && (cz - w <= g.nz - 1);
+    const bool y_hit = (cy + w >= 0) && (cy - w <= g.ny - 1);
+    const bool x_hit = (x1 >= 0) && (x0 <= g.nx - 1);
+    if (z_hit && y_hit && x_hit) {
+      const int32_t xa = x0 < 0 ? 0 : x0, xb = x1 > g.nx - 1 ? g.nx - 1 : x1;
+      for (int32_t iz = z0; iz <= z1; iz++) {
+        const int32_t adz = iz > cz ? iz - cz : cz - iz;
+        for (int32_t iy = y0; iy <= y1; iy++) {
+          const int32_t ady = iy > cy ? iy - cy : cy - iy;
+          const uint32_t row = (uint32_t)((iz * g.ny + iy) * g.nx);
+          if (first || adz == w || ady == w) {
+            knn_scan_range(r, k, q, sx, sorig, cell_start[row + xa], cell_start[row + xb + 1]);
+          } else {
+            if (x0 >= 0 && x0 <= g.nx - 1) knn_scan_range(r, k, q, sx, sorig, cell_start[row + x0], cell_start[row + x0 + 1]);
+            if (x1 >= 0 && x1 <= g.nx - 1) knn_scan_range(r, k, q, sx, sorig, cell_start[row + x1], cell_start[row + x1 + 1]);
+          }
+        }
+      }
+    }
+    first = false;
+    // unscanned points are farther than (w*h) along some axis; keep a relative safety margin for
+    // the rounding in grid_cell_coord
+    const double guard = (double)w * g.h * (1.0 - 1e-9);
+    if (r.count == k && r.worst < guard * guard) break;
+    if (max_dist > 0.0 && guard >= max_dist) break;
+    if (cx - w <= 0 && cx + w >= g.nx - 1 && cy - w <= 0 && cy + w >= g.ny - 1 && cz - w <= 0 && cz + w >= g.nz - 1) break;
+    w++;
+  }
+  int kept = 0;
+#pragma unroll
+  for (int j = 0; j < kMaxK; j++) {
+    if (j < r.count && kept == j && (max_dist <= 0.0 || sqrt(r.d2[j]) < max_dist)) kept = j + 1;
+  }
+  return kept;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * fitLine (geometry.cpp:42-59): PCA direction through the centroid; the condition number the
+ * reference returns is always DBL_MAX (dead guard), so it is not computed.
+ * ---------------------------------------------------------------------------------------------- */
+LOAMX_HD void jacobi_rotate(double& app, double& aqq, double& apq, double& arp, double& arq, double& vp0, double& vp1,
+                            double& vp2, double& vq0, double& vq1, double& vq2) {
+  // annihilate apq; r is the third index. (app,aqq,apq) 2x2 block, (arp,arq) couplings.
+  if (apq == 0.0) return;
+  const double theta = (aqq - app) / (2.0 * apq);
+  const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+  const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+  const double app_n = app - t * apq, aqq_n = aqq + t * apq;
+  const double arp_n = c * arp - s * arq, arq_n = s * arp + c * arq;
+  app = app_n, aqq = aqq_n, apq = 0.0, arp = arp_n, arq = arq_n;
+  double a, b;
+  a = vp0, b = vq0, vp0 = c * a - s * b, vq0 = s * a + c * b;
+  a = vp1, b = vq1, vp1 = c * a - s * b, vq1 = s * a + c * b;
+  a = vp2, b = vq2, vp2 = c * a - s * b, vq2 = s * a + c * b;
+}
+
+LOAMX_HD void fit_line(const Vec3 pts[kMaxK], int K, Vec3& a, Vec3& b) {
+  Vec3 sum = v3(0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < kMaxK; i++)
+    if (i < K) sum = vadd(sum, pts[i]);
+  const Vec3 center = v3(sum.x / (double)K, sum.y / (double)K, sum.z / (double)K);
+  double a00 = 0, a11 = 0, a22 = 0, a01 = 0, a02 = 0, a12 = 0;
+#pragma unroll
+  for (int i = 0; i < kMaxK; i++) {
+    if (i < K) {
+      const Vec3 d = vsub(pts[i], center);
+      a00 += d.x * d.x, a11 += d.y * d.y, a22 += d.z * d.z;
+      a01 += d.x * d.y, a02 += d.x * d.z, a12 += d.y * d.z;
+    }
+  }
+  // cyclic Jacobi; columns of V are eigenvectors
+  double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
+  for (int sweep = 0; sweep < 32; sweep++) {
+    if (a01 == 0.0 && a02 == 0.0 && a12 == 0.0) break;
+    jacobi_rotate(a00, a11, a01, a02, a12, v00, v10, v20, v01, v11, v21);  // (p,q,r) = (0,1,2)
+    jacobi_rotate(a00, a22, a02, a01, a12, v00, v10, v20, v02, v12, v22);  // (0,2,1)
+    jacobi_rotate(a11, a22, a12, a01, a02, v01, v11, v21, v02, v12, v22);  // (1,2,0)
+  }
+  Vec3 dir = v3(v00, v10, v20);
+  double best = a00;
+  if (a11 > best) best = a11, dir = v3(v01, v11, v21);
+  if (a22 > best) best = a22, dir = v3(v02, v12, v22);
+  a = vadd(center, vscale(0.1, dir));  // geometry.cpp:53
+  b = vsub(center, vscale(0.1, dir));
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * fitPlane (geometry.cpp:62-73): least squares P * abc = 1 by column-pivoted Householder QR
+ * (Eigen ColPivHouseholderQR semantics incl. its near-zero pivot cut-off), n = abc/|abc|,
+ * d = 1/|abc|, returns the signed mean of P n - d.
+ * ---------------------------------------------------------------------------------------------- */
+LOAMX_HD double fit_plane(const Vec3 pts[kMaxK], int K, Vec3& normal, double& d_out) {
+  double c0[kMaxK], c1[kMaxK], c2[kMaxK];  // columns of the K x 3 matrix
+#pragma unroll
+  for (int r = 0; r < kMaxK; r++) {
+    c0[r] = r < K ? pts[r].x : 0.0;
+    c1[r] = r < K ? pts[r].y : 0.0;
+    c2[r] = r < K ? pts[r].z : 0.0;
+  }
+  double nu0 = 0, nu1 = 0, nu2 = 0;
+#pragma unroll
+  for (int r = 0; r < kMaxK; r++) nu0 += c0[r] * c0[r], nu1 += c1[r] * c1[r], nu2 += c2[r] * c2[r];
+  nu0 = sqrt(nu0), nu1 = sqrt(nu1), nu2 = sqrt(nu2);
+  double nd0 = nu0, nd1 = nu1, nd2 = nu2;
+  double maxn = nu0 > nu1 ? nu0 : nu1;
+  maxn = maxn > nu2 ? maxn : nu2;
+  const double threshold_helper = (maxn * kDblEps) * (maxn * kDblEps) / (double)K;
+  const double downdate_thr = 1.4901161193847656e-08;  // sqrt(eps)
+  int p0 = 0, p1 = 1, p2 = 2;  // column permutation: physical column j holds original column pj
+  int nonzero_pivots = 3;
+  double tau0 = 0, tau1 = 0, tau2 = 0;
+
+#define LOAMX_SWAP(a_, b_) { double t_ = a_; a_ = b_; b_ = t_; }
+#define LOAMX_SWAPCOL(ca, cb) { _Pragma("unroll") for (int r_ = 0; r_ < kMaxK; r_++) LOAMX_SWAP(ca[r_], cb[r_]) }
+  // ---- k = 0
+  {
+    int big = 0;
+    double bn = nu0;
+    if (nu1 > bn) big = 1, bn = nu1;
+    if (nu2 > bn) big = 2, bn = nu2;
+    if (nonzero_pivots == 3 && bn * bn < threshold_helper * (double)(K - 0)) nonzero_pivots = 0;
+    if (big == 1) { LOAMX_SWAPCOL(c0, c1) LOAMX_SWAP(nu0, nu1) LOAMX_SWAP(nd0, nd1) int t = p0; p0 = p1; p1 = t; }
+    if (big == 2) { LOAMX_SWAPCOL(c0, c2) LOAMX_SWAP(nu0, nu2) LOAMX_SWAP(nd0, nd2) int t = p0; p0 = p2; p2 = t; }
+    double tail = 0;
+#pragma unroll
+    for (int r = 1; r < kMaxK; r++) tail += c0[r] * c0[r];
+    const double x0 = c0[0];
+    double beta;
+    if (tail <= kDblMin) {
+      tau0 = 0, beta = x0;
+#pragma unroll
+      for (int r = 1; r < kMaxK; r++) c0[r] = 0;
+    } else {
+      beta = sqrt(x0 * x0 + tail);
+      if (x0 >= 0) beta = -beta;
+#pragma unroll
+      for (int r = 1; r < kMaxK; r++) c0[r] = c0[r] / (x0 - beta);
+      tau0 = (beta - x0) / beta;
+    }
+    c0[0] = beta;
+    if (tau0 != 0) {
+      double t1 = c1[0], t2 = c2[0];
+#pragma unroll
+      for (int r = 1; r < kMaxK; r++) t1 += c0[r] * c1[r], t2 += c0[r] * c2[r];
+      c1[0] -= tau0 * t1, c2[0] -= tau0 * t2;
+#pragma unroll
+      for (int r = 1; r < kMaxK; r++) c1[r] -= tau0 * c0[r] * t1, c2[r] -= tau0 * c0[r] * t2;
+    }
+    // norm down-dating for columns 1, 2
+    if (nu1 != 0) {
+      double temp = fabs(c1[0]) / nu1;
+      temp = (1.0 + temp) * (1.0 - temp);
+      temp = temp < 0 ? 0 : temp;
+      const double ratio = nu1 / nd1;
+      if (temp * ratio * ratio <= downdate_thr) {
+        double s = 0;
+#pragma unroll
+        for (int r = 1; r < kMaxK; r++) s += c1[r] * c1[r];
+        nd1 = sqrt(s), nu1 = nd1;
+      } else {
+        nu1 *= sqrt(temp);
+      }
+    }
+    if (nu2 != 0) {
+      double temp = fabs(c2[0]) / nu2;
+      temp = (1.0 + temp) * (1.0 - temp);
+      temp = temp < 0 ? 0 : temp;
+      const double ratio = nu2 / nd2;
+      if (temp * ratio * ratio <= downdate_thr) {
+        double s = 0;
+#pragma unroll
+        for (int r = 1; r < kMaxK; r++) s += c2[r] * c2[r];
+        nd2 = sqrt(s), nu2 = nd2;
+      } else {
+        nu2 *= sqrt(temp);
+      }
+    }
+  }
+  // ---- k = 1
+  {
+    int big = 1;
+    double bn = nu1;
+    if (nu2 > bn) big = 2, bn = nu2;
+    if (nonzero_pivots == 3 && bn * bn < threshold_helper * (double)(K - 1)) nonzero_pivots = 1;
+    if (big == 2) { LOAMX_SWAPCOL(c1, c2) LOAMX_SWAP(nu1, nu2) LOAMX_SWAP(nd1, nd2) int t = p1; p1 = p2; p2 = t; }
+    double tail = 0;
+#pragma unroll
+    for (int r = 2; r < kMaxK; r++) tail += c1[r] * c1[r];
+    const double x0 = c1[1];
+    double beta;
+    if (tail <= kDblMin) {
+      tau1 = 0, beta = x0;
+#pragma unroll
+      for (int r = 2; r < kMaxK; r++) c1[r] = 0;
+    } else {
+      beta = sqrt(x0 * x0 + tail);
+      if (x0 >= 0) beta = -beta;
+#pragma unroll
+      for (int r = 2; r < kMaxK; r++) c1[r] = c1[r] / (x0 - beta);
+      tau1 = (beta - x0) / beta;
+    }
+    c1[1] = beta;
+    if (tau1 != 0) {
+      double t2 = c2[1];
+#pragma unroll
+      for (int r = 2; r < kMaxK; r++) t2 += c1[r] * c2[r];
+      c2[1] -= tau1 * t2;
+#pragma unroll
+      for (int r = 2; r < kMaxK; r++) c2[r] -= tau1 * c1[r] * t2;
+    }
+    if (nu2 != 0) {
+      double temp = fabs(c2[1]) / nu2;
+      temp = (1.0 + temp) * (1.0 - temp);
+      temp = temp < 0 ? 0 : temp;
+      const double ratio = nu2 / nd2;
+      if (temp * ratio * ratio <= downdate_thr) {
+        double s = 0;
+#pragma unroll
+        for (int r = 2; r < kMaxK; r++) s += c2[r] * c2[r];
+        nd2 = sqrt(s), nu2 = nd2;
+      } else {
+        nu2 *= sqrt(temp);
+      }
+    }
+  }
+  // ---- k = 2
+  {
+    if (nonzero_pivots == 3 && nu2 * nu2 < threshold_helper * (double)(K - 2)) nonzero_pivots = 2;
+    double tail = 0;
+#pragma unroll
+    for (int r = 3; r < kMaxK; r++) tail += c2[r] * c2[r];
+    const double x0 = c2[2];
+    double beta;
+    if (tail <= kDblMin) {
+      tau2 = 0, beta = x0;
+#pragma unroll
+      for (int r = 3; r < kMaxK; r++) c2[r] = 0;
+    } else {
+      beta = sqrt(x0 * x0 + tail);
+      if (x0 >= 0) beta = -beta;
+#pragma unroll
+      for (int r = 3; r < kMaxK; r++) c2[r] = c2[r] / (x0 - beta);
+      tau2 = (beta - x0) / beta;
+    }
+    c2[2] = beta;
+  }
+#undef LOAMX_SWAPCOL
+#undef LOAMX_SWAP
+  // ---- solve: c = Q^T * ones (first nonzero_pivots reflectors), back substitution, un-permute.
+  // Rows >= K of the zero-padded columns are zero, so they never contribute.
+  double rhs[kMaxK];
+#pragma unroll
+  for (int r = 0; r < kMaxK; r++) rhs[r] = r < K ? 1.0 : 0.0;
+  if (nonzero_pivots > 0 && tau0 != 0) {
+    double t = rhs[0];
+#pragma unroll
+    for (int r = 1; r < kMaxK; r++) t += c0[r] * rhs[r];
+    rhs[0] -= tau0 * t;
+#pragma unroll
+    for (int r = 1; r < kMaxK; r++) rhs[r] -= tau0 * c0[r] * t;
+  }
+  if (nonzero_pivots > 1 && tau1 != 0) {
+    double t = rhs[1];
+#pragma unroll
+    for (int r = 2; r < kMaxK; r++) t += c1[r] * rhs[r];
+    rhs[1] -= tau1 * t;
+#pragma unroll
+    for (int r = 2; r < kMaxK; r++) rhs[r] -= tau1 * c1[r] * t;
+  }
+  if (nonzero_pivots > 2) {
+    if (K - 2 == 1) {
+      rhs[2] *= (1.0 - tau2);
+    } else if (tau2 != 0) {
+      double t = rhs[2];
+#pragma unroll
+      for (int r = 3; r < kMaxK; r++) t += c2[r] * rhs[r];
+      rhs[2] -= tau2 * t;
+    }
+  }
+  // R = [[c0[0], c1[0], c2[0]], [0, c1[1], c2[1]], [0, 0, c2[2]]]
+  double y0 = 0, y1 = 0, y2 = 0;
+  if (nonzero_pivots > 2) y2 = rhs[2] / c2[2];
+  if (nonzero_pivots > 1) y1 = (rhs[1] - c2[1] * y2) / c1[1];
+  if (nonzero_pivots > 0) y0 = (rhs[0] - c1[0] * y1 - c2[0] * y2) / c0[0];
+  double abc[3] = {0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    if (p0 == j) abc[j] = y0;
+    if (p1 == j) abc[j] = y1;
+    if (p2 == j) abc[j] = y2;
+  }
+  const double n = sqrt(abc[0] * abc[0] + abc[1] * abc[1] + abc[2] * abc[2]);
+  normal = v3(abc[0] / n, abc[1] / n, abc[2] / n);
+  d_out = 1.0 / n;
+  double sum = 0;
+#pragma unroll
+  for (int r = 0; r < kMaxK; r++)
+    if (r < K) sum += (pts[r].x * normal.x + pts[r].y * normal.y + pts[r].z * normal.z) - d_out;
+  return sum / (double)K;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * One residual block: value, tangent Jacobian row (1x6), Huber(1.0) corrected, accumulated into the
+ * normal equations. acc[0..20] = upper triangle of J^T J (row-major: 00 01 .. 05 11 12 ..),
+ * acc[21..26] = J^T f, acc[27] = cost, acc[28] = number of non-finite evaluations.
+ * x = ambient update (qx,qy,qz,qw,tx,ty,tz); p = the already moved source point.
+ * Edge: prim = a(3), b(3) (registration-inl.h:92-103); plane: prim = n(3), d (registration-inl.h:106-117).
+ * ---------------------------------------------------------------------------------------------- */
+constexpr int kAccSize = 29;
+
+LOAMX_HD void residual_accumulate(bool is_plane, Vec3 v, const double prim[6], const double x[7], double acc[kAccSize]) {
+  const Vec3 u = v3(x[0], x[1], x[2]);
+  const double w = x[3];
+  Vec3 uv = vcross(u, v);
+  uv = vadd(uv, uv);
+  const Vec3 pp = vadd(vadd(vadd(v, vscale(w, uv)), vcross(u, uv)), v3(x[4], x[5], x[6]));
+  Vec3 g;
+  double r;
+  if (is_plane) {
+    const Vec3 n = v3(prim[0], prim[1], prim[2]);
+    const double s = vdot(n, pp) - prim[3];
+    r = fabs(s);
+    g = vscale(copysign(1.0, s), n);  // Jet abs: copysign(1, s)
+  } else {
+    const Vec3 a = v3(prim[0], prim[1], prim[2]), b = v3(prim[3], prim[4], prim[5]);
+    const Vec3 c = vcross(vsub(pp, a), vsub(pp, b));
+    const double cn = vnorm(c);
+    const Vec3 ab = vsub(a, b);
+    const double den = vnorm(ab);
+    r = cn / den;
+    g = vscale(1.0 / (cn * den), vcross(ab, c));
+  }
+  // ambient Jacobian wrt (ux,uy,uz,w), then Ceres QuaternionManifold::PlusJacobian applied to the
+  // Eigen-ordered storage: rows indexed by storage slot, read as (W,X,Y,Z)
+  const double udv = vdot(u, v);
+  // M = -2w[v]x + 2(u.v)I + 2 u v^T - 4 v u^T ; amb_j = g^T M[:,j]
+  const double gu = vdot(g, u), gv = vdot(g, v);
+  const Vec3 vxg = vcross(v, g);  // g^T [v]x = (g x v)^T  =>  g^T (-2w [v]x) = 2w (v x g)^T
+  const double amb0 = 2.0 * w * vxg.x + 2.0 * udv * g.x + 2.0 * gu * v.x - 4.0 * gv * u.x;
+  const double amb1 = 2.0 * w * vxg.y + 2.0 * udv * g.y + 2.0 * gu * v.y - 4.0 * gv * u.y;
+  const double amb2 = 2.0 * w * vxg.z + 2.0 * udv * g.z + 2.0 * gu * v.z - 4.0 * gv * u.z;
+  const double amb3 = 2.0 * vdot(g, vcross(u, v));
+  const double W = x[0], X = x[1], Y = x[2], Z = x[3];
+  double J[6];
+  J[0] = amb0 * (-X) + amb1 * W + amb2 * (-Z) + amb3 * Y;
+  J[1] = amb0 * (-Y) + amb1 * Z + amb2 * W + amb3 * (-X);
+  J[2] = amb0 * (-Z) + amb1 * (-Y) + amb2 * X + amb3 * W;
+  J[3] = g.x, J[4] = g.y, J[5] = g.z;
+  bool finite = (r - r == 0.0);
+#pragma unroll
+  for (int j = 0; j < 6; j++) finite = finite && (J[j] - J[j] == 0.0);
+  if (!finite) {
+    acc[28] += 1.0;
+    return;
+  }
+  // HuberLoss(1.0) + Corrector (rho'' <= 0 => scale residual and Jacobian by sqrt(rho'))
+  const double s2 = r * r;
+  double rho0 = s2, rho1 = 1.0;
+  if (s2 > 1.0) {
+    const double sr = sqrt(s2);
+    rho0 = 2.0 * sr - 1.0;
+    rho1 = 1.0 / sr;
+    if (rho1 < kDblMin) rho1 = kDblMin;
+  }
+  const double sc = sqrt(rho1);
+  const double f = r * sc;
+#pragma unroll
+  for (int j = 0; j < 6; j++) J[j] *= sc;
+  int t = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+#pragma unroll
+    for (int j = i; j < 6; j++) acc[t++] += J[i] * J[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 6; j++) acc[21 + j] += J[j] * f;
+  acc[27] += 0.5 * rho0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Ceres manifold Plus for the 7 ambient doubles (QuaternionManifold on raw storage read as
+ * (W,X,Y,Z), EuclideanManifold<3>)
+ * ---------------------------------------------------------------------------------------------- */
+LOAMX_HD void manifold_plus(const double x[7], const double delta[6], double out[7]) {
+  const double nd = sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
+  if (nd == 0.0) {
+    out[0] = x[0], out[1] = x[1], out[2] = x[2], out[3] = x[3];
+  } else {
+    const double sbd = sin(nd) / nd;
+    const double z0 = cos(nd), z1 = sbd * delta[0], z2 = sbd * delta[1], z3 = sbd * delta[2];
+    out[0] = z0 * x[0] - z1 * x[1] - z2 * x[2] - z3 * x[3];
+    out[1] = z0 * x[1] + z1 * x[0] + z2 * x[3] - z3 * x[2];
+    out[2] = z0 * x[2] - z1 * x[3] + z2 * x[0] + z3 * x[1];
+    out[3] = z0 * x[3] + z1 * x[2] - z2 * x[1] + z3 * x[0];
+  }
+  out[4] = x[4] + delta[3], out[5] = x[5] + delta[4], out[6] = x[6] + delta[5];
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-pair trust-region state (Ceres 2.2.0 TrustRegionMinimizer + LevenbergMarquardtStrategy with
+ * DENSE_QR replaced by the algebraically identical damped normal equations on the 6x6 system).
+ * One sweep = evaluation of cost / J^T J / J^T f at `xeval`; lm_begin / lm_step consume a sweep
+ * and either publish the next point to evaluate or finish.
+ * ---------------------------------------------------------------------------------------------- */
+struct LmState {
+  double x[7];       // current accepted point
+  double x_user[7];  // what the caller's parameter blocks hold (updated by successful steps)
+  double xeval[7];   // point the next sweep evaluates
+  double H[21], g[6];
+  double x_cost, minimum_cost, x_norm;
+  double scaling[6], diagonal[6];
+  double radius, decrease_factor;
+  double model_cost_change;
+  int32_t iteration;
+  int32_t num_invalid;
+  int32_t reuse_diagonal;
+  int32_t active;  // 1 while more sweeps are needed
+};
+
+LOAMX_HD double sym_at(const double H[21], int i, int j) {
+  if (i > j) {
+    const int t = i;
+    i = j;
+    j = t;
+  }
+  // offset of row i in the packed upper triangle: i*6 - i*(i-1)/2
+  return H[i * 6 - (i * (i - 1)) / 2 + (j - i)];
+}
+
+// Solve (S H S + D^2) y = S g by Cholesky; returns false if not positive definite / non-finite.
+LOAMX_HD bool lm_solve6(const double H[21], const double g[6], const double scaling[6], const double d2[6], double y[6]) {
+  double A[6][6], b[6];
+  for (int i = 0; i < 6; i++) {
+    for (int j = 0; j < 6; j++) A[i][j] = scaling[i] * sym_at(H, i, j) * scaling[j];
+    A[i][i] += d2[i];
+    b[i] = scaling[i] * g[i];
+  }
+  for (int j = 0; j < 6; j++) {
+    double s = A[j][j];
+    for (int k = 0; k < j; k++) s -= A[j][k] * A[j][k];
+    if (!(s > 0.0)) return false;
+    const double l = sqrt(s);
+    A[j][j] = l;
+    for (int i = j + 1; i < 6; i++) {
+      double t = A[i][j];
+      for (int k = 0; k < j; k++) t -= A[i][k] * A[j][k];
+      A[i][j] = t / l;
+    }
+  }
+  for (int i = 0; i < 6; i++) {
+    double t = b[i];
+    for (int k = 0; k < i; k++) t -= A[i][k] * y[k];
+    y[i] = t / A[i][i];
+  }
+  for (int i = 5; i >= 0; i--) {
+    double t = y[i];
+    for (int k = i + 1; k < 6; k++) t -= A[k][i] * y[k];
+    y[i] = t / A[i][i];
+  }
+  for (int i = 0; i < 6; i++)
+    if (!(y[i] - y[i] == 0.0)) return false;
+  return true;
+}
+
+// Runs trust-region iterations that need no new evaluation (invalid steps) until it can publish a
+// candidate in st.xeval (returns true) or the solve is over (returns false).
+LOAMX_HD bool lm_propose(LmState& st) {
+  const int max_num_iterations = 4;
+  for (;;) {
+    // FinalizeIterationAndCheckIfMinimizerCanContinue (the successful-step bookkeeping is done by
+    // the caller before it gets here)
+    if (st.iteration >= max_num_iterations) return false;
+    if (st.radius <= 1e-32) return false;
+    st.iteration++;
+    // LevenbergMarquardtStrategy::ComputeStep on the column-scaled Jacobian
+    if (!st.reuse_diagonal) {
+      for (int j = 0; j < 6; j++) {
+        double d = st.scaling[j] * sym_at(st.H, j, j) * st.scaling[j];
+        d = d < 1e-6 ? 1e-6 : d;
+        d = d > 1e32 ? 1e32 : d;
+        st.diagonal[j] = d;
+      }
+    }
+    double d2[6], y[6];
+    for (int j = 0; j < 6; j++) d2[j] = st.diagonal[j] / st.radius;  // lm_diagonal^2
+    const bool solved = lm_solve6(st.H, st.g, st.scaling, d2, y);
+    st.reuse_diagonal = 1;
+    bool valid = false;
+    double step[6];
+    if (solved) {
+      for (int j = 0; j < 6; j++) step[j] = -y[j];
+      // model_cost_change = -(J step)^T (f + J step / 2) = -step^T S g - step^T S H S step / 2
+      double lin = 0, quad = 0;
+      for (int i = 0; i < 6; i++) {
+        lin += step[i] * st.scaling[i] * st.g[i];
+        double row = 0;
+        for (int j = 0; j < 6; j++) row += st.scaling[i] * sym_at(st.H, i, j) * st.scaling[j] * step[j];
+        quad += step[i] * row;
+      }
+      st.model_cost_change = -lin - 0.5 * quad;
+      valid = st.model_cost_change > 0.0;
+    }
+    if (!valid) {
+      if (++st.num_invalid >= 5) return false;
+      st.radius *= 0.5;  // LM StepIsInvalid
+      st.reuse_diagonal = 0;
+      continue;
+    }
+    st.num_invalid = 0;
+    double delta[6];
+    for (int j = 0; j < 6; j++) delta[j] = step[j] * st.scaling[j];
+    manifold_plus(st.x, delta, st.xeval);
+    return true;
+  }
+}
+
+LOAMX_HD void lm_init(LmState& st) {
+  for (int i = 0; i < 7; i++) st.x[i] = st.x_user[i] = st.xeval[i] = (i == 3) ? 1.0 : 0.0;  // Pose3d() identity
+  st.radius = 1e4, st.decrease_factor = 2.0;
+  st.iteration = 0, st.num_invalid = 0, st.reuse_diagonal = 0, st.active = 1;
+  st.x_cost = 0, st.minimum_cost = 0, st.x_norm = 1.0, st.model_cost_change = 0;
+  for (int j = 0; j < 6; j++) st.scaling[j] = 1.0, st.diagonal[j] = 0.0, st.g[j] = 0.0;
+  for (int j = 0; j < 21; j++) st.H[j] = 0.0;
+}
+
+LOAMX_HD double gradient_max_norm(const LmState& st) {
+  double neg[6], xp[7];
+  for (int j = 0; j < 6; j++) neg[j] = -st.g[j];
+  manifold_plus(st.x, neg, xp);
+  double m = 0;
+  for (int i = 0; i < 7; i++) {
+    const double a = fabs(st.x[i] - xp[i]);
+    m = a > m ? a : m;
+  }
+  return m;
+}
+
+// Consume the sweep at xeval. `first` = this was the iteration-0 evaluation at the identity.
+// acc layout as residual_accumulate. Sets st.active = 0 when the solve is over.
+LOAMX_HD void lm_consume(LmState& st, const double acc[kAccSize], bool first) {
+  const bool eval_ok = (acc[28] == 0.0);
+  if (first) {
+    if (!eval_ok) {  // "Initial residual and Jacobian evaluation failed": parameters untouched
+      st.active = 0;
+      return;
+    }
+    for (int j = 0; j < 21; j++) st.H[j] = acc[j];
+    for (int j = 0; j < 6; j++) st.g[j] = acc[21 + j];
+    st.x_cost = acc[27];
+    st.minimum_cost = st.x_cost;
+    for (int j = 0; j < 6; j++) st.scaling[j] = 1.0 / (1.0 + sqrt(sym_at(st.H, j, j)));  // jacobi scaling, once
+    st.active = lm_propose(st) ? 1 : 0;
+    return;
+  }
+  const double cand_cost = eval_ok ? acc[27] : kDblMax;
+  // ParameterToleranceReached: candidate discarded
+  double step_norm = 0;
+  for (int i = 0; i < 7; i++) step_norm += (st.x[i] - st.xeval[i]) * (st.x[i] - st.xeval[i]);
+  step_norm = sqrt(step_norm);
+  if (step_norm <= 1e-8 * (st.x_norm + 1e-8)) {
+    st.active = 0;
+    return;
+  }
+  // FunctionToleranceReached: candidate discarded
+  if (fabs(st.x_cost - cand_cost) <= 1e-6 * st.x_cost) {
+    st.active = 0;
+    return;
+  }
+  const double relative_decrease = (st.x_cost - cand_cost) / st.model_cost_change;
+  if (relative_decrease > 1e-3) {
+    // HandleSuccessfulStep: the sweep already holds J^T J, J^T f at the candidate
+    for (int i = 0; i < 7; i++) st.x[i] = st.xeval[i];
+    double n2 = 0;
+    for (int i = 0; i < 7; i++) n2 += st.x[i] * st.x[i];
+    st.x_norm = sqrt(n2);
+    // (a non-finite Jacobian at an accepted candidate would have made cand_cost = DBL_MAX above)
+    for (int j = 0; j < 21; j++) st.H[j] = acc[j];
+    for (int j = 0; j < 6; j++) st.g[j] = acc[21 + j];
+    st.x_cost = acc[27];
+    double q = 2.0 * relative_decrease - 1.0;
+    q = 1.0 - q * q * q;
+    st.radius = st.radius / (q > 1.0 / 3.0 ? q : 1.0 / 3.0);
+    st.radius = st.radius < 1e16 ? st.radius : 1e16;
+    st.decrease_factor = 2.0;
+    st.reuse_diagonal = 0;
+    // Finalize: publish to the user's parameter blocks
+    if (st.x_cost < st.minimum_cost) {
+      st.minimum_cost = st.x_cost;
+      for (int i = 0; i < 7; i++) st.x_user[i] = st.x[i];
+    }
+    if (st.iteration < 4 && gradient_max_norm(st) <= 1e-10) {
+      st.active = 0;
+      return;
+    }
+  } else {
+    st.radius = st.radius / st.decrease_factor;  // StepRejected
+    st.decrease_factor *= 2.0;
+    st.reuse_diagonal = 1;
+  }
+  st.active = lm_propose(st) ? 1 : 0;
+}
+
+// registration-inl.h:63-73: est <- update (+) est; converged iff the update is small.
+LOAMX_HD bool outer_update(double est[7], const double update[7], double rot_thresh, double pos_thresh) {
+  double next[7];
+  pose_compose(update, est, next);
+  for (int i = 0; i < 7; i++) est[i] = next[i];
+  const double angle_change = quat_angle_to_identity(update);
+  const double position_change = sqrt(update[4] * update[4] + update[5] * update[5] + update[6] * update[6]);
+  return angle_change < rot_thresh && position_change < pos_thresh;
+}
+
+}  // namespace loamx

@@ -1,0 +1,280 @@
+// hostcheck.cpp — TEST-ONLY serial emulation of the HIP kernels' per-thread math on the CPU.
+//
+// It includes the product's __host__ __device__ headers (extract_math.h, reg_math.h, synth.h) and
+// replaces each kernel's thread grid / wave reduction by plain loops, so that the arithmetic the
+// GPU will execute can be compared with the oracle in this GPU-less container. It is built only by
+// tests/ (tests/hostcheck/Makefile), is never linked into libloamx.so and is not a product path.
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/loamx.h"
+#include "../../loam_amd/csrc/extract_math.h"
+#include "../../loam_amd/csrc/reg_math.h"
+#include "../../loam_amd/csrc/synth.h"
+
+using namespace loamx;
+
+static ExtractParams make_params(uint64_t H, uint64_t W, double rmin, double rmax, const loamx_fe_params* fe) {
+  ExtractParams P{};
+  P.H = (uint32_t)H, P.W = (uint32_t)W, P.np = (uint32_t)fe->neighbor_points, P.S = (uint32_t)fe->number_sectors;
+  P.pps = P.S ? P.W / P.S : 0;
+  P.max_edge = (uint32_t)fe->max_edge_feats_per_sector, P.max_planar = (uint32_t)fe->max_planar_feats_per_sector;
+  P.min_range = rmin, P.max_range = rmax;
+  P.edge_thr = fe->edge_feat_threshold, P.planar_thr = fe->planar_feat_threshold;
+  P.occ_thr = fe->occlusion_thresh, P.par_thr = fe->parallel_thresh;
+  return P;
+}
+
+extern "C" {
+
+// curvature + validity exactly as curvature_valid_kernel computes them
+int hostcheck_curvature_valid(const double* xyz, uint64_t H, uint64_t W, double rmin, double rmax,
+                              const loamx_fe_params* fe, double* curv, uint8_t* mask) {
+  const ExtractParams P = make_params(H, W, rmin, rmax, fe);
+  std::vector<double> r(W);
+  std::vector<uint8_t> code(W);
+  for (uint64_t line = 0; line < H; line++) {
+    const double* p = xyz + line * W * 3;
+    for (uint32_t c = 0; c < W; c++) r[c] = point_range(p[3 * c], p[3 * c + 1], p[3 * c + 2]);
+    for (uint32_t c = 0; c < W; c++)
+      code[c] = is_line_end(c, P.W, P.np) ? (uint8_t)kCodeNone : point_code(r[c - 1], r[c], r[c + 1], P);
+    for (uint32_t c = 0; c < W; c++) {
+      curv[line * W + c] = is_line_end(c, P.W, P.np) ? -1.0 : curvature_at(p, (int)c, P.np);
+      mask[line * W + c] = valid_from_codes(code.data(), (int)c, c, P.W, P.np) ? 1 : 0;
+    }
+  }
+  return 0;
+}
+
+// per-sector greedy selection exactly as select_kernel does it (repeated arg-max / arg-min under
+// the total order of extract_math.h, suppression of +-(np-1))
+int hostcheck_select(const double* curv, const uint8_t* mask_in, uint64_t H, uint64_t W, const loamx_fe_params* fe,
+                     uint32_t* edge_idx, uint64_t* n_edge, uint32_t* planar_idx, uint64_t* n_planar) {
+  const ExtractParams P = make_params(H, W, 0, 0, fe);
+  uint64_t ne = 0, npl = 0;
+  std::vector<uint8_t> valid(W);
+  for (uint64_t line = 0; line < H; line++) {
+    const double* c = curv + line * W;
+    for (uint32_t i = 0; i < W; i++) valid[i] = mask_in[line * W + i];
+    for (uint32_t s = 0; s < P.S; s++) {
+      const uint32_t start = s * P.pps, end = (s == P.S - 1) ? P.W : start + P.pps;
+      for (int pass = 0; pass < 2; pass++) {
+        const uint32_t maxf = pass == 0 ? P.max_edge : P.max_planar;
+        uint32_t n = 0;
+        for (;;) {
+          int32_t best = -1;
+          double bc = 0;
+          for (uint32_t i = start; i < end; i++) {
+            if (!valid[i]) continue;
+            if (pass == 0 ? !(c[i] > P.edge_thr) : !(c[i] < P.planar_thr)) continue;
+            if (best < 0 || (pass == 0 ? edge_before(c[i], (int32_t)i, bc, best) : planar_before(c[i], (int32_t)i, bc, best)))
+              best = (int32_t)i, bc = c[i];
+          }
+          if (best < 0) break;
+          if (pass == 0)
+            edge_idx[ne++] = (uint32_t)(line * W + best);
+          else
+            planar_idx[npl++] = (uint32_t)(line * W + best);
+          for (uint32_t k = 0; k < P.np; k++) valid[best + k] = 0, valid[best - k] = 0;
+          n++;
+          if (n > maxf) break;
+        }
+      }
+    }
+  }
+  *n_edge = ne, *n_planar = npl;
+  return 0;
+}
+
+/* ---- registration ------------------------------------------------------------------------------ */
+struct HostGrid {
+  GridDesc g;
+  std::vector<uint32_t> cell_start;
+  std::vector<double> sx;
+  std::vector<uint32_t> sorig;
+};
+
+static void build_grid(const double* pts, uint32_t n, double max_dist, HostGrid& G) {
+  Vec3 lo = v3(0, 0, 0), hi = v3(0, 0, 0);
+  for (uint32_t i = 0; i < n; i++) {
+    const Vec3 p = v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    if (i == 0) lo = hi = p;
+    lo = v3(std::min(lo.x, p.x), std::min(lo.y, p.y), std::min(lo.z, p.z));
+    hi = v3(std::max(hi.x, p.x), std::max(hi.y, p.y), std::max(hi.z, p.z));
+  }
+  grid_choose(G.g, lo, hi, n, max_dist, kGridCellsCap);
+  const uint32_t ncell = (uint32_t)(G.g.nx * G.g.ny * G.g.nz);
+  G.cell_start.assign(ncell + 1, 0);
+  std::vector<uint32_t> cell(n);
+  for (uint32_t i = 0; i < n; i++) {
+    cell[i] = grid_cell_of_point(G.g, v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
+    G.cell_start[cell[i] + 1]++;
+  }
+  for (uint32_t c = 0; c < ncell; c++) G.cell_start[c + 1] += G.cell_start[c];
+  std::vector<uint32_t> cursor(G.cell_start.begin(), G.cell_start.end() - 1);
+  G.sx.resize(3 * (size_t)n);
+  G.sorig.resize(n);
+  // fill in reverse original order: the GPU fill order is arbitrary (atomics); the search result
+  // must not depend on it
+  for (uint32_t k = n; k-- > 0;) {
+    const uint32_t pos = cursor[cell[k]]++;
+    G.sx[3 * pos] = pts[3 * k], G.sx[3 * pos + 1] = pts[3 * k + 1], G.sx[3 * pos + 2] = pts[3 * k + 2];
+    G.sorig[pos] = k;
+  }
+}
+
+uint64_t hostcheck_knn(const double* pts, uint64_t n, const double q[3], uint64_t k, double max_dist, uint64_t* idx_out) {
+  HostGrid G;
+  build_grid(pts, (uint32_t)n, max_dist, G);
+  KnnResult r;
+  const int kept = knn_search(G.g, G.cell_start.data(), G.sx.data(), G.sorig.data(), v3(q[0], q[1], q[2]), (int)k,
+                              max_dist, r);
+  for (int j = 0; j < kept; j++) idx_out[j] = r.orig[j];
+  return (uint64_t)kept;
+}
+
+double hostcheck_fit_plane(const double* pts, uint64_t k, double out[4]) {
+  Vec3 P[kMaxK];
+  for (uint64_t i = 0; i < k; i++) P[i] = v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+  Vec3 n;
+  double d;
+  const double avg = fit_plane(P, (int)k, n, d);
+  out[0] = n.x, out[1] = n.y, out[2] = n.z, out[3] = d;
+  return avg;
+}
+void hostcheck_fit_line(const double* pts, uint64_t k, double out[6]) {
+  Vec3 P[kMaxK];
+  for (uint64_t i = 0; i < k; i++) P[i] = v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+  Vec3 a, b;
+  fit_line(P, (int)k, a, b);
+  out[0] = a.x, out[1] = a.y, out[2] = a.z, out[3] = b.x, out[4] = b.y, out[5] = b.z;
+}
+
+struct Slot {
+  bool valid;
+  Vec3 p;
+  double prim[6];
+  uint32_t nearest;
+};
+
+static uint32_t associate(const double* src, uint32_t n_src, const double* tgt, const HostGrid& G, const double est[7],
+                          bool is_plane, const loamx_reg_params* prm, std::vector<Slot>& slots) {
+  const int k = (int)(is_plane ? prm->num_plane_neighbors : prm->num_edge_neighbors);
+  const double maxd = is_plane ? prm->max_plane_neighbor_dist : prm->max_edge_neighbor_dist;
+  const int minfit = (int)(is_plane ? prm->min_plane_fit_points : prm->min_line_fit_points);
+  slots.assign(n_src, Slot{});
+  uint32_t count = 0;
+  (void)tgt;
+  for (uint32_t i = 0; i < n_src; i++) {
+    Slot& s = slots[i];
+    s.valid = false;
+    s.p = pose_act(est, v3(src[3 * i], src[3 * i + 1], src[3 * i + 2]));
+    KnnResult r;
+    const int kept = knn_search(G.g, G.cell_start.data(), G.sx.data(), G.sorig.data(), s.p, k, maxd, r);
+    if (kept < minfit) continue;
+    Vec3 nb[kMaxK];
+    for (int j = 0; j < kMaxK; j++)
+      if (j < kept) nb[j] = v3(G.sx[3 * r.pos[j]], G.sx[3 * r.pos[j] + 1], G.sx[3 * r.pos[j] + 2]);
+    if (is_plane) {
+      Vec3 n;
+      double d;
+      const double avg = fit_plane(nb, kept, n, d);
+      if (avg > prm->max_avg_point_plane_dist) continue;
+      s.prim[0] = n.x, s.prim[1] = n.y, s.prim[2] = n.z, s.prim[3] = d;
+    } else {
+      Vec3 a, b;
+      fit_line(nb, kept, a, b);
+      // min_line_condition_number guard is dead code in the reference (condition number == DBL_MAX)
+      if (kDblMax < prm->min_line_condition_number) continue;
+      s.prim[0] = a.x, s.prim[1] = a.y, s.prim[2] = a.z, s.prim[3] = b.x, s.prim[4] = b.y, s.prim[5] = b.z;
+    }
+    s.valid = true;
+    s.nearest = r.orig[0];
+    count++;
+  }
+  return count;
+}
+
+int hostcheck_associate(const double* src, uint64_t n_src, const double* tgt, uint64_t n_tgt, const double est[7],
+                        int is_plane, const loamx_reg_params* prm, uint8_t* valid, uint64_t* nearest, double* moved,
+                        double* prims) {
+  HostGrid G;
+  build_grid(tgt, (uint32_t)n_tgt, is_plane ? prm->max_plane_neighbor_dist : prm->max_edge_neighbor_dist, G);
+  std::vector<Slot> slots;
+  associate(src, (uint32_t)n_src, tgt, G, est, is_plane != 0, prm, slots);
+  const int pw = is_plane ? 4 : 6;
+  for (uint64_t i = 0; i < n_src; i++) {
+    valid[i] = slots[i].valid;
+    nearest[i] = slots[i].valid ? slots[i].nearest : 0;
+    moved[3 * i] = slots[i].p.x, moved[3 * i + 1] = slots[i].p.y, moved[3 * i + 2] = slots[i].p.z;
+    for (int j = 0; j < pw; j++) prims[i * pw + j] = slots[i].valid ? slots[i].prim[j] : 0.0;
+  }
+  return 0;
+}
+
+static void sweep(const std::vector<Slot>& edges, const std::vector<Slot>& planes, const double x[7], double acc[kAccSize]) {
+  for (int j = 0; j < kAccSize; j++) acc[j] = 0;
+  for (const Slot& s : edges)
+    if (s.valid) residual_accumulate(false, s.p, s.prim, x, acc);
+  for (const Slot& s : planes)
+    if (s.valid) residual_accumulate(true, s.p, s.prim, x, acc);
+}
+
+int hostcheck_register(const double* src_edge, uint64_t n_se, const double* src_planar, uint64_t n_sp,
+                       const double* tgt_edge, uint64_t n_te, const double* tgt_planar, uint64_t n_tp,
+                       const double init[7], const loamx_reg_params* prm, loamx_reg_result* out,
+                       loamx_iter_info* info) {
+  HostGrid GE, GP;
+  build_grid(tgt_edge, (uint32_t)n_te, prm->max_edge_neighbor_dist, GE);
+  build_grid(tgt_planar, (uint32_t)n_tp, prm->max_plane_neighbor_dist, GP);
+  double est[7];
+  memcpy(est, init, sizeof(est));
+  uint32_t term = LOAMX_MAX_ITER, iters = 0;
+  for (uint64_t it = 0; it < prm->max_iterations; it++) {
+    std::vector<Slot> edges, planes;
+    const uint32_t ne = associate(src_edge, (uint32_t)n_se, tgt_edge, GE, est, false, prm, edges);
+    const uint32_t np = associate(src_planar, (uint32_t)n_sp, tgt_planar, GP, est, true, prm, planes);
+    if ((uint64_t)ne + np < prm->min_associations) {
+      term = LOAMX_INSUFFICIENT_ASSOCIATIONS;
+      break;
+    }
+    LmState st;
+    lm_init(st);
+    double acc[kAccSize];
+    bool first = true;
+    while (st.active) {
+      sweep(edges, planes, st.xeval, acc);
+      lm_consume(st, acc, first);
+      first = false;
+    }
+    if (info) {
+      memcpy(info[it].target_T_source_init, est, sizeof(est));
+      memcpy(info[it].estimate_update, st.x_user, sizeof(est));
+      info[it].n_edge_associations = ne, info[it].n_plane_associations = np;
+    }
+    iters = (uint32_t)it + 1;
+    if (outer_update(est, st.x_user, prm->rotation_convergence_thresh, prm->position_convergence_thresh)) {
+      term = LOAMX_CONVERGED;
+      break;
+    }
+  }
+  memcpy(out->pose, est, sizeof(est));
+  out->termination = term, out->iterations = iters;
+  return 0;
+}
+
+void hostcheck_synth_scan(uint64_t seed, uint64_t pair, uint32_t which, uint32_t H, uint32_t W, double sigma, double* xyz) {
+  const loamx_synth::Pose7 pose = loamx_synth::pair_pose(seed, pair);
+  for (uint32_t l = 0; l < H; l++)
+    for (uint32_t c = 0; c < W; c++) loamx_synth::scan_point(seed, pair, which, pose, l, c, H, W, sigma, xyz + 3 * ((size_t)l * W + c));
+}
+void hostcheck_synth_pose(uint64_t seed, uint64_t pair, double out[7]) {
+  const loamx_synth::Pose7 p = loamx_synth::pair_pose(seed, pair);
+  for (int i = 0; i < 4; i++) out[i] = p.q[i];
+  for (int i = 0; i < 3; i++) out[4 + i] = p.t[i];
+}
+
+}  // extern "C"

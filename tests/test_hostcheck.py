@@ -1,0 +1,146 @@
+"""CPU-only: the HIP kernels' per-thread math (the __host__ __device__ headers under
+loam_amd/csrc, run serially by tests/hostcheck) against the oracle. This is what lets the kernels
+be trusted before they reach a GPU; the GPU parity tests proper are in test_gpu_*.py."""
+import numpy as np
+import pytest
+
+import hostcheck_lib as Hc
+import reference_kats as K
+
+
+def _pdiff(O, a, b):
+    d = O.pose_compose(O.pose_inverse(a), b)
+    return O.quat_angular_distance(d[:4], [0, 0, 0, 1.0]), float(np.linalg.norm(d[4:]))
+
+
+@pytest.mark.parametrize("kat", K.fe_kats(), ids=lambda k: k["name"])
+def test_kernel_math_on_reference_kats(oracle, kat):
+    fe = Hc.fe_params(*K.KAT_FE_PARAMS)
+    curv, mask = Hc.curvature_valid(kat["pts"], kat["H"], kat["W"], kat["rmin"], kat["rmax"], fe)
+    ofe = oracle.FeParams(*K.KAT_FE_PARAMS)
+    assert np.array_equal(curv.view(np.uint64), oracle.compute_curvature(kat["pts"], kat["H"], kat["W"], ofe).view(np.uint64))
+    assert np.array_equal(mask, oracle.compute_valid_points(kat["pts"], kat["H"], kat["W"], kat["rmin"], kat["rmax"], ofe))
+
+
+@pytest.mark.parametrize("H,W,seed", [(16, 256, 3), (64, 1024, 1), (8, 100, 5), (4, 37, 9)])
+def test_extraction_bit_exact_on_synthetic(oracle, H, W, seed):
+    xyz = Hc.synth_scan(seed, 0, 0, H, W, 0.01)
+    for params in [(3, 6, 10, 50, 100.0, 1.0, 0.5, 1.0), (5, 4, 2, 7, 50.0, 0.5, 0.3, 0.5), (1, 3, 0, 3, 10.0, 2.0, 0.5, 1.0)]:
+        ofe = oracle.FeParams(*params)
+        fe = Hc.fe_params(*params)
+        curv, mask = Hc.curvature_valid(xyz, H, W, 1.0, 120.0, fe)
+        assert np.array_equal(curv.view(np.uint64), oracle.compute_curvature(xyz, H, W, ofe).view(np.uint64))
+        assert np.array_equal(mask, oracle.compute_valid_points(xyz, H, W, 1.0, 120.0, ofe))
+        e, p = Hc.select(curv, mask, H, W, fe)
+        oe, op = oracle.extract_features(xyz, H, W, 1.0, 120.0, ofe)
+        se, sp, ties = oracle.extract_features(xyz, H, W, 1.0, 120.0, ofe, stable=True)
+        assert np.array_equal(e, se) and np.array_equal(p, sp)
+        if ties == 0:  # tie-free: identical to the reference's std::sort order as well
+            assert np.array_equal(e, oe) and np.array_equal(p, op)
+
+
+def test_extraction_tie_policy_on_noise_free_scan(oracle):
+    # noise-free synthetic scans contain exact curvature ties: the kernels' documented
+    # policy is the stable ascending order
+    xyz = Hc.synth_scan(2, 0, 0, 32, 512, 0.0)
+    ofe = oracle.FeParams()
+    curv, mask = Hc.curvature_valid(xyz, 32, 512, 1.0, 120.0, Hc.fe_params())
+    e, p = Hc.select(curv, mask, 32, 512, Hc.fe_params())
+    se, sp, ties = oracle.extract_features(xyz, 32, 512, 1.0, 120.0, ofe, stable=True)
+    assert np.array_equal(e, se) and np.array_equal(p, sp)
+
+
+def test_out_of_range_and_dropout_points(oracle):
+    xyz = Hc.synth_scan(4, 0, 0, 8, 256, 0.01)
+    rng = np.random.default_rng(0)
+    drop = rng.random(len(xyz)) < 0.05
+    xyz[drop] = 0.0  # no-return points
+    xyz[rng.random(len(xyz)) < 0.02] *= 30.0  # beyond max range
+    ofe = oracle.FeParams()
+    curv, mask = Hc.curvature_valid(xyz, 8, 256, 1.0, 120.0, Hc.fe_params())
+    assert np.array_equal(curv.view(np.uint64), oracle.compute_curvature(xyz, 8, 256, ofe).view(np.uint64))
+    assert np.array_equal(mask, oracle.compute_valid_points(xyz, 8, 256, 1.0, 120.0, ofe))
+    e, p = Hc.select(curv, mask, 8, 256, Hc.fe_params())
+    se, sp, _ = oracle.extract_features(xyz, 8, 256, 1.0, 120.0, ofe, stable=True)
+    assert np.array_equal(e, se) and np.array_equal(p, sp)
+
+
+def test_fits_match_oracle(oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(500):
+        k = int(rng.integers(4, 6))
+        base = rng.normal(size=3) * 5
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        pts = base + rng.normal(size=(k, 3)) * 0.3
+        pts -= np.outer((pts - base) @ n, n) * 0.98
+        no, do, ao = oracle.fit_plane(pts)
+        nh, dh, ah = Hc.fit_plane(pts)
+        assert np.abs(no - nh).max() < 1e-12 and abs(do - dh) < 1e-12 * max(1, abs(do)) and abs(ao - ah) < 1e-12
+        k = int(rng.integers(3, 6))
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        pts = base + np.outer(rng.normal(size=k), d) + rng.normal(size=(k, 3)) * 0.01
+        a, b, cond = oracle.fit_line(pts)
+        ah_, bh_ = Hc.fit_line(pts)
+        err = min(max(np.abs(a - ah_).max(), np.abs(b - bh_).max()), max(np.abs(a - bh_).max(), np.abs(b - ah_).max()))
+        assert err < 1e-10
+        assert cond == np.finfo(np.float64).max
+
+
+def test_grid_knn_is_exact(oracle):
+    rng = np.random.default_rng(1)
+    xyz = Hc.synth_scan(1, 0, 0, 32, 512, 0.01)
+    e, p = oracle.extract_features(xyz, 32, 512, 1.0, 120.0)
+    for pts, radii in ((xyz[p], (2.0, 0.3, -1.0)), (xyz[e], (1.0, -1.0))):
+        tree = oracle.KDTree(pts)
+        for _ in range(400):
+            q = pts[rng.integers(len(pts))] + rng.normal(size=3) * rng.choice([0.05, 0.5, 3.0, 30.0])
+            for R in radii:
+                for k in (1, 5, 8):
+                    a = tree.knn(q, k, R)
+                    assert np.array_equal(a, Hc.knn(pts, q, k, R))
+                    assert np.array_equal(a, oracle.knn_bruteforce(pts, q, k, R))
+    # empty and tiny target sets
+    assert len(Hc.knn(np.zeros((0, 3)), [0, 0, 0], 5, 1.0)) == 0
+    assert np.array_equal(Hc.knn(np.array([[1.0, 0, 0], [0.5, 0, 0]]), [0, 0, 0], 5, -1.0), [1, 0])
+
+
+@pytest.mark.parametrize("case", K.REGISTRATION_CASES, ids=lambda c: c["name"])
+def test_registration_math_on_reference_scenes(oracle, case):
+    tgt_e, tgt_p = K.registration_scene()
+    src_e = K.transform_points(case["source_T_target"], tgt_e)
+    src_p = K.transform_points(case["source_T_target"], tgt_p)
+    prm = oracle.RegParams()
+    if case["max_iter"] is not None:
+        prm.max_iterations = case["max_iter"]
+    po, to, io = oracle.register_features(src_e, src_p, tgt_e, tgt_p, case["init"], prm)
+    ph, th, ih = Hc.register(src_e, src_p, tgt_e, tgt_p, case["init"], Hc.conv_reg(prm))
+    assert (to, io) == (th, ih)
+    rot, trans = _pdiff(oracle, po, ph)
+    assert rot < 1e-5 and trans < 1e-5  # the north-star tolerance; observed ~1e-16
+    rot_err, trans_err = K.registration_error(case["source_T_target"], ph, oracle.pose_compose, oracle.quat_angular_distance)
+    assert rot_err < case["rot_tol"] and np.all(np.abs(trans_err) < case["trans_tol"])
+
+
+def test_registration_math_on_synthetic_pair(oracle):
+    H, W = 32, 512
+    A = Hc.synth_scan(7, 1, 0, H, W, 0.01)
+    B = Hc.synth_scan(7, 1, 1, H, W, 0.01)
+    ea, pa = oracle.extract_features(A, H, W, 1.0, 120.0)
+    eb, pb = oracle.extract_features(B, H, W, 1.0, 120.0)
+    po, to, io = oracle.register_features(B[eb], B[pb], A[ea], A[pa])
+    ph, th, ih = Hc.register(B[eb], B[pb], A[ea], A[pa])
+    assert (to, io) == (th, ih)
+    rot, trans = _pdiff(oracle, po, ph)
+    assert rot < 1e-5 and trans < 1e-5
+    rot, trans = _pdiff(oracle, Hc.synth_pose(7, 1), ph)
+    assert rot < 1e-2 and trans < 3e-2  # ICF convergence thresholds are 1e-3 rad / 1e-2 m per step
+
+
+def test_plane_only_and_insufficient(oracle):
+    e, p = K.plane_only_scene()
+    ph, th, ih = Hc.register(e, p, e, p)
+    assert oracle.quat_angular_distance(ph[:4], [0, 0, 0, 1.0]) < 1e-4 and np.all(np.abs(ph[4:]) < 1e-3)
+    ph, th, ih = Hc.register(e, p + np.array([100.0, 0, 0]), e, p)
+    assert th == 2 and ih == 0 and np.allclose(ph, [0, 0, 0, 1, 0, 0, 0])
