@@ -1,0 +1,48 @@
+"""Builds libloamx.so (the HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+    python -m loam_amd.build            # build if sources are newer than the library
+    python -m loam_amd.build --force
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libloamx.so")
+SOURCES = ["loamx_api.hip", "extract_kernels.hip", "register_kernels.hip", "synth_kernels.hip"]
+HEADERS = ["loamx_internal.h", "extract_math.h", "reg_math.h", "synth.h", os.path.join("..", "..", "include", "loamx.h")]
+# -ffp-contract=off: the reference's x86-64 build has no FMA; curvature bits must match
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libloamx.so cannot be built (there is no CPU fallback)")
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [_hipcc()] + FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

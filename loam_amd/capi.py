@@ -1,0 +1,338 @@
+"""ctypes binding of libloamx.so — the C ABI declared in include/loamx.h.
+
+This is host plumbing only: every compute call goes to the HIP kernels through the C ABI. If the
+library is missing it raises; there is no Python or CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+OK, ERR_SCAN_SIZE, ERR_BAD_PARAM, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_NO_DEVICE = range(7)
+CONVERGED, MAX_ITER, INSUFFICIENT_ASSOCIATIONS = 0, 1, 2
+K_CURVATURE, K_SELECT, K_COMPACT, K_GRID, K_ASSOC, K_SWEEP, K_LM, K_COUNT = range(8)
+
+
+class LidarParams(C.Structure):
+    """loam::LidarParams (reference: loam/include/loam/common.h:29-41)"""
+    _fields_ = [("scan_lines", C.c_uint64), ("points_per_line", C.c_uint64), ("min_range", C.c_double),
+                ("max_range", C.c_double)]
+
+
+class FeatureExtractionParams(C.Structure):
+    """loam::FeatureExtractionParams (reference: loam/include/loam/features.h:37-66)"""
+    _fields_ = [("neighbor_points", C.c_uint64), ("number_sectors", C.c_uint64),
+                ("max_edge_feats_per_sector", C.c_uint64), ("max_planar_feats_per_sector", C.c_uint64),
+                ("edge_feat_threshold", C.c_double), ("planar_feat_threshold", C.c_double),
+                ("occlusion_thresh", C.c_double), ("parallel_thresh", C.c_double)]
+
+    def __init__(self, *a, **kw):
+        if not a and not kw:
+            a = (3, 6, 10, 50, 100.0, 1.0, 0.5, 1.0)
+        super().__init__(*a, **kw)
+
+
+class RegistrationParams(C.Structure):
+    """loam::RegistrationParams (reference: loam/include/loam/registration.h:40-75)"""
+    _fields_ = [("num_edge_neighbors", C.c_uint64), ("max_edge_neighbor_dist", C.c_double),
+                ("min_line_fit_points", C.c_uint64), ("min_line_condition_number", C.c_double),
+                ("num_plane_neighbors", C.c_uint64), ("max_plane_neighbor_dist", C.c_double),
+                ("min_plane_fit_points", C.c_uint64), ("max_avg_point_plane_dist", C.c_double),
+                ("max_iterations", C.c_uint64), ("rotation_convergence_thresh", C.c_double),
+                ("position_convergence_thresh", C.c_double), ("min_associations", C.c_uint64)]
+
+    def __init__(self, *a, **kw):
+        if not a and not kw:
+            a = (5, 1.0, 3, 10.0, 5, 2.0, 4, 0.1, 10, 1e-3, 1e-2, 100)
+        super().__init__(*a, **kw)
+
+
+class RegResult(C.Structure):
+    _fields_ = [("pose", C.c_double * 7), ("termination", C.c_uint32), ("iterations", C.c_uint32)]
+
+
+class IterInfo(C.Structure):
+    _fields_ = [("target_T_source_init", C.c_double * 7), ("estimate_update", C.c_double * 7),
+                ("n_edge_associations", C.c_uint32), ("n_plane_associations", C.c_uint32)]
+
+
+class RegDetail(C.Structure):
+    _fields_ = [("iter_info", C.POINTER(IterInfo)), ("n_iter_info", C.c_uint32), ("pairs_iteration", C.c_uint32),
+                ("edge_pairs", C.POINTER(C.c_uint32)), ("edge_pairs_cap", C.c_size_t), ("n_edge_pairs", C.c_size_t),
+                ("plane_pairs", C.POINTER(C.c_uint32)), ("plane_pairs_cap", C.c_size_t),
+                ("n_plane_pairs", C.c_size_t)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("total_ms", C.c_double), ("algorithmic_bytes", C.c_double)]
+
+
+RESULT_DTYPE = np.dtype([("pose", np.float64, 7), ("termination", np.uint32), ("iterations", np.uint32)])
+
+EXPORTS = [
+    "loamx_default_fe_params", "loamx_default_reg_params", "loamx_status_string", "loamx_last_error",
+    "loamx_ctx_create", "loamx_ctx_destroy", "loamx_ctx_set_stream", "loamx_ctx_synchronize",
+    "loamx_compute_curvature", "loamx_compute_valid_points", "loamx_extract_features", "loamx_register_features",
+    "loamx_edge_capacity", "loamx_planar_capacity", "loamx_extract_features_batch_dev",
+    "loamx_register_features_batch_dev", "loamx_register_scan_pairs_dev", "loamx_ctx_enable_kernel_timing",
+    "loamx_ctx_reset_kernel_stats", "loamx_ctx_get_kernel_stats", "loamx_kernel_name", "loamx_synth_pair_pose",
+    "loamx_synth_scan_host", "loamx_synth_scan_pairs_dev", "loamx_dev_alloc", "loamx_dev_free",
+    "loamx_copy_to_device", "loamx_copy_to_host",
+]
+
+_lib = None
+
+
+def load(build_if_missing=True):
+    """Loads libloamx.so (building it with hipcc if needed). Raises if it cannot be had."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if build_if_missing and _build.needs_build():
+        _build.build()
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: build it with `python -m loam_amd.build` (no CPU fallback exists)")
+    lib = C.CDLL(path)
+    dp, u32p, vp = C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.c_void_p
+    lib.loamx_status_string.restype = C.c_char_p
+    lib.loamx_last_error.restype = C.c_char_p
+    lib.loamx_last_error.argtypes = [vp]
+    lib.loamx_kernel_name.restype = C.c_char_p
+    lib.loamx_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.loamx_ctx_destroy.argtypes = [vp]
+    lib.loamx_ctx_destroy.restype = None
+    lib.loamx_ctx_set_stream.argtypes = [vp, vp]
+    lib.loamx_ctx_synchronize.argtypes = [vp]
+    lib.loamx_compute_curvature.argtypes = [vp, dp, C.c_size_t, C.POINTER(LidarParams),
+                                            C.POINTER(FeatureExtractionParams), dp]
+    lib.loamx_compute_valid_points.argtypes = [vp, dp, C.c_size_t, C.POINTER(LidarParams),
+                                               C.POINTER(FeatureExtractionParams), C.POINTER(C.c_uint8)]
+    lib.loamx_extract_features.argtypes = [vp, dp, C.c_size_t, C.POINTER(LidarParams),
+                                           C.POINTER(FeatureExtractionParams), u32p, C.c_size_t,
+                                           C.POINTER(C.c_size_t), u32p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.loamx_register_features.argtypes = [vp, dp, C.c_size_t, dp, C.c_size_t, dp, C.c_size_t, dp, C.c_size_t, dp,
+                                            C.POINTER(RegistrationParams), C.POINTER(RegResult),
+                                            C.POINTER(RegDetail)]
+    lib.loamx_edge_capacity.restype = C.c_size_t
+    lib.loamx_edge_capacity.argtypes = [C.POINTER(LidarParams), C.POINTER(FeatureExtractionParams)]
+    lib.loamx_planar_capacity.restype = C.c_size_t
+    lib.loamx_planar_capacity.argtypes = [C.POINTER(LidarParams), C.POINTER(FeatureExtractionParams)]
+    lib.loamx_extract_features_batch_dev.argtypes = [vp, vp, C.c_size_t, C.POINTER(LidarParams),
+                                                     C.POINTER(FeatureExtractionParams), vp, vp, vp, vp, vp, vp]
+    lib.loamx_register_features_batch_dev.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t,
+                                                      C.c_size_t, vp, C.POINTER(RegistrationParams), vp]
+    lib.loamx_register_scan_pairs_dev.argtypes = [vp, vp, C.c_size_t, C.POINTER(LidarParams),
+                                                  C.POINTER(FeatureExtractionParams), C.POINTER(RegistrationParams),
+                                                  vp]
+    lib.loamx_ctx_enable_kernel_timing.argtypes = [vp, C.c_int]
+    lib.loamx_ctx_reset_kernel_stats.argtypes = [vp]
+    lib.loamx_ctx_get_kernel_stats.argtypes = [vp, C.POINTER(KernelStat)]
+    lib.loamx_synth_pair_pose.argtypes = [C.c_uint64, C.c_uint64, dp]
+    lib.loamx_synth_pair_pose.restype = None
+    lib.loamx_synth_scan_host.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, dp]
+    lib.loamx_synth_scan_host.restype = None
+    lib.loamx_synth_scan_pairs_dev.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_size_t, C.c_uint32, C.c_uint32,
+                                               C.c_double, vp]
+    lib.loamx_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.loamx_dev_free.argtypes = [vp, vp]
+    lib.loamx_copy_to_device.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.loamx_copy_to_host.argtypes = [vp, vp, vp, C.c_size_t]
+    _lib = lib
+    return lib
+
+
+class LoamxError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _pts(a):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1, 3))
+    return a
+
+
+def synth_pair_pose(seed, pair_id):
+    out = np.empty(7)
+    load().loamx_synth_pair_pose(seed, pair_id, _dp(out))
+    return out
+
+
+def synth_scan_host(seed, pair_id, which, scan_lines, points_per_line, sigma=0.01):
+    out = np.empty((scan_lines * points_per_line, 3))
+    load().loamx_synth_scan_host(seed, pair_id, which, scan_lines, points_per_line, sigma, _dp(out))
+    return out
+
+
+class DeviceBuffer:
+    """Raw device allocation owned by a Context (for hosts that do not use torch tensors)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, nbytes
+        p = C.c_void_p()
+        ctx._check(ctx.lib.loamx_dev_alloc(ctx.h, nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.ctx._check(self.ctx.lib.loamx_copy_to_device(self.ctx.h, self.ptr, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        self.ctx._check(self.ctx.lib.loamx_copy_to_host(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.loamx_dev_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """One device + stream + workspace (loamx_ctx)."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.loamx_ctx_create(device, C.byref(h))
+        if rc != OK:
+            raise LoamxError(rc, "loamx_ctx_create: " + self.lib.loamx_status_string(rc).decode() +
+                             " (libloamx has no CPU fallback)")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.loamx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != OK:
+            msg = self.lib.loamx_last_error(self.h).decode() or self.lib.loamx_status_string(rc).decode()
+            raise LoamxError(rc, msg)
+
+    def set_stream(self, hip_stream_handle):
+        self._check(self.lib.loamx_ctx_set_stream(self.h, hip_stream_handle))
+
+    def synchronize(self):
+        self._check(self.lib.loamx_ctx_synchronize(self.h))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    # ---- host entry points -------------------------------------------------------------------------
+    def compute_curvature(self, xyz, lidar, fe=None):
+        fe = fe or FeatureExtractionParams()
+        xyz = _pts(xyz)
+        out = np.empty(len(xyz))
+        self._check(self.lib.loamx_compute_curvature(self.h, _dp(xyz), len(xyz), C.byref(lidar), C.byref(fe), _dp(out)))
+        return out
+
+    def compute_valid_points(self, xyz, lidar, fe=None):
+        fe = fe or FeatureExtractionParams()
+        xyz = _pts(xyz)
+        out = np.empty(len(xyz), dtype=np.uint8)
+        self._check(self.lib.loamx_compute_valid_points(self.h, _dp(xyz), len(xyz), C.byref(lidar), C.byref(fe),
+                                                        out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out.astype(bool)
+
+    def extract_features(self, xyz, lidar, fe=None):
+        """Returns (edge_idx, planar_idx) in the reference's output order."""
+        fe = fe or FeatureExtractionParams()
+        xyz = _pts(xyz)
+        ecap = max(1, self.lib.loamx_edge_capacity(C.byref(lidar), C.byref(fe)))
+        pcap = max(1, self.lib.loamx_planar_capacity(C.byref(lidar), C.byref(fe)))
+        e = np.empty(ecap, dtype=np.uint32)
+        p = np.empty(pcap, dtype=np.uint32)
+        ne, npl = C.c_size_t(0), C.c_size_t(0)
+        u32p = C.POINTER(C.c_uint32)
+        self._check(self.lib.loamx_extract_features(self.h, _dp(xyz), len(xyz), C.byref(lidar), C.byref(fe),
+                                                    e.ctypes.data_as(u32p), ecap, C.byref(ne),
+                                                    p.ctypes.data_as(u32p), pcap, C.byref(npl)))
+        return e[:ne.value].copy(), p[:npl.value].copy()
+
+    def register_features(self, src_edge, src_planar, tgt_edge, tgt_planar, init_pose=None, reg=None,
+                          want_detail=False, pairs_iteration=0):
+        """Returns (pose7, termination, iterations[, detail dict])."""
+        reg = reg or RegistrationParams()
+        arrs = [_pts(a) for a in (src_edge, src_planar, tgt_edge, tgt_planar)]
+        init = np.ascontiguousarray([0, 0, 0, 1, 0, 0, 0] if init_pose is None else init_pose, dtype=np.float64)
+        res = RegResult()
+        detail = None
+        if want_detail:
+            info = (IterInfo * max(1, reg.max_iterations))()
+            ep = np.zeros((max(1, len(arrs[0])), 2), dtype=np.uint32)
+            pp = np.zeros((max(1, len(arrs[1])), 2), dtype=np.uint32)
+            u32p = C.POINTER(C.c_uint32)
+            detail = RegDetail(info, 0, pairs_iteration, ep.ctypes.data_as(u32p), len(ep), 0,
+                               pp.ctypes.data_as(u32p), len(pp), 0)
+        self._check(self.lib.loamx_register_features(
+            self.h, _dp(arrs[0]), len(arrs[0]), _dp(arrs[1]), len(arrs[1]), _dp(arrs[2]), len(arrs[2]),
+            _dp(arrs[3]), len(arrs[3]), _dp(init), C.byref(reg), C.byref(res),
+            C.byref(detail) if detail is not None else None))
+        pose = np.array(list(res.pose))
+        if want_detail:
+            d = dict(iterations=[dict(target_T_source_init=np.array(list(info[i].target_T_source_init)),
+                                      estimate_update=np.array(list(info[i].estimate_update)),
+                                      n_edge=info[i].n_edge_associations, n_plane=info[i].n_plane_associations)
+                                 for i in range(detail.n_iter_info)],
+                     edge_pairs=ep[:detail.n_edge_pairs].copy(), plane_pairs=pp[:detail.n_plane_pairs].copy())
+            return pose, res.termination, res.iterations, d
+        return pose, res.termination, res.iterations
+
+    # ---- device-resident batch entry points (raw device pointers as ints) -----------------------------
+    def edge_capacity(self, lidar, fe):
+        return self.lib.loamx_edge_capacity(C.byref(lidar), C.byref(fe))
+
+    def planar_capacity(self, lidar, fe):
+        return self.lib.loamx_planar_capacity(C.byref(lidar), C.byref(fe))
+
+    def extract_features_batch_dev(self, d_xyz, n_scans, lidar, fe, d_edge_idx, d_n_edge, d_edge_xyz, d_planar_idx,
+                                   d_n_planar, d_planar_xyz):
+        self._check(self.lib.loamx_extract_features_batch_dev(self.h, d_xyz, n_scans, C.byref(lidar), C.byref(fe),
+                                                              d_edge_idx, d_n_edge, d_edge_xyz, d_planar_idx,
+                                                              d_n_planar, d_planar_xyz))
+
+    def register_features_batch_dev(self, n_pairs, d_src_edge, d_n_src_edge, d_src_planar, d_n_src_planar,
+                                    d_tgt_edge, d_n_tgt_edge, d_tgt_planar, d_n_tgt_planar, edge_stride,
+                                    planar_stride, d_init, reg, d_results):
+        self._check(self.lib.loamx_register_features_batch_dev(
+            self.h, n_pairs, d_src_edge, d_n_src_edge, d_src_planar, d_n_src_planar, d_tgt_edge, d_n_tgt_edge,
+            d_tgt_planar, d_n_tgt_planar, edge_stride, planar_stride, d_init, C.byref(reg), d_results))
+
+    def register_scan_pairs_dev(self, d_xyz, n_pairs, lidar, fe, reg, d_results):
+        self._check(self.lib.loamx_register_scan_pairs_dev(self.h, d_xyz, n_pairs, C.byref(lidar), C.byref(fe),
+                                                           C.byref(reg), d_results))
+
+    def synth_scan_pairs_dev(self, seed, first_pair, n_pairs, scan_lines, points_per_line, sigma, d_xyz):
+        self._check(self.lib.loamx_synth_scan_pairs_dev(self.h, seed, first_pair, n_pairs, scan_lines,
+                                                        points_per_line, sigma, d_xyz))
+
+    # ---- kernel timing --------------------------------------------------------------------------------------
+    def enable_kernel_timing(self, on=True):
+        self._check(self.lib.loamx_ctx_enable_kernel_timing(self.h, 1 if on else 0))
+
+    def reset_kernel_stats(self):
+        self._check(self.lib.loamx_ctx_reset_kernel_stats(self.h))
+
+    def kernel_stats(self):
+        st = (KernelStat * K_COUNT)()
+        self._check(self.lib.loamx_ctx_get_kernel_stats(self.h, st))
+        return {self.lib.loamx_kernel_name(i).decode(): dict(launches=int(st[i].launches), total_ms=st[i].total_ms,
+                                                              algorithmic_bytes=st[i].algorithmic_bytes)
+                for i in range(K_COUNT)}

@@ -1,0 +1,251 @@
+// extract_kernels.hip — loam::extractFeatures on gfx950 (reference: loam/include/loam/features-inl.h,
+// loam/src/features.cpp). Three kernels:
+//
+//   curvature_valid_kernel  rows a5+a6: un-normalised curvature (FP64, contraction off) and the
+//                           validity mask, one 256-thread workgroup per 1024-point tile of a scan
+//                           line. HBM-bound: reads 24 B/point, writes 8 B + 1 B  => 33 B/point.
+//   select_kernel           rows a7-a9: the per-sector "sort + greedy walk" restated as repeated
+//                           arg-max / arg-min under the sort's total order, one wavefront per scan
+//                           line (sectors of a line are sequentially dependent; lines
+//                           are independent), curvature + mask staged in LDS, 64-lane butterfly
+//                           reductions. Compute/latency-bound.
+//   compact_kernel          row a10: prefix over the per-sector counts and gather of the feature
+//                           indices / point copies into the reference's output order.
+#include "loamx_internal.h"
+
+namespace loamx {
+
+namespace {
+
+constexpr int kTile = 1024;
+constexpr int kHaloMax = kMaxNeighborPoints + 1;
+constexpr int kLocalMax = kTile + 2 * kHaloMax;
+
+__global__ __launch_bounds__(256) void curvature_valid_kernel(const double* __restrict__ xyz, ExtractParams P,
+                                                              double* __restrict__ curv_out,
+                                                              uint8_t* __restrict__ mask_out) {
+  __shared__ double s_xyz[kLocalMax * 3];
+  __shared__ double s_r[kLocalMax];
+  __shared__ uint8_t s_code[kLocalMax];
+  const int tid = threadIdx.x;
+  const size_t line = blockIdx.x;  // scan * H + line
+  const int W = (int)P.W, np = (int)P.np;
+  const int halo = np + 1;
+  const int t0 = (int)blockIdx.y * kTile;
+  const int base = t0 - halo;  // column of local index 0
+  const int lo = t0 - halo > 0 ? t0 - halo : 0;
+  const int hi = t0 + kTile + halo < W ? t0 + kTile + halo : W;
+  const double* __restrict__ g = xyz + line * (size_t)W * 3;
+
+  // coalesced copy of the tile (+halo) of ring-ordered points into LDS
+  const int nd = (hi - lo) * 3;
+  for (int k = tid; k < nd; k += 256) s_xyz[(lo - base) * 3 + k] = g[(size_t)lo * 3 + k];
+  __syncthreads();
+  for (int c = lo + tid; c < hi; c += 256) {
+    const int li = c - base;
+    s_r[li] = point_range(s_xyz[3 * li], s_xyz[3 * li + 1], s_xyz[3 * li + 2]);
+  }
+  __syncthreads();
+  {
+    const int clo = t0 - np > 0 ? t0 - np : 0;
+    const int chi = t0 + kTile + np < W ? t0 + kTile + np : W;
+    for (int c = clo + tid; c < chi; c += 256) {
+      const int li = c - base;
+      s_code[li] = is_line_end((uint32_t)c, P.W, P.np) ? (uint8_t)kCodeNone
+                                                         : point_code(s_r[li - 1], s_r[li], s_r[li + 1], P);
+    }
+  }
+  __syncthreads();
+  for (int k = tid; k < kTile; k += 256) {
+    const int c = t0 + k;
+    if (c >= W) break;
+    const int li = c - base;
+    const double cv = is_line_end((uint32_t)c, P.W, P.np) ? -1.0 : curvature_at(s_xyz, li, P.np);
+    const bool ok = valid_from_codes(s_code, li, (uint32_t)c, P.W, P.np);
+    curv_out[line * (size_t)W + c] = cv;
+    mask_out[line * (size_t)W + c] = ok ? 1 : 0;
+  }
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS operations of one wavefront complete in issue order; this only stops the compiler from
+  // moving LDS accesses across the point where lanes exchange data through LDS.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool EDGE>
+__device__ __forceinline__ uint32_t select_pass(const double* s_c, volatile uint8_t* s_v, int lane, int start, int end,
+                                                double thr, uint32_t max_feats, uint32_t np, uint32_t line_base,
+                                                uint32_t* __restrict__ stage) {
+  uint32_t n = 0;
+  for (;;) {
+    double bc = 0.0;
+    int32_t bi = -1;
+    for (int i = start + lane; i < end; i += 64) {
+      if (s_v[i]) {
+        const double c = s_c[i];
+        const bool cand = EDGE ? (c > thr) : (c < thr);
+        if (cand && (bi < 0 || (EDGE ? edge_before(c, i, bc, bi) : planar_before(c, i, bc, bi)))) bc = c, bi = i;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double oc = __shfl_xor(bc, off);
+      const int32_t oi = __shfl_xor(bi, off);
+      if (oi >= 0 && (bi < 0 || (EDGE ? edge_before(oc, oi, bc, bi) : planar_before(oc, oi, bc, bi)))) bc = oc, bi = oi;
+    }
+    if (bi < 0) break;  // wave-uniform: every lane holds the same winner
+    if (lane == 0) stage[n] = line_base + (uint32_t)bi;
+    if ((uint32_t)lane < np) {  // features-inl.h:148-151 / :170-173: idx +- n for n = 0 .. np-1
+      s_v[bi + lane] = 0;
+      s_v[bi - lane] = 0;
+    }
+    wave_lds_sync();
+    n++;
+    if (n > max_feats) break;  // features-inl.h:155 / :177 (max + 1 features can be taken)
+  }
+  return n;
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void select_kernel(const double* __restrict__ curv,
+                                                            const uint8_t* __restrict__ mask, size_t n_lines,
+                                                            ExtractParams P, ExtractStage st) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t line = (size_t)blockIdx.x * WAVES + wave;
+  if (line >= n_lines) return;  // whole wavefront leaves; no workgroup barrier is used below
+  const int W = (int)P.W;
+  const size_t per_wave = (size_t)W * 8 + (((size_t)W + 7) & ~(size_t)7);
+  double* s_c = reinterpret_cast<double*>(smem + wave * per_wave);
+  volatile uint8_t* s_v = reinterpret_cast<volatile uint8_t*>(s_c + W);
+  for (int i = lane; i < W; i += 64) {
+    s_c[i] = curv[line * (size_t)W + i];
+    s_v[i] = mask[line * (size_t)W + i];
+  }
+  wave_lds_sync();
+  const uint32_t line_base = (uint32_t)(line % P.H) * P.W;
+  for (uint32_t s = 0; s < P.S; s++) {
+    const int start = (int)(s * P.pps);
+    const int end = (s == P.S - 1) ? W : start + (int)P.pps;  // features-inl.h:31-35
+    const size_t group = line * P.S + s;
+    const uint32_t ne = select_pass<true>(s_c, s_v, lane, start, end, P.edge_thr, P.max_edge, P.np, line_base,
+                                          st.edge_stage + group * P.cap_edge);
+    const uint32_t npl = select_pass<false>(s_c, s_v, lane, start, end, P.planar_thr, P.max_planar, P.np, line_base,
+                                            st.planar_stage + group * P.cap_planar);
+    if (lane == 0) {
+      st.edge_cnt[group] = ne;
+      st.planar_cnt[group] = npl;
+    }
+  }
+}
+
+// block-wide exclusive scan of one value per thread (256 threads); returns the exclusive prefix and
+// writes the block total to *total
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_scan, uint32_t* total) {
+  const int tid = threadIdx.x;
+  s_scan[tid] = v;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const uint32_t add = tid >= off ? s_scan[tid - off] : 0;
+    __syncthreads();
+    s_scan[tid] += add;
+    __syncthreads();
+  }
+  const uint32_t incl = s_scan[tid];
+  *total = s_scan[255];
+  __syncthreads();
+  return incl - v;
+}
+
+__device__ __forceinline__ void compact_one(const double* __restrict__ scan_xyz, uint32_t groups, uint32_t cap,
+                                            const uint32_t* __restrict__ stage, const uint32_t* __restrict__ cnt,
+                                            uint32_t* __restrict__ out_idx, double* __restrict__ out_xyz,
+                                            uint32_t* __restrict__ out_n, uint32_t* s_scan, uint32_t* s_off,
+                                            uint32_t* s_cnt) {
+  const int tid = threadIdx.x;
+  uint32_t carry = 0;
+  for (uint32_t g0 = 0; g0 < groups; g0 += 256) {
+    const uint32_t g = g0 + tid;
+    const uint32_t c = g < groups ? cnt[g] : 0;
+    uint32_t total;
+    const uint32_t excl = block_exclusive_scan(c, s_scan, &total);
+    s_off[tid] = carry + excl;
+    s_cnt[tid] = c;
+    __syncthreads();
+    const uint32_t chunk_groups = groups - g0 < 256 ? groups - g0 : 256;
+    const uint32_t items = chunk_groups * cap;
+    for (uint32_t it = tid; it < items; it += 256) {
+      const uint32_t gl = it / cap, j = it - gl * cap;
+      if (j < s_cnt[gl]) {
+        const uint32_t idx = stage[(size_t)(g0 + gl) * cap + j];
+        const uint32_t o = s_off[gl] + j;
+        out_idx[o] = idx;
+        if (out_xyz) {
+          out_xyz[3 * (size_t)o] = scan_xyz[3 * (size_t)idx];
+          out_xyz[3 * (size_t)o + 1] = scan_xyz[3 * (size_t)idx + 1];
+          out_xyz[3 * (size_t)o + 2] = scan_xyz[3 * (size_t)idx + 2];
+        }
+      }
+    }
+    carry += total;
+    __syncthreads();
+  }
+  if (tid == 0) *out_n = carry;
+}
+
+__global__ __launch_bounds__(256) void compact_kernel(const double* __restrict__ xyz, ExtractParams P, ExtractStage st,
+                                                      uint32_t* __restrict__ edge_idx, uint32_t* __restrict__ n_edge,
+                                                      double* __restrict__ edge_xyz, size_t edge_stride,
+                                                      uint32_t* __restrict__ planar_idx,
+                                                      uint32_t* __restrict__ n_planar, double* __restrict__ planar_xyz,
+                                                      size_t planar_stride) {
+  __shared__ uint32_t s_scan[256], s_off[256], s_cnt[256];
+  const size_t scan = blockIdx.x;
+  const uint32_t groups = P.H * P.S;
+  const double* scan_xyz = xyz + scan * (size_t)P.H * P.W * 3;
+  compact_one(scan_xyz, groups, P.cap_edge, st.edge_stage + scan * (size_t)groups * P.cap_edge,
+              st.edge_cnt + scan * (size_t)groups, edge_idx + scan * edge_stride,
+              edge_xyz ? edge_xyz + scan * edge_stride * 3 : nullptr, n_edge + scan, s_scan, s_off, s_cnt);
+  compact_one(scan_xyz, groups, P.cap_planar, st.planar_stage + scan * (size_t)groups * P.cap_planar,
+              st.planar_cnt + scan * (size_t)groups, planar_idx + scan * planar_stride,
+              planar_xyz ? planar_xyz + scan * planar_stride * 3 : nullptr, n_planar + scan, s_scan, s_off, s_cnt);
+}
+
+}  // namespace
+
+void launch_curvature_valid(const double* d_xyz, size_t n_scans, const ExtractParams& P, double* d_curv,
+                            uint8_t* d_mask, hipStream_t s) {
+  const size_t n_lines = n_scans * P.H;
+  if (n_lines == 0 || P.W == 0) return;
+  const dim3 grid((unsigned)n_lines, (P.W + kTile - 1) / kTile);
+  hipLaunchKernelGGL(curvature_valid_kernel, grid, dim3(256), 0, s, d_xyz, P, d_curv, d_mask);
+}
+
+void launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, const ExtractParams& P,
+                   const ExtractStage& st, hipStream_t s) {
+  const size_t n_lines = n_scans * P.H;
+  if (n_lines == 0 || P.W == 0) return;
+  const size_t per_wave = (size_t)P.W * 8 + (((size_t)P.W + 7) & ~(size_t)7);
+  if (P.W <= 1024) {
+    constexpr int WAVES = 4;
+    hipLaunchKernelGGL(select_kernel<WAVES>, dim3((unsigned)((n_lines + WAVES - 1) / WAVES)), dim3(WAVES * 64),
+                       per_wave * WAVES, s, d_curv, d_mask, n_lines, P, st);
+  } else {
+    hipLaunchKernelGGL(select_kernel<1>, dim3((unsigned)n_lines), dim3(64), per_wave, s, d_curv, d_mask, n_lines, P,
+                       st);
+  }
+}
+
+void launch_compact(const double* d_xyz, size_t n_scans, const ExtractParams& P, const ExtractStage& st,
+                    uint32_t* d_edge_idx, uint32_t* d_n_edge, double* d_edge_xyz, size_t edge_stride,
+                    uint32_t* d_planar_idx, uint32_t* d_n_planar, double* d_planar_xyz, size_t planar_stride,
+                    hipStream_t s) {
+  if (n_scans == 0) return;
+  hipLaunchKernelGGL(compact_kernel, dim3((unsigned)n_scans), dim3(256), 0, s, d_xyz, P, st, d_edge_idx, d_n_edge,
+                     d_edge_xyz, edge_stride, d_planar_idx, d_n_planar, d_planar_xyz, planar_stride);
+}
+
+}  // namespace loamx

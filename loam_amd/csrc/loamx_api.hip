@@ -1,0 +1,775 @@
+// loamx_api.hip — the C ABI of libloamx.so (include/loamx.h): context, device workspace,
+// orchestration of the extraction and registration kernels, per-kernel hipEvent timing.
+// No CPU compute path exists here: without a usable HIP device every entry point fails.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "loamx_internal.h"
+#include "synth.h"
+
+using namespace loamx;
+
+namespace {
+
+enum WsId {
+  WS_XYZ = 0, WS_CURV, WS_MASK, WS_EDGE_STAGE, WS_PLANAR_STAGE, WS_EDGE_CNT, WS_PLANAR_CNT,
+  WS_EDGE_IDX, WS_PLANAR_IDX, WS_N_EDGE, WS_N_PLANAR, WS_EDGE_XYZ, WS_PLANAR_XYZ,
+  WS_GRID_DESC_E, WS_GRID_DESC_P, WS_CELLS_E, WS_CELLS_P, WS_SORTED_XYZ_E, WS_SORTED_XYZ_P, WS_SORTED_IDX_E,
+  WS_SORTED_IDX_P, WS_ASSOC_E, WS_ASSOC_P, WS_NEAREST_E, WS_NEAREST_P, WS_NASSOC, WS_STATE, WS_PARTIALS,
+  WS_COUNTERS, WS_ITERINFO, WS_SRC_E, WS_SRC_P, WS_TGT_E, WS_TGT_P, WS_FCOUNTS, WS_RESULTS, WS_INIT,
+  WS_COUNT
+};
+
+struct Buf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct PendingEvent {
+  int kernel;
+  hipEvent_t e0, e1;
+  double bytes;
+};
+
+}  // namespace
+
+struct loamx_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::string last_error;
+  Buf ws[WS_COUNT];
+  uint32_t* h_pinned = nullptr;  // small pinned readback area
+  bool timing = false;
+  std::vector<PendingEvent> pending;
+  std::vector<hipEvent_t> event_pool;
+  loamx_kernel_stat stats[LOAMX_K_COUNT] = {};
+  unsigned long long sweep_slots_base[2] = {0, 0};
+  std::mutex mu;
+};
+
+namespace {
+
+const char* kKernelNames[LOAMX_K_COUNT] = {"curvature_valid_kernel", "select_kernel", "compact_kernel",
+                                           "grid_build_kernel",      "associate_kernel", "sweep_kernel",
+                                           "lm_kernels"};
+
+int fail(loamx_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                          \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess)                                                                           \
+      return fail(ctx, LOAMX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+  } while (0)
+
+int ensure(loamx_ctx* ctx, int id, size_t bytes) {
+  Buf& b = ctx->ws[id];
+  if (bytes == 0) bytes = 8;
+  if (b.cap >= bytes) return LOAMX_OK;
+  if (b.p) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(b.p));
+    b.p = nullptr, b.cap = 0;
+  }
+  HIP_TRY(ctx, hipMalloc(&b.p, bytes));
+  b.cap = bytes;
+  return LOAMX_OK;
+}
+#define ENSURE(ctx, id, bytes)                       \
+  do {                                               \
+    int rc_ = ensure(ctx, id, bytes);                \
+    if (rc_ != LOAMX_OK) return rc_;                 \
+  } while (0)
+
+template <typename T>
+T* wsp(loamx_ctx* ctx, int id) {
+  return reinterpret_cast<T*>(ctx->ws[id].p);
+}
+
+// timing helpers ------------------------------------------------------------------------------------
+hipEvent_t take_event(loamx_ctx* ctx) {
+  if (!ctx->event_pool.empty()) {
+    hipEvent_t e = ctx->event_pool.back();
+    ctx->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+struct TimedScope {
+  loamx_ctx* ctx;
+  PendingEvent pe;
+  bool on;
+  TimedScope(loamx_ctx* c, int kernel, double bytes) : ctx(c), on(c->timing) {
+    if (on) {
+      pe.kernel = kernel, pe.bytes = bytes;
+      pe.e0 = take_event(ctx), pe.e1 = take_event(ctx);
+      (void)hipEventRecord(pe.e0, ctx->stream);
+    }
+  }
+  ~TimedScope() {
+    if (on) {
+      (void)hipEventRecord(pe.e1, ctx->stream);
+      ctx->pending.push_back(pe);
+    }
+  }
+};
+
+int check_launch(loamx_ctx* ctx, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ctx, LOAMX_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+  return LOAMX_OK;
+}
+#define CHECK_LAUNCH(ctx, what)                      \
+  do {                                               \
+    int rc_ = check_launch(ctx, what);               \
+    if (rc_ != LOAMX_OK) return rc_;                 \
+  } while (0)
+
+// parameter translation -------------------------------------------------------------------------------
+int make_extract_params(loamx_ctx* ctx, const loamx_lidar_params* lidar, const loamx_fe_params* fe, ExtractParams& P) {
+  if (!lidar || !fe) return fail(ctx, LOAMX_ERR_BAD_PARAM, "null parameter struct");
+  if (fe->number_sectors == 0) return fail(ctx, LOAMX_ERR_BAD_PARAM, "number_sectors must be >= 1");
+  if (fe->neighbor_points == 0)
+    return fail(ctx, LOAMX_ERR_BAD_PARAM, "neighbor_points must be >= 1 (the reference reads point idx-1)");
+  if (fe->neighbor_points > (uint64_t)kMaxNeighborPoints)
+    return fail(ctx, LOAMX_ERR_UNSUPPORTED, "neighbor_points > 16 not supported by the kernels");
+  if (lidar->points_per_line > (uint64_t)kMaxLineWidth)
+    return fail(ctx, LOAMX_ERR_UNSUPPORTED, "points_per_line > 4096 not supported by the kernels");
+  if (lidar->scan_lines * lidar->points_per_line > 0xFFFFFFFFull / 4)
+    return fail(ctx, LOAMX_ERR_UNSUPPORTED, "scan too large for 32-bit point indices");
+  if (fe->number_sectors > 65535) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "number_sectors > 65535");
+  P = ExtractParams{};
+  P.H = (uint32_t)lidar->scan_lines, P.W = (uint32_t)lidar->points_per_line;
+  P.np = (uint32_t)fe->neighbor_points, P.S = (uint32_t)fe->number_sectors;
+  P.pps = P.W / P.S;
+  const uint64_t longest = (uint64_t)P.W - (uint64_t)(P.S - 1) * P.pps;  // last sector takes the remainder
+  const uint64_t lim = 0x7FFFFFFFull;
+  P.max_edge = (uint32_t)(fe->max_edge_feats_per_sector < lim ? fe->max_edge_feats_per_sector : lim);
+  P.max_planar = (uint32_t)(fe->max_planar_feats_per_sector < lim ? fe->max_planar_feats_per_sector : lim);
+  P.cap_edge = (uint32_t)((uint64_t)P.max_edge + 1 < longest ? (uint64_t)P.max_edge + 1 : longest);
+  P.cap_planar = (uint32_t)((uint64_t)P.max_planar + 1 < longest ? (uint64_t)P.max_planar + 1 : longest);
+  if (P.cap_edge == 0) P.cap_edge = 1;
+  if (P.cap_planar == 0) P.cap_planar = 1;
+  P.min_range = lidar->min_range, P.max_range = lidar->max_range;
+  P.edge_thr = fe->edge_feat_threshold, P.planar_thr = fe->planar_feat_threshold;
+  P.occ_thr = fe->occlusion_thresh, P.par_thr = fe->parallel_thresh;
+  return LOAMX_OK;
+}
+
+int make_reg_config(loamx_ctx* ctx, const loamx_reg_params* r, RegConfig& C) {
+  if (!r) return fail(ctx, LOAMX_ERR_BAD_PARAM, "null registration params");
+  if (r->num_edge_neighbors > (uint64_t)kMaxK || r->num_plane_neighbors > (uint64_t)kMaxK)
+    return fail(ctx, LOAMX_ERR_UNSUPPORTED, "num_*_neighbors > 8 not supported by the kernels");
+  if (r->min_plane_fit_points < 3 && r->num_plane_neighbors > 0)
+    return fail(ctx, LOAMX_ERR_BAD_PARAM, "min_plane_fit_points must be >= 3");
+  if (r->min_line_fit_points < 2 && r->num_edge_neighbors > 0)
+    return fail(ctx, LOAMX_ERR_BAD_PARAM, "min_line_fit_points must be >= 2");
+  if (r->max_iterations > 1000) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "max_iterations > 1000");
+  C.k_edge = (int)r->num_edge_neighbors, C.k_plane = (int)r->num_plane_neighbors;
+  C.min_line_pts = (int)(r->min_line_fit_points > 64 ? 64 : r->min_line_fit_points);
+  C.min_plane_pts = (int)(r->min_plane_fit_points > 64 ? 64 : r->min_plane_fit_points);
+  C.r_edge = r->max_edge_neighbor_dist, C.r_plane = r->max_plane_neighbor_dist;
+  C.min_line_cond = r->min_line_condition_number, C.max_avg_plane_dist = r->max_avg_point_plane_dist;
+  C.max_iterations = (uint32_t)r->max_iterations;
+  C.rot_thresh = r->rotation_convergence_thresh, C.pos_thresh = r->position_convergence_thresh;
+  C.min_associations = (uint32_t)(r->min_associations > 0xFFFFFFFFull ? 0xFFFFFFFFull : r->min_associations);
+  return LOAMX_OK;
+}
+
+size_t edge_capacity(const ExtractParams& P) { return (size_t)P.H * P.S * P.cap_edge; }
+size_t planar_capacity(const ExtractParams& P) { return (size_t)P.H * P.S * P.cap_planar; }
+
+// extraction over device-resident scans ------------------------------------------------------------------
+int extract_dev(loamx_ctx* ctx, const double* d_xyz, size_t n_scans, const ExtractParams& P, uint32_t* d_edge_idx,
+                uint32_t* d_n_edge, double* d_edge_xyz, uint32_t* d_planar_idx, uint32_t* d_n_planar,
+                double* d_planar_xyz, bool only_curvature_mask) {
+  const size_t N = (size_t)P.H * P.W;
+  if (n_scans == 0) return LOAMX_OK;
+  if (N == 0) {
+    if (!only_curvature_mask) {
+      HIP_TRY(ctx, hipMemsetAsync(d_n_edge, 0, n_scans * sizeof(uint32_t), ctx->stream));
+      HIP_TRY(ctx, hipMemsetAsync(d_n_planar, 0, n_scans * sizeof(uint32_t), ctx->stream));
+    }
+    return LOAMX_OK;
+  }
+  ENSURE(ctx, WS_CURV, n_scans * N * sizeof(double));
+  ENSURE(ctx, WS_MASK, n_scans * N);
+  {
+    TimedScope t(ctx, LOAMX_K_CURVATURE, (double)n_scans * (double)N * 33.0);
+    launch_curvature_valid(d_xyz, n_scans, P, wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), ctx->stream);
+  }
+  CHECK_LAUNCH(ctx, "curvature_valid_kernel");
+  if (only_curvature_mask) return LOAMX_OK;
+  const size_t groups = n_scans * P.H * P.S;
+  ENSURE(ctx, WS_EDGE_STAGE, groups * P.cap_edge * sizeof(uint32_t));
+  ENSURE(ctx, WS_PLANAR_STAGE, groups * P.cap_planar * sizeof(uint32_t));
+  ENSURE(ctx, WS_EDGE_CNT, groups * sizeof(uint32_t));
+  ENSURE(ctx, WS_PLANAR_CNT, groups * sizeof(uint32_t));
+  ExtractStage st{wsp<uint32_t>(ctx, WS_EDGE_STAGE), wsp<uint32_t>(ctx, WS_PLANAR_STAGE),
+                  wsp<uint32_t>(ctx, WS_EDGE_CNT), wsp<uint32_t>(ctx, WS_PLANAR_CNT)};
+  {
+    TimedScope t(ctx, LOAMX_K_SELECT, (double)n_scans * (double)N * 9.0);
+    launch_select(wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), n_scans, P, st, ctx->stream);
+  }
+  CHECK_LAUNCH(ctx, "select_kernel");
+  {
+    TimedScope t(ctx, LOAMX_K_COMPACT, 0.0);
+    launch_compact(d_xyz, n_scans, P, st, d_edge_idx, d_n_edge, d_edge_xyz, edge_capacity(P), d_planar_idx,
+                   d_n_planar, d_planar_xyz, planar_capacity(P), ctx->stream);
+  }
+  CHECK_LAUNCH(ctx, "compact_kernel");
+  return LOAMX_OK;
+}
+
+// registration over device-resident feature sets ------------------------------------------------------
+struct RegInputs {
+  size_t n_pairs, edge_stride, planar_stride;
+  uint32_t in_pitch;
+  const double *src_edge, *src_planar, *tgt_edge, *tgt_planar;
+  const uint32_t *n_src_edge, *n_src_planar, *n_tgt_edge, *n_tgt_planar;
+  const double* init;
+};
+
+// host-side hook called after the association kernels of iteration `it` (detail capture)
+typedef int (*AfterAssocHook)(loamx_ctx*, const RegBatch&, uint32_t it, void* user);
+
+int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_reg_result* d_results, bool want_iter_info,
+                 AfterAssocHook hook, void* hook_user) {
+  if (in.n_pairs == 0) return LOAMX_OK;
+  if (in.n_pairs > 0x7FFFFFFFull / 128) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "too many pairs in one call");
+  const size_t np = in.n_pairs, es = in.edge_stride ? in.edge_stride : 1, ps = in.planar_stride ? in.planar_stride : 1;
+  if (es > 0x7FFFFFFFull || ps > 0x7FFFFFFFull) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "feature set too large");
+  RegBatch B{};
+  B.n_pairs = np, B.edge_stride = es, B.planar_stride = ps, B.in_pitch = in.in_pitch;
+  B.src_edge = in.src_edge, B.n_src_edge = in.n_src_edge, B.src_planar = in.src_planar, B.n_src_planar = in.n_src_planar;
+  B.tgt_edge = in.tgt_edge, B.n_tgt_edge = in.n_tgt_edge, B.tgt_planar = in.tgt_planar, B.n_tgt_planar = in.n_tgt_planar;
+  B.init = in.init;
+  ENSURE(ctx, WS_GRID_DESC_E, np * sizeof(GridDesc));
+  ENSURE(ctx, WS_GRID_DESC_P, np * sizeof(GridDesc));
+  ENSURE(ctx, WS_CELLS_E, np * (size_t)(kGridCellsCap + 1) * sizeof(uint32_t));
+  ENSURE(ctx, WS_CELLS_P, np * (size_t)(kGridCellsCap + 1) * sizeof(uint32_t));
+  ENSURE(ctx, WS_SORTED_XYZ_E, np * es * 3 * sizeof(double));
+  ENSURE(ctx, WS_SORTED_XYZ_P, np * ps * 3 * sizeof(double));
+  ENSURE(ctx, WS_SORTED_IDX_E, np * es * sizeof(uint32_t));
+  ENSURE(ctx, WS_SORTED_IDX_P, np * ps * sizeof(uint32_t));
+  ENSURE(ctx, WS_ASSOC_E, 9 * np * es * sizeof(double));
+  ENSURE(ctx, WS_ASSOC_P, 7 * np * ps * sizeof(double));
+  ENSURE(ctx, WS_NEAREST_E, np * es * sizeof(uint32_t));
+  ENSURE(ctx, WS_NEAREST_P, np * ps * sizeof(uint32_t));
+  ENSURE(ctx, WS_NASSOC, np * 2 * sizeof(uint32_t));
+  ENSURE(ctx, WS_STATE, np * sizeof(PairState));
+  B.blocks_per_pair = (uint32_t)((es + ps + kSweepChunk - 1) / kSweepChunk);
+  ENSURE(ctx, WS_PARTIALS, np * B.blocks_per_pair * kAccSize * sizeof(double));
+  {
+    const bool fresh = ctx->ws[WS_COUNTERS].cap == 0;
+    ENSURE(ctx, WS_COUNTERS, 64);
+    if (fresh) HIP_TRY(ctx, hipMemsetAsync(ctx->ws[WS_COUNTERS].p, 0, 64, ctx->stream));
+  }
+  if (want_iter_info) ENSURE(ctx, WS_ITERINFO, np * (size_t)(C.max_iterations ? C.max_iterations : 1) * sizeof(loamx_iter_info));
+  B.grid_edge = GridSet{wsp<GridDesc>(ctx, WS_GRID_DESC_E), wsp<uint32_t>(ctx, WS_CELLS_E),
+                        wsp<double>(ctx, WS_SORTED_XYZ_E), wsp<uint32_t>(ctx, WS_SORTED_IDX_E), es};
+  B.grid_plane = GridSet{wsp<GridDesc>(ctx, WS_GRID_DESC_P), wsp<uint32_t>(ctx, WS_CELLS_P),
+                         wsp<double>(ctx, WS_SORTED_XYZ_P), wsp<uint32_t>(ctx, WS_SORTED_IDX_P), ps};
+  B.assoc = AssocBuffers{wsp<double>(ctx, WS_ASSOC_E), wsp<double>(ctx, WS_ASSOC_P), wsp<uint32_t>(ctx, WS_NEAREST_E),
+                         wsp<uint32_t>(ctx, WS_NEAREST_P), wsp<uint32_t>(ctx, WS_NASSOC)};
+  B.state = wsp<PairState>(ctx, WS_STATE);
+  B.partials = wsp<double>(ctx, WS_PARTIALS);
+  // counters: [0] n_active (u32), [8..24) sweep slot counters (2 x u64)
+  B.n_active = wsp<uint32_t>(ctx, WS_COUNTERS);
+  B.sweep_slots = reinterpret_cast<unsigned long long*>(wsp<unsigned char>(ctx, WS_COUNTERS) + 8);
+  B.iter_info = want_iter_info ? wsp<loamx_iter_info>(ctx, WS_ITERINFO) : nullptr;
+  hipStream_t s = ctx->stream;
+
+  {
+    TimedScope t(ctx, LOAMX_K_GRID, 0.0);
+    launch_grid_build(B, C, s);
+  }
+  CHECK_LAUNCH(ctx, "grid_build_kernel");
+  launch_state_init(B, C, s);
+  CHECK_LAUNCH(ctx, "state_init_kernel");
+  for (uint32_t it = 0; it < C.max_iterations; it++) {
+    {
+      TimedScope t(ctx, LOAMX_K_ASSOC, 0.0);
+      launch_associate(B, C, s);
+    }
+    CHECK_LAUNCH(ctx, "associate_kernel");
+    if (hook) {
+      int rc = hook(ctx, B, it, hook_user);
+      if (rc != LOAMX_OK) return rc;
+    }
+    {
+      TimedScope t(ctx, LOAMX_K_LM, 0.0);
+      launch_lm_begin(B, C, it, s);
+    }
+    for (int k = 0; k < 5; k++) {  // iteration-0 evaluation + max_num_iterations = 4 candidates
+      {
+        TimedScope t(ctx, LOAMX_K_SWEEP, 0.0);
+        launch_sweep(B, s);
+      }
+      {
+        TimedScope t(ctx, LOAMX_K_LM, 0.0);
+        launch_lm_step(B, s);
+      }
+    }
+    CHECK_LAUNCH(ctx, "sweep/lm kernels");
+    HIP_TRY(ctx, hipMemsetAsync(B.n_active, 0, sizeof(uint32_t), s));
+    {
+      TimedScope t(ctx, LOAMX_K_LM, 0.0);
+      launch_outer_update(B, C, it, s);
+    }
+    CHECK_LAUNCH(ctx, "outer_update_kernel");
+    if (it + 1 < C.max_iterations) {
+      // one 4-byte readback per outer iteration: stop as soon as every pair has terminated
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, B.n_active, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      HIP_TRY(ctx, hipStreamSynchronize(s));
+      if (ctx->h_pinned[0] == 0) break;
+    }
+  }
+  launch_write_results(B, d_results, s);
+  CHECK_LAUNCH(ctx, "write_results_kernel");
+  return LOAMX_OK;
+}
+
+int resolve_events(loamx_ctx* ctx) {
+  if (ctx->pending.empty()) return LOAMX_OK;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (PendingEvent& pe : ctx->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pe.e0, pe.e1) == hipSuccess) {
+      ctx->stats[pe.kernel].launches++;
+      ctx->stats[pe.kernel].total_ms += (double)ms;
+      ctx->stats[pe.kernel].algorithmic_bytes += pe.bytes;
+    }
+    ctx->event_pool.push_back(pe.e0);
+    ctx->event_pool.push_back(pe.e1);
+  }
+  ctx->pending.clear();
+  return LOAMX_OK;
+}
+
+}  // namespace
+
+/* ================================================================================================== */
+extern "C" {
+
+void loamx_default_fe_params(loamx_fe_params* p) { *p = loamx_fe_params{3, 6, 10, 50, 100.0, 1.0, 0.5, 1.0}; }
+void loamx_default_reg_params(loamx_reg_params* p) {
+  *p = loamx_reg_params{5, 1.0, 3, 10.0, 5, 2.0, 4, 0.1, 10, 1e-3, 1e-2, 100};
+}
+
+const char* loamx_status_string(int status) {
+  switch (status) {
+    case LOAMX_OK: return "ok";
+    case LOAMX_ERR_SCAN_SIZE: return "LOAM: provided lidar scan size does not match provided lidar parameters";
+    case LOAMX_ERR_BAD_PARAM: return "bad parameter";
+    case LOAMX_ERR_HIP: return "HIP error";
+    case LOAMX_ERR_CAPACITY: return "output capacity too small";
+    case LOAMX_ERR_UNSUPPORTED: return "unsupported parameter combination";
+    case LOAMX_ERR_NO_DEVICE: return "no usable HIP device";
+    default: return "unknown status";
+  }
+}
+
+const char* loamx_last_error(const loamx_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+const char* loamx_kernel_name(int id) { return (id >= 0 && id < LOAMX_K_COUNT) ? kKernelNames[id] : "?"; }
+
+int loamx_ctx_create(int device, loamx_ctx** out) {
+  if (!out) return LOAMX_ERR_BAD_PARAM;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return LOAMX_ERR_NO_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return LOAMX_ERR_NO_DEVICE;
+  loamx_ctx* ctx = new loamx_ctx;
+  ctx->device = device;
+  if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pinned), 256, hipHostMallocDefault) != hipSuccess) {
+    delete ctx;
+    return LOAMX_ERR_HIP;
+  }
+  ctx->stream = ctx->own_stream;
+  *out = ctx;
+  return LOAMX_OK;
+}
+
+void loamx_ctx_destroy(loamx_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (PendingEvent& pe : ctx->pending) {
+    (void)hipEventDestroy(pe.e0);
+    (void)hipEventDestroy(pe.e1);
+  }
+  for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+  for (Buf& b : ctx->ws)
+    if (b.p) (void)hipFree(b.p);
+  if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+int loamx_ctx_set_stream(loamx_ctx* ctx, void* hip_stream) {
+  if (!ctx) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return LOAMX_OK;
+}
+
+int loamx_ctx_synchronize(loamx_ctx* ctx) {
+  if (!ctx) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return LOAMX_OK;
+}
+
+size_t loamx_edge_capacity(const loamx_lidar_params* lidar, const loamx_fe_params* fe) {
+  ExtractParams P;
+  if (make_extract_params(nullptr, lidar, fe, P) != LOAMX_OK) return 0;
+  return edge_capacity(P);
+}
+size_t loamx_planar_capacity(const loamx_lidar_params* lidar, const loamx_fe_params* fe) {
+  ExtractParams P;
+  if (make_extract_params(nullptr, lidar, fe, P) != LOAMX_OK) return 0;
+  return planar_capacity(P);
+}
+
+/* ---- host entry points ---------------------------------------------------------------------------- */
+static int host_curv_mask(loamx_ctx* ctx, const double* xyz, size_t n_points, const loamx_lidar_params* lidar,
+                          const loamx_fe_params* fe, double* curvature_out, uint8_t* mask_out) {
+  if (!ctx) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!lidar || !fe) return fail(ctx, LOAMX_ERR_BAD_PARAM, "null parameter struct");
+  if (n_points != lidar->scan_lines * lidar->points_per_line) {  // common.h:104-113
+    char msg[256];
+    snprintf(msg, sizeof(msg), "LOAM: provided lidar scan size ( %zu)  does not match provided lidar parameters (%llu x %llu)",
+             n_points, (unsigned long long)lidar->scan_lines, (unsigned long long)lidar->points_per_line);
+    return fail(ctx, LOAMX_ERR_SCAN_SIZE, msg);
+  }
+  if (n_points == 0) return LOAMX_OK;
+  ExtractParams P;
+  int rc = make_extract_params(ctx, lidar, fe, P);
+  if (rc != LOAMX_OK) return rc;
+  ENSURE(ctx, WS_XYZ, n_points * 3 * sizeof(double));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_XYZ].p, xyz, n_points * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  rc = extract_dev(ctx, wsp<double>(ctx, WS_XYZ), 1, P, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true);
+  if (rc != LOAMX_OK) return rc;
+  if (curvature_out)
+    HIP_TRY(ctx, hipMemcpyAsync(curvature_out, ctx->ws[WS_CURV].p, n_points * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (mask_out)
+    HIP_TRY(ctx, hipMemcpyAsync(mask_out, ctx->ws[WS_MASK].p, n_points, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return LOAMX_OK;
+}
+
+int loamx_compute_curvature(loamx_ctx* ctx, const double* xyz, size_t n_points, const loamx_lidar_params* lidar,
+                            const loamx_fe_params* fe, double* curvature_out) {
+  return host_curv_mask(ctx, xyz, n_points, lidar, fe, curvature_out, nullptr);
+}
+
+int loamx_compute_valid_points(loamx_ctx* ctx, const double* xyz, size_t n_points, const loamx_lidar_params* lidar,
+                               const loamx_fe_params* fe, uint8_t* mask_out) {
+  return host_curv_mask(ctx, xyz, n_points, lidar, fe, nullptr, mask_out);
+}
+
+int loamx_extract_features(loamx_ctx* ctx, const double* xyz, size_t n_points, const loamx_lidar_params* lidar,
+                           const loamx_fe_params* fe, uint32_t* edge_idx, size_t edge_cap, size_t* n_edge,
+                           uint32_t* planar_idx, size_t planar_cap, size_t* n_planar) {
+  if (!ctx) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!lidar || !fe || !n_edge || !n_planar) return fail(ctx, LOAMX_ERR_BAD_PARAM, "null argument");
+  if (n_points != lidar->scan_lines * lidar->points_per_line) {
+    char msg[256];
+    snprintf(msg, sizeof(msg), "LOAM: provided lidar scan size ( %zu)  does not match provided lidar parameters (%llu x %llu)",
+             n_points, (unsigned long long)lidar->scan_lines, (unsigned long long)lidar->points_per_line);
+    return fail(ctx, LOAMX_ERR_SCAN_SIZE, msg);
+  }
+  *n_edge = 0, *n_planar = 0;
+  if (n_points == 0) return LOAMX_OK;
+  ExtractParams P;
+  int rc = make_extract_params(ctx, lidar, fe, P);
+  if (rc != LOAMX_OK) return rc;
+  const size_t ecap = edge_capacity(P), pcap = planar_capacity(P);
+  ENSURE(ctx, WS_XYZ, n_points * 3 * sizeof(double));
+  ENSURE(ctx, WS_EDGE_IDX, ecap * sizeof(uint32_t));
+  ENSURE(ctx, WS_PLANAR_IDX, pcap * sizeof(uint32_t));
+  ENSURE(ctx, WS_N_EDGE, sizeof(uint32_t));
+  ENSURE(ctx, WS_N_PLANAR, sizeof(uint32_t));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_XYZ].p, xyz, n_points * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  rc = extract_dev(ctx, wsp<double>(ctx, WS_XYZ), 1, P, wsp<uint32_t>(ctx, WS_EDGE_IDX), wsp<uint32_t>(ctx, WS_N_EDGE), nullptr,
+                   wsp<uint32_t>(ctx, WS_PLANAR_IDX), wsp<uint32_t>(ctx, WS_N_PLANAR), nullptr, false);
+  if (rc != LOAMX_OK) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_pinned[0], ctx->ws[WS_N_EDGE].p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_pinned[1], ctx->ws[WS_N_PLANAR].p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const size_t ne = ctx->h_pinned[0], npl = ctx->h_pinned[1];
+  *n_edge = ne, *n_planar = npl;
+  if (ne > edge_cap || npl > planar_cap) return fail(ctx, LOAMX_ERR_CAPACITY, "feature index capacity too small");
+  if (ne) HIP_TRY(ctx, hipMemcpy(edge_idx, ctx->ws[WS_EDGE_IDX].p, ne * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (npl) HIP_TRY(ctx, hipMemcpy(planar_idx, ctx->ws[WS_PLANAR_IDX].p, npl * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return LOAMX_OK;
+}
+
+namespace {
+struct DetailHook {
+  loamx_reg_detail* detail;
+  size_t n_se, n_sp;
+};
+int detail_hook(loamx_ctx* ctx, const RegBatch& B, uint32_t it, void* user) {
+  DetailHook* h = static_cast<DetailHook*>(user);
+  loamx_reg_detail* d = h->detail;
+  if (!d || it != d->pairs_iteration) return LOAMX_OK;
+  for (int kind = 0; kind < 2; kind++) {
+    const size_t n = kind ? h->n_sp : h->n_se;
+    uint32_t* out = kind ? d->plane_pairs : d->edge_pairs;
+    const size_t cap = kind ? d->plane_pairs_cap : d->edge_pairs_cap;
+    size_t* out_n = kind ? &d->n_plane_pairs : &d->n_edge_pairs;
+    *out_n = 0;
+    if (!out || cap == 0 || n == 0) continue;
+    std::vector<uint32_t> nearest(n);
+    HIP_TRY(ctx, hipMemcpyAsync(nearest.data(), kind ? B.assoc.nearest_plane : B.assoc.nearest_edge, n * sizeof(uint32_t),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    size_t m = 0;
+    for (size_t i = 0; i < n; i++) {
+      if (nearest[i] == 0xFFFFFFFFu) continue;
+      if (m < cap) out[2 * m] = (uint32_t)i, out[2 * m + 1] = nearest[i];
+      m++;
+    }
+    *out_n = m;
+  }
+  return LOAMX_OK;
+}
+}  // namespace
+
+int loamx_register_features(loamx_ctx* ctx, const double* src_edge, size_t n_se, const double* src_planar, size_t n_sp,
+                            const double* tgt_edge, size_t n_te, const double* tgt_planar, size_t n_tp,
+                            const double init_pose[7], const loamx_reg_params* reg, loamx_reg_result* result,
+                            loamx_reg_detail* detail) {
+  if (!ctx) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!result || !init_pose) return fail(ctx, LOAMX_ERR_BAD_PARAM, "null argument");
+  RegConfig C;
+  int rc = make_reg_config(ctx, reg, C);
+  if (rc != LOAMX_OK) return rc;
+  const size_t es = n_se > n_te ? n_se : n_te, ps = n_sp > n_tp ? n_sp : n_tp;
+  if (es > 0x7FFFFFFFull || ps > 0x7FFFFFFFull) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "feature set too large");
+  hipStream_t s = ctx->stream;
+  const size_t esz = (es ? es : 1) * 3 * sizeof(double), psz = (ps ? ps : 1) * 3 * sizeof(double);
+  ENSURE(ctx, WS_SRC_E, esz);
+  ENSURE(ctx, WS_TGT_E, esz);
+  ENSURE(ctx, WS_SRC_P, psz);
+  ENSURE(ctx, WS_TGT_P, psz);
+  ENSURE(ctx, WS_FCOUNTS, 4 * sizeof(uint32_t));
+  ENSURE(ctx, WS_RESULTS, sizeof(loamx_reg_result));
+  ENSURE(ctx, WS_INIT, 7 * sizeof(double));
+  if (n_se) HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_SRC_E].p, src_edge, n_se * 24, hipMemcpyHostToDevice, s));
+  if (n_te) HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_TGT_E].p, tgt_edge, n_te * 24, hipMemcpyHostToDevice, s));
+  if (n_sp) HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_SRC_P].p, src_planar, n_sp * 24, hipMemcpyHostToDevice, s));
+  if (n_tp) HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_TGT_P].p, tgt_planar, n_tp * 24, hipMemcpyHostToDevice, s));
+  const uint32_t counts[4] = {(uint32_t)n_se, (uint32_t)n_sp, (uint32_t)n_te, (uint32_t)n_tp};
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_FCOUNTS].p, counts, sizeof(counts), hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_INIT].p, init_pose, 7 * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));  // `counts` is a stack array
+  RegInputs in{};
+  in.n_pairs = 1, in.edge_stride = es, in.planar_stride = ps, in.in_pitch = 1;
+  in.src_edge = wsp<double>(ctx, WS_SRC_E), in.src_planar = wsp<double>(ctx, WS_SRC_P);
+  in.tgt_edge = wsp<double>(ctx, WS_TGT_E), in.tgt_planar = wsp<double>(ctx, WS_TGT_P);
+  const uint32_t* fc = wsp<uint32_t>(ctx, WS_FCOUNTS);
+  in.n_src_edge = fc, in.n_src_planar = fc + 1, in.n_tgt_edge = fc + 2, in.n_tgt_planar = fc + 3;
+  in.init = wsp<double>(ctx, WS_INIT);
+  DetailHook hook{detail, n_se, n_sp};
+  if (detail) detail->n_iter_info = 0, detail->n_edge_pairs = 0, detail->n_plane_pairs = 0;
+  rc = register_dev(ctx, in, C, wsp<loamx_reg_result>(ctx, WS_RESULTS), detail && detail->iter_info,
+                    detail ? detail_hook : nullptr, &hook);
+  if (rc != LOAMX_OK) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(result, ctx->ws[WS_RESULTS].p, sizeof(loamx_reg_result), hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  if (detail && detail->iter_info && result->iterations) {
+    HIP_TRY(ctx, hipMemcpy(detail->iter_info, ctx->ws[WS_ITERINFO].p, result->iterations * sizeof(loamx_iter_info),
+                           hipMemcpyDeviceToHost));
+    detail->n_iter_info = result->iterations;
+  }
+  return LOAMX_OK;
+}
+
+/* ---- device-resident batch entry points ----------------------------------------------------------- */
+int loamx_extract_features_batch_dev(loamx_ctx* ctx, const double* d_xyz, size_t n_scans, const loamx_lidar_params* lidar,
+                                     const loamx_fe_params* fe, uint32_t* d_edge_idx, uint32_t* d_n_edge,
+                                     double* d_edge_xyz, uint32_t* d_planar_idx, uint32_t* d_n_planar,
+                                     double* d_planar_xyz) {
+  if (!ctx) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ExtractParams P;
+  int rc = make_extract_params(ctx, lidar, fe, P);
+  if (rc != LOAMX_OK) return rc;
+  return extract_dev(ctx, d_xyz, n_scans, P, d_edge_idx, d_n_edge, d_edge_xyz, d_planar_idx, d_n_planar, d_planar_xyz, false);
+}
+
+int loamx_register_features_batch_dev(loamx_ctx* ctx, size_t n_pairs, const double* d_src_edge,
+                                      const uint32_t* d_n_src_edge, const double* d_src_planar,
+                                      const uint32_t* d_n_src_planar, const double* d_tgt_edge,
+                                      const uint32_t* d_n_tgt_edge, const double* d_tgt_planar,
+                                      const uint32_t* d_n_tgt_planar, size_t edge_stride, size_t planar_stride,
+                                      const double* d_init, const loamx_reg_params* reg, loamx_reg_result* d_results) {
+  if (!ctx) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  RegConfig C;
+  int rc = make_reg_config(ctx, reg, C);
+  if (rc != LOAMX_OK) return rc;
+  RegInputs in{n_pairs, edge_stride, planar_stride, 1, d_src_edge, d_src_planar, d_tgt_edge, d_tgt_planar,
+               d_n_src_edge, d_n_src_planar, d_n_tgt_edge, d_n_tgt_planar, d_init};
+  return register_dev(ctx, in, C, d_results, false, nullptr, nullptr);
+}
+
+int loamx_register_scan_pairs_dev(loamx_ctx* ctx, const double* d_xyz, size_t n_pairs, const loamx_lidar_params* lidar,
+                                  const loamx_fe_params* fe, const loamx_reg_params* reg, loamx_reg_result* d_results) {
+  if (!ctx) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ExtractParams P;
+  int rc = make_extract_params(ctx, lidar, fe, P);
+  if (rc != LOAMX_OK) return rc;
+  RegConfig C;
+  rc = make_reg_config(ctx, reg, C);
+  if (rc != LOAMX_OK) return rc;
+  if (n_pairs == 0) return LOAMX_OK;
+  const size_t n_scans = 2 * n_pairs, ecap = edge_capacity(P), pcap = planar_capacity(P);
+  ENSURE(ctx, WS_EDGE_IDX, n_scans * ecap * sizeof(uint32_t));
+  ENSURE(ctx, WS_PLANAR_IDX, n_scans * pcap * sizeof(uint32_t));
+  ENSURE(ctx, WS_N_EDGE, n_scans * sizeof(uint32_t));
+  ENSURE(ctx, WS_N_PLANAR, n_scans * sizeof(uint32_t));
+  ENSURE(ctx, WS_EDGE_XYZ, n_scans * ecap * 3 * sizeof(double));
+  ENSURE(ctx, WS_PLANAR_XYZ, n_scans * pcap * 3 * sizeof(double));
+  rc = extract_dev(ctx, d_xyz, n_scans, P, wsp<uint32_t>(ctx, WS_EDGE_IDX), wsp<uint32_t>(ctx, WS_N_EDGE),
+                   wsp<double>(ctx, WS_EDGE_XYZ), wsp<uint32_t>(ctx, WS_PLANAR_IDX), wsp<uint32_t>(ctx, WS_N_PLANAR),
+                   wsp<double>(ctx, WS_PLANAR_XYZ), false);
+  if (rc != LOAMX_OK) return rc;
+  // scan 2p = target, scan 2p+1 = source (interleaved => in_pitch 2)
+  RegInputs in{};
+  in.n_pairs = n_pairs, in.edge_stride = ecap, in.planar_stride = pcap, in.in_pitch = 2;
+  in.tgt_edge = wsp<double>(ctx, WS_EDGE_XYZ), in.src_edge = in.tgt_edge + ecap * 3;
+  in.tgt_planar = wsp<double>(ctx, WS_PLANAR_XYZ), in.src_planar = in.tgt_planar + pcap * 3;
+  in.n_tgt_edge = wsp<uint32_t>(ctx, WS_N_EDGE), in.n_src_edge = in.n_tgt_edge + 1;
+  in.n_tgt_planar = wsp<uint32_t>(ctx, WS_N_PLANAR), in.n_src_planar = in.n_tgt_planar + 1;
+  in.init = nullptr;
+  return register_dev(ctx, in, C, d_results, false, nullptr, nullptr);
+}
+
+/* ---- kernel timing ------------------------------------------------------------------------------------ */
+int loamx_ctx_enable_kernel_timing(loamx_ctx* ctx, int enable) {
+  if (!ctx) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  ctx->timing = enable != 0;
+  return LOAMX_OK;
+}
+
+static int read_sweep_slots(loamx_ctx* ctx, unsigned long long out[2]) {
+  out[0] = out[1] = 0;
+  if (!ctx->ws[WS_COUNTERS].p) return LOAMX_OK;
+  HIP_TRY(ctx, hipMemcpy(out, wsp<unsigned char>(ctx, WS_COUNTERS) + 8, 16, hipMemcpyDeviceToHost));
+  return LOAMX_OK;
+}
+
+int loamx_ctx_reset_kernel_stats(loamx_ctx* ctx) {
+  if (!ctx) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = resolve_events(ctx);
+  if (rc != LOAMX_OK) return rc;
+  memset(ctx->stats, 0, sizeof(ctx->stats));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->ws[WS_COUNTERS].p) HIP_TRY(ctx, hipMemset(wsp<unsigned char>(ctx, WS_COUNTERS) + 8, 0, 16));
+  return LOAMX_OK;
+}
+
+int loamx_ctx_get_kernel_stats(loamx_ctx* ctx, loamx_kernel_stat* stats) {
+  if (!ctx || !stats) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = resolve_events(ctx);
+  if (rc != LOAMX_OK) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  unsigned long long slots[2];
+  rc = read_sweep_slots(ctx, slots);
+  if (rc != LOAMX_OK) return rc;
+  memcpy(stats, ctx->stats, sizeof(ctx->stats));
+  stats[LOAMX_K_SWEEP].algorithmic_bytes = 72.0 * (double)slots[0] + 56.0 * (double)slots[1];
+  return LOAMX_OK;
+}
+
+/* ---- synthetic workload ------------------------------------------------------------------------------- */
+void loamx_synth_pair_pose(uint64_t seed, uint64_t pair_id, double pose_out[7]) {
+  const loamx_synth::Pose7 p = loamx_synth::pair_pose(seed, pair_id);
+  for (int i = 0; i < 4; i++) pose_out[i] = p.q[i];
+  for (int i = 0; i < 3; i++) pose_out[4 + i] = p.t[i];
+}
+
+void loamx_synth_scan_host(uint64_t seed, uint64_t pair_id, uint32_t which, uint32_t H, uint32_t W, double sigma,
+                           double* xyz_out) {
+  const loamx_synth::Pose7 pose = loamx_synth::pair_pose(seed, pair_id);
+  for (uint32_t l = 0; l < H; l++)
+    for (uint32_t c = 0; c < W; c++)
+      loamx_synth::scan_point(seed, pair_id, which, pose, l, c, H, W, sigma, xyz_out + 3 * ((size_t)l * W + c));
+}
+
+int loamx_synth_scan_pairs_dev(loamx_ctx* ctx, uint64_t seed, uint64_t first_pair, size_t n_pairs, uint32_t H, uint32_t W,
+                               double sigma, double* d_xyz) {
+  if (!ctx) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  launch_synth_pairs(seed, first_pair, n_pairs, H, W, sigma, d_xyz, ctx->stream);
+  CHECK_LAUNCH(ctx, "synth_kernel");
+  return LOAMX_OK;
+}
+
+/* ---- raw device memory helpers ------------------------------------------------------------------------ */
+int loamx_dev_alloc(loamx_ctx* ctx, size_t bytes, void** d_ptr) {
+  if (!ctx || !d_ptr) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMalloc(d_ptr, bytes ? bytes : 8));
+  return LOAMX_OK;
+}
+int loamx_dev_free(loamx_ctx* ctx, void* d_ptr) {
+  if (!ctx) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipFree(d_ptr));
+  return LOAMX_OK;
+}
+int loamx_copy_to_device(loamx_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+  if (!ctx) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return LOAMX_OK;
+}
+int loamx_copy_to_host(loamx_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+  if (!ctx) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return LOAMX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+// loamx_internal.h — declarations shared by the .hip translation units of libloamx.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/loamx.h"
+#include "extract_math.h"
+#include "reg_math.h"
+
+namespace loamx {
+
+/* ---- extraction (extract_kernels.hip) ---------------------------------------------------------- */
+constexpr int kMaxNeighborPoints = 16;  // LDS halo bound of curvature_valid_kernel
+constexpr int kMaxLineWidth = 4096;     // select_kernel keeps one line's curvature + mask in LDS
+
+// staging layout written by select_kernel: per (scan, line, sector) a fixed slot of cap entries
+struct ExtractStage {
+  uint32_t* edge_stage;    // [n_scans][H][S][cap_edge]
+  uint32_t* planar_stage;  // [n_scans][H][S][cap_planar]
+  uint32_t* edge_cnt;      // [n_scans][H][S]
+  uint32_t* planar_cnt;    // [n_scans][H][S]
+};
+
+void launch_curvature_valid(const double* d_xyz, size_t n_scans, const ExtractParams& P, double* d_curv,
+                            uint8_t* d_mask, hipStream_t s);
+void launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, const ExtractParams& P,
+                   const ExtractStage& st, hipStream_t s);
+// edge_stride / planar_stride: entries per scan in the output arrays
+void launch_compact(const double* d_xyz, size_t n_scans, const ExtractParams& P, const ExtractStage& st,
+                    uint32_t* d_edge_idx, uint32_t* d_n_edge, double* d_edge_xyz, size_t edge_stride,
+                    uint32_t* d_planar_idx, uint32_t* d_n_planar, double* d_planar_xyz, size_t planar_stride,
+                    hipStream_t s);
+
+/* ---- registration (register_kernels.hip) ------------------------------------------------------- */
+struct RegConfig {
+  int k_edge, k_plane;
+  int min_line_pts, min_plane_pts;
+  double r_edge, r_plane;
+  double min_line_cond, max_avg_plane_dist;
+  uint32_t max_iterations;
+  double rot_thresh, pos_thresh;
+  uint32_t min_associations;
+};
+
+// One target feature set's spatial index (device pointers into the workspace)
+struct GridSet {
+  GridDesc* desc;        // [n_pairs]
+  uint32_t* cell_start;  // [n_pairs][kGridCellsCap + 1]
+  double* sorted_xyz;    // [n_pairs][stride][3]
+  uint32_t* sorted_idx;  // [n_pairs][stride]
+  size_t stride;
+};
+
+// Association records, structure-of-arrays over the whole batch (field-major) so the residual
+// sweep streams each field with fully coalesced 8-byte loads.
+//   edges : 9 fields (moved point xyz, line a xyz, line b xyz) x n_pairs x edge_stride
+//   planes: 7 fields (moved point xyz, normal xyz, d)          x n_pairs x planar_stride
+// An invalid slot has NaN in field 0.
+struct AssocBuffers {
+  double* edge;       // [9][n_pairs * edge_stride]
+  double* plane;      // [7][n_pairs * planar_stride]
+  uint32_t* nearest_edge;   // [n_pairs * edge_stride]   nearest target index (detail capture)
+  uint32_t* nearest_plane;  // [n_pairs * planar_stride]
+  uint32_t* n_assoc;  // [n_pairs][2] valid edge / plane associations of the current iteration
+};
+
+struct PairState {
+  double est[7];
+  LmState lm;
+  uint32_t active;       // outer loop still running
+  uint32_t termination;
+  uint32_t iterations;
+  uint32_t first_sweep;  // next sweep is the iteration-0 evaluation
+};
+
+constexpr int kSweepThreads = 256;
+constexpr int kSweepItems = 8;  // association slots per thread
+constexpr int kSweepChunk = kSweepThreads * kSweepItems;
+
+struct RegBatch {
+  size_t n_pairs;
+  size_t edge_stride, planar_stride;  // capacity (points) of one feature set; also the slot pitch of assoc/grid arrays
+  // Input feature sets of pair p start at base + p * in_pitch * stride * 3 and their counts at
+  // n[p * in_pitch]: in_pitch = 1 for separate arrays, 2 when source and target scans are interleaved.
+  uint32_t in_pitch;
+  const double* src_edge;
+  const uint32_t* n_src_edge;
+  const double* src_planar;
+  const uint32_t* n_src_planar;
+  const double* tgt_edge;
+  const uint32_t* n_tgt_edge;
+  const double* tgt_planar;
+  const uint32_t* n_tgt_planar;
+  const double* init;  // may be null
+  GridSet grid_edge, grid_plane;
+  AssocBuffers assoc;
+  PairState* state;      // [n_pairs]
+  double* partials;      // [n_pairs][blocks_per_pair][kAccSize]
+  uint32_t blocks_per_pair;
+  uint32_t* n_active;    // device counter read back by the host after every outer iteration
+  unsigned long long* sweep_slots;  // [2] edge / plane association slots streamed by sweep_kernel (roofline bytes)
+  loamx_iter_info* iter_info;  // optional [n_pairs][max_iterations]
+};
+
+void launch_grid_build(const RegBatch& B, const RegConfig& C, hipStream_t s);
+void launch_state_init(const RegBatch& B, const RegConfig& C, hipStream_t s);
+void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s);
+void launch_lm_begin(const RegBatch& B, const RegConfig& C, uint32_t iteration, hipStream_t s);
+void launch_sweep(const RegBatch& B, hipStream_t s);
+void launch_lm_step(const RegBatch& B, hipStream_t s);
+void launch_outer_update(const RegBatch& B, const RegConfig& C, uint32_t iteration, hipStream_t s);
+void launch_write_results(const RegBatch& B, loamx_reg_result* d_results, hipStream_t s);
+
+/* ---- synthetic generator (synth_kernels.hip) --------------------------------------------------- */
+void launch_synth_pairs(uint64_t seed, uint64_t first_pair, size_t n_pairs, uint32_t H, uint32_t W, double sigma,
+                        double* d_xyz, hipStream_t s);
+
+}  // namespace loamx

@@ -1,0 +1,403 @@
+// register_kernels.hip — loam::registerFeatures on gfx950 for a batch of independent pairs
+// (reference: loam/include/loam/registration-inl.h:11-78, loam/src/registration.cpp:23-103).
+//
+// Per outer ICF iteration the host enqueues, for all pairs at once:
+//   associate_kernel<edge>, associate_kernel<plane>   rows a16-a19: move the source point by the
+//                           current estimate, exact k-NN in the target's uniform grid (replaces the
+//                           nanoflann KD-tree), fitLine / fitPlane in registers, guards, write the
+//                           association record (structure of arrays).
+//   lm_begin_kernel         min_associations check, Ceres problem/solver state reset.
+//   5 x { sweep_kernel, lm_step_kernel }
+//                           rows a20-a22: sweep = residual + Jacobian row + Huber + 6x6 normal
+//                           equations over all association slots of a pair, streamed from HBM
+//                           (72 B per edge slot, 56 B per plane slot), wavefront shuffle + LDS
+//                           reduction to one 29-double partial per workgroup; lm_step = fixed-order
+//                           reduction of the partials and the trust-region bookkeeping of one
+//                           Levenberg-Marquardt iteration (6x6 Cholesky) per pair.
+//   outer_update_kernel     row a23: est <- update (+) est, convergence test, termination type.
+// grid_build_kernel (once per call) builds the per-target-set grid entirely in LDS.
+#include "loamx_internal.h"
+
+namespace loamx {
+
+namespace {
+
+/* ------------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+  return v;
+}
+
+constexpr int kBuildThreads = 1024;
+
+// One workgroup builds the whole index of one target set: bounding box, cell size, counting sort by
+// cell with the cell table in LDS (128 KiB), exclusive scan, scatter. Deterministic in everything
+// but the order of points inside a cell, which the search does not depend on.
+__global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double* __restrict__ pts_base,
+                                                                   const uint32_t* __restrict__ n_pts, size_t stride,
+                                                                   uint32_t in_pitch, double max_dist, GridSet gs) {
+  __shared__ uint32_t s_cells[kGridCellsCap];
+  __shared__ double s_red[6][kBuildThreads / 64];
+  __shared__ uint32_t s_wave_sum[kBuildThreads / 64];
+  __shared__ GridDesc s_g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t pair = blockIdx.x;
+  const uint32_t n_raw = n_pts[pair * in_pitch];
+  const uint32_t n = n_raw < stride ? n_raw : (uint32_t)stride;
+  const double* __restrict__ pts = pts_base + pair * in_pitch * stride * 3;
+
+  double lx = kDblMax, ly = kDblMax, lz = kDblMax, hx = -kDblMax, hy = -kDblMax, hz = -kDblMax;
+  for (uint32_t i = tid; i < n; i += kBuildThreads) {
+    const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+    lx = fmin(lx, x), ly = fmin(ly, y), lz = fmin(lz, z);
+    hx = fmax(hx, x), hy = fmax(hy, y), hz = fmax(hz, z);
+  }
+  lx = wave_min(lx), ly = wave_min(ly), lz = wave_min(lz);
+  hx = wave_max(hx), hy = wave_max(hy), hz = wave_max(hz);
+  if (lane == 0) {
+    s_red[0][wave] = lx, s_red[1][wave] = ly, s_red[2][wave] = lz;
+    s_red[3][wave] = hx, s_red[4][wave] = hy, s_red[5][wave] = hz;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double a[6];
+    for (int k = 0; k < 6; k++) {
+      a[k] = s_red[k][0];
+      for (int w = 1; w < kBuildThreads / 64; w++) a[k] = k < 3 ? fmin(a[k], s_red[k][w]) : fmax(a[k], s_red[k][w]);
+    }
+    GridDesc g;
+    grid_choose(g, v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), n, max_dist, kGridCellsCap);
+    s_g = g;
+    gs.desc[pair] = g;
+  }
+  __syncthreads();
+  const GridDesc g = s_g;
+  const uint32_t ncell = (uint32_t)(g.nx * g.ny * g.nz);
+  for (uint32_t c = tid; c < ncell; c += kBuildThreads) s_cells[c] = 0;
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += kBuildThreads) {
+    const uint32_t cell = grid_cell_of_point(g, v3(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]));
+    atomicAdd(&s_cells[cell], 1u);
+  }
+  __syncthreads();
+  // exclusive scan of s_cells[0..ncell): contiguous chunk per thread + block scan of chunk sums
+  const uint32_t per = (ncell + kBuildThreads - 1) / kBuildThreads;
+  const uint32_t c0 = tid * per, c1 = c0 + per < ncell ? c0 + per : ncell;
+  uint32_t local = 0;
+  for (uint32_t c = c0; c < c1; c++) local += s_cells[c];
+  uint32_t incl = local;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) s_wave_sum[wave] = incl;
+  __syncthreads();
+  uint32_t wave_off = 0;
+  for (int w = 0; w < wave; w++) wave_off += s_wave_sum[w];
+  uint32_t run = wave_off + incl - local;
+  uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
+  for (uint32_t c = c0; c < c1; c++) {
+    const uint32_t cnt = s_cells[c];
+    s_cells[c] = run;
+    cs[c] = run;
+    run += cnt;
+  }
+  if (tid == 0) cs[ncell] = n;
+  __syncthreads();
+  double* __restrict__ sx = gs.sorted_xyz + pair * gs.stride * 3;
+  uint32_t* __restrict__ si = gs.sorted_idx + pair * gs.stride;
+  for (uint32_t i = tid; i < n; i += kBuildThreads) {
+    const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+    const uint32_t cell = grid_cell_of_point(g, v3(x, y, z));
+    const uint32_t pos = atomicAdd(&s_cells[cell], 1u);
+    sx[3 * (size_t)pos] = x, sx[3 * (size_t)pos + 1] = y, sx[3 * (size_t)pos + 2] = z;
+    si[pos] = i;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+__global__ void state_init_kernel(RegBatch B, RegConfig C) {
+  const size_t pair = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= B.n_pairs) return;
+  PairState& S = B.state[pair];
+  for (int i = 0; i < 7; i++) S.est[i] = B.init ? B.init[pair * 7 + i] : (i == 3 ? 1.0 : 0.0);
+  S.active = C.max_iterations > 0 ? 1u : 0u;
+  S.termination = LOAMX_MAX_ITER;  // registration-inl.h:27
+  S.iterations = 0;
+  S.first_sweep = 0;
+  S.lm.active = 0;
+  B.assoc.n_assoc[2 * pair] = 0;
+  B.assoc.n_assoc[2 * pair + 1] = 0;
+}
+
+constexpr int kAssocThreads = 256;
+
+template <bool PLANE>
+__global__ __launch_bounds__(kAssocThreads) void associate_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
+  __shared__ uint32_t s_count[kAssocThreads / 64];
+  const size_t pair = blockIdx.x / blocks_per_pair;
+  const uint32_t i = (blockIdx.x % blocks_per_pair) * kAssocThreads + threadIdx.x;
+  const PairState& S = B.state[pair];
+  if (!S.active) return;  // uniform per workgroup
+  const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
+  const uint32_t n_src = PLANE ? B.n_src_planar[pair * B.in_pitch] : B.n_src_edge[pair * B.in_pitch];
+  const GridSet& gs = PLANE ? B.grid_plane : B.grid_edge;
+  bool valid = false;
+  if (i < n_src && i < stride) {
+    const double* __restrict__ src = (PLANE ? B.src_planar : B.src_edge) + (pair * B.in_pitch * stride + i) * 3;
+    const Vec3 p = pose_act(S.est, v3(src[0], src[1], src[2]));  // registration.cpp:34 / :75
+    const GridDesc g = gs.desc[pair];
+    const uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
+    const double* __restrict__ sx = gs.sorted_xyz + pair * gs.stride * 3;
+    const uint32_t* __restrict__ si = gs.sorted_idx + pair * gs.stride;
+    KnnResult r;
+    const int kept = knn_search(g, cs, sx, si, p, PLANE ? C.k_plane : C.k_edge, PLANE ? C.r_plane : C.r_edge, r);
+    double prim[6] = {0, 0, 0, 0, 0, 0};
+    if (kept >= (PLANE ? C.min_plane_pts : C.min_line_pts)) {  // registration.cpp:39 / :80
+      Vec3 nb[kMaxK];
+#pragma unroll
+      for (int j = 0; j < kMaxK; j++) {
+        if (j < kept) nb[j] = v3(sx[3 * (size_t)r.pos[j]], sx[3 * (size_t)r.pos[j] + 1], sx[3 * (size_t)r.pos[j] + 2]);
+        else nb[j] = v3(0, 0, 0);
+      }
+      if (PLANE) {
+        Vec3 nrm;
+        double d;
+        const double avg = fit_plane(nb, kept, nrm, d);
+        valid = !(avg > C.max_avg_plane_dist);  // registration.cpp:90
+        prim[0] = nrm.x, prim[1] = nrm.y, prim[2] = nrm.z, prim[3] = d;
+      } else {
+        Vec3 a, b;
+        fit_line(nb, kept, a, b);
+        valid = !(kDblMax < C.min_line_cond);  // registration.cpp:49 (condition number is always DBL_MAX)
+        prim[0] = a.x, prim[1] = a.y, prim[2] = a.z, prim[3] = b.x, prim[4] = b.y, prim[5] = b.z;
+      }
+    }
+    const size_t field = B.n_pairs * stride, slot = pair * stride + i;
+    double* __restrict__ rec = PLANE ? B.assoc.plane : B.assoc.edge;
+    rec[slot] = valid ? p.x : __longlong_as_double(0x7FF8000000000000ll);
+    rec[field + slot] = p.y;
+    rec[2 * field + slot] = p.z;
+#pragma unroll
+    for (int f = 0; f < (PLANE ? 4 : 6); f++) rec[(3 + f) * field + slot] = prim[f];
+    (PLANE ? B.assoc.nearest_plane : B.assoc.nearest_edge)[slot] = valid ? r.orig[0] : 0xFFFFFFFFu;
+  }
+  const unsigned long long m = __ballot(valid);
+  if ((threadIdx.x & 63) == 0) s_count[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t c = 0;
+    for (int w = 0; w < kAssocThreads / 64; w++) c += s_count[w];
+    if (c) atomicAdd(&B.assoc.n_assoc[2 * pair + (PLANE ? 1 : 0)], c);
+  }
+}
+
+__global__ void lm_begin_kernel(RegBatch B, RegConfig C, uint32_t iteration) {
+  const size_t pair = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= B.n_pairs) return;
+  PairState& S = B.state[pair];
+  if (!S.active) return;
+  const uint32_t ne = B.assoc.n_assoc[2 * pair], np = B.assoc.n_assoc[2 * pair + 1];
+  B.assoc.n_assoc[2 * pair] = 0;
+  B.assoc.n_assoc[2 * pair + 1] = 0;
+  if ((uint64_t)ne + np < C.min_associations) {  // registration-inl.h:45-48
+    S.termination = LOAMX_INSUFFICIENT_ASSOCIATIONS;
+    S.active = 0;
+    S.lm.active = 0;
+    return;
+  }
+  lm_init(S.lm);
+  S.first_sweep = 1;
+  if (B.iter_info) {
+    loamx_iter_info& I = B.iter_info[pair * C.max_iterations + iteration];
+    for (int i = 0; i < 7; i++) I.target_T_source_init[i] = S.est[i];
+    I.n_edge_associations = ne;
+    I.n_plane_associations = np;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(kSweepThreads) void sweep_kernel(RegBatch B) {
+  __shared__ double s_part[kSweepThreads / 64][kAccSize];
+  const size_t pair = blockIdx.x / B.blocks_per_pair;
+  const uint32_t blk = blockIdx.x % B.blocks_per_pair;
+  const PairState& S = B.state[pair];
+  if (!S.active || !S.lm.active) return;  // uniform per workgroup
+  double x[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) x[i] = S.lm.xeval[i];
+  const uint32_t n_se_raw = B.n_src_edge[pair * B.in_pitch], n_sp_raw = B.n_src_planar[pair * B.in_pitch];
+  const uint32_t n_se = n_se_raw < B.edge_stride ? n_se_raw : (uint32_t)B.edge_stride;
+  const uint32_t n_sp = n_sp_raw < B.planar_stride ? n_sp_raw : (uint32_t)B.planar_stride;
+  const size_t efield = B.n_pairs * B.edge_stride, pfield = B.n_pairs * B.planar_stride;
+  const double* __restrict__ E = B.assoc.edge + pair * B.edge_stride;
+  const double* __restrict__ Pl = B.assoc.plane + pair * B.planar_stride;
+  double acc[kAccSize];
+#pragma unroll
+  for (int j = 0; j < kAccSize; j++) acc[j] = 0.0;
+  // the slot space of a pair is [edges 0..n_se) ++ [planes 0..n_sp); chunk `blk` of it
+  const uint32_t total = n_se + n_sp;
+  const uint32_t base = blk * kSweepChunk;
+  if (blk == 0 && threadIdx.x == 0 && B.sweep_slots) {
+    atomicAdd(&B.sweep_slots[0], (unsigned long long)n_se);
+    atomicAdd(&B.sweep_slots[1], (unsigned long long)n_sp);
+  }
+#pragma unroll 1
+  for (int it = 0; it < kSweepItems; it++) {
+    const uint32_t v = base + it * kSweepThreads + threadIdx.x;
+    if (v >= total) break;
+    if (v < n_se) {
+      const double px = E[v];
+      if (px == px) {
+        double prim[6];
+#pragma unroll
+        for (int f = 0; f < 6; f++) prim[f] = E[(3 + f) * efield + v];
+        residual_accumulate(false, v3(px, E[efield + v], E[2 * efield + v]), prim, x, acc);
+      }
+    } else {
+      const uint32_t q = v - n_se;
+      const double px = Pl[q];
+      if (px == px) {
+        double prim[6];
+#pragma unroll
+        for (int f = 0; f < 4; f++) prim[f] = Pl[(3 + f) * pfield + q];
+        prim[4] = prim[5] = 0.0;
+        residual_accumulate(true, v3(px, Pl[pfield + q], Pl[2 * pfield + q]), prim, x, acc);
+      }
+    }
+  }
+  // wavefront shuffle reduction, then LDS across the 4 wavefronts, fixed order => deterministic
+#pragma unroll
+  for (int j = 0; j < kAccSize; j++) {
+    double v = acc[j];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off);
+    acc[j] = v;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < kAccSize; j++) s_part[wave][j] = acc[j];
+  }
+  __syncthreads();
+  if (threadIdx.x < kAccSize) {
+    double v = s_part[0][threadIdx.x];
+    for (int w = 1; w < kSweepThreads / 64; w++) v += s_part[w][threadIdx.x];
+    B.partials[(pair * B.blocks_per_pair + blk) * kAccSize + threadIdx.x] = v;
+  }
+}
+
+__global__ void lm_step_kernel(RegBatch B) {
+  const size_t pair = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= B.n_pairs) return;
+  PairState& S = B.state[pair];
+  if (!S.active || !S.lm.active) return;
+  const uint32_t n_se_raw = B.n_src_edge[pair * B.in_pitch], n_sp_raw = B.n_src_planar[pair * B.in_pitch];
+  const uint32_t n_se = n_se_raw < B.edge_stride ? n_se_raw : (uint32_t)B.edge_stride;
+  const uint32_t n_sp = n_sp_raw < B.planar_stride ? n_sp_raw : (uint32_t)B.planar_stride;
+  const uint32_t used = (n_se + n_sp + kSweepChunk - 1) / kSweepChunk;  // blocks that wrote a partial
+  double acc[kAccSize];
+  for (int j = 0; j < kAccSize; j++) acc[j] = 0.0;
+  for (uint32_t b = 0; b < used && b < B.blocks_per_pair; b++) {
+    const double* __restrict__ p = B.partials + (pair * B.blocks_per_pair + b) * kAccSize;
+    for (int j = 0; j < kAccSize; j++) acc[j] += p[j];
+  }
+  LmState lm = S.lm;
+  lm_consume(lm, acc, S.first_sweep != 0);
+  S.lm = lm;
+  S.first_sweep = 0;
+}
+
+__global__ void outer_update_kernel(RegBatch B, RegConfig C, uint32_t iteration) {
+  const size_t pair = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= B.n_pairs) return;
+  PairState& S = B.state[pair];
+  if (!S.active) return;
+  double upd[7];
+  for (int i = 0; i < 7; i++) upd[i] = S.lm.x_user[i];
+  if (B.iter_info) {
+    loamx_iter_info& I = B.iter_info[pair * C.max_iterations + iteration];
+    for (int i = 0; i < 7; i++) I.estimate_update[i] = upd[i];
+  }
+  S.iterations = iteration + 1;
+  double est[7];
+  for (int i = 0; i < 7; i++) est[i] = S.est[i];
+  const bool converged = outer_update(est, upd, C.rot_thresh, C.pos_thresh);  // registration-inl.h:65-73
+  for (int i = 0; i < 7; i++) S.est[i] = est[i];
+  if (converged) {
+    S.termination = LOAMX_CONVERGED;
+    S.active = 0;
+  } else if (iteration + 1 >= C.max_iterations) {
+    S.active = 0;  // termination stays MAX_ITER
+  } else {
+    atomicAdd(B.n_active, 1u);
+  }
+}
+
+__global__ void write_results_kernel(RegBatch B, loamx_reg_result* __restrict__ out) {
+  const size_t pair = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= B.n_pairs) return;
+  const PairState& S = B.state[pair];
+  for (int i = 0; i < 7; i++) out[pair].pose[i] = S.est[i];
+  out[pair].termination = S.termination;
+  out[pair].iterations = S.iterations;
+}
+
+inline unsigned per_pair_grid(size_t n_pairs) { return (unsigned)((n_pairs + 63) / 64); }
+
+}  // namespace
+
+void launch_grid_build(const RegBatch& B, const RegConfig& C, hipStream_t s) {
+  if (B.n_pairs == 0) return;
+  hipLaunchKernelGGL(grid_build_kernel, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.tgt_edge, B.n_tgt_edge,
+                     B.edge_stride, B.in_pitch, C.r_edge, B.grid_edge);
+  hipLaunchKernelGGL(grid_build_kernel, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.tgt_planar,
+                     B.n_tgt_planar, B.planar_stride, B.in_pitch, C.r_plane, B.grid_plane);
+}
+
+void launch_state_init(const RegBatch& B, const RegConfig& C, hipStream_t s) {
+  if (B.n_pairs == 0) return;
+  hipLaunchKernelGGL(state_init_kernel, dim3(per_pair_grid(B.n_pairs)), dim3(64), 0, s, B, C);
+}
+
+void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s) {
+  if (B.n_pairs == 0) return;
+  const uint32_t be = (uint32_t)((B.edge_stride + kAssocThreads - 1) / kAssocThreads);
+  const uint32_t bp = (uint32_t)((B.planar_stride + kAssocThreads - 1) / kAssocThreads);
+  if (be) hipLaunchKernelGGL(associate_kernel<false>, dim3((unsigned)(B.n_pairs * be)), dim3(kAssocThreads), 0, s, B, C, be);
+  if (bp) hipLaunchKernelGGL(associate_kernel<true>, dim3((unsigned)(B.n_pairs * bp)), dim3(kAssocThreads), 0, s, B, C, bp);
+}
+
+void launch_sweep(const RegBatch& B, hipStream_t s) {
+  if (B.n_pairs == 0 || B.blocks_per_pair == 0) return;
+  hipLaunchKernelGGL(sweep_kernel, dim3((unsigned)(B.n_pairs * B.blocks_per_pair)), dim3(kSweepThreads), 0, s, B);
+}
+
+void launch_lm_step(const RegBatch& B, hipStream_t s) {
+  if (B.n_pairs == 0) return;
+  hipLaunchKernelGGL(lm_step_kernel, dim3(per_pair_grid(B.n_pairs)), dim3(64), 0, s, B);
+}
+
+void launch_lm_begin(const RegBatch& B, const RegConfig& C, uint32_t iteration, hipStream_t s) {
+  if (B.n_pairs == 0) return;
+  hipLaunchKernelGGL(lm_begin_kernel, dim3(per_pair_grid(B.n_pairs)), dim3(64), 0, s, B, C, iteration);
+}
+
+void launch_outer_update(const RegBatch& B, const RegConfig& C, uint32_t iteration, hipStream_t s) {
+  if (B.n_pairs == 0) return;
+  hipLaunchKernelGGL(outer_update_kernel, dim3(per_pair_grid(B.n_pairs)), dim3(64), 0, s, B, C, iteration);
+}
+
+void launch_write_results(const RegBatch& B, loamx_reg_result* d_results, hipStream_t s) {
+  if (B.n_pairs == 0) return;
+  hipLaunchKernelGGL(write_results_kernel, dim3(per_pair_grid(B.n_pairs)), dim3(64), 0, s, B, d_results);
+}
+
+}  // namespace loamx

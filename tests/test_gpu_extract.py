@@ -1,0 +1,118 @@
+"""GPU parity: loam::extractFeatures path (C ABI -> HIP kernels) against the CPU oracle.
+Bar: curvature bit-exact, mask exact, feature index sequences identical."""
+import numpy as np
+import pytest
+
+import reference_kats as K
+from gpu_common import ctx, to_capi_fe
+from loam_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kat", K.fe_kats(), ids=lambda k: k["name"])
+def test_reference_kats_on_gpu(oracle, kat):
+    lidar = capi.LidarParams(kat["H"], kat["W"], kat["rmin"], kat["rmax"])
+    fe = capi.FeatureExtractionParams(*K.KAT_FE_PARAMS)
+    ofe = oracle.FeParams(*K.KAT_FE_PARAMS)
+    c = ctx().compute_curvature(kat["pts"], lidar, fe)
+    m = ctx().compute_valid_points(kat["pts"], lidar, fe)
+    assert np.array_equal(c.view(np.uint64), oracle.compute_curvature(kat["pts"], kat["H"], kat["W"], ofe).view(np.uint64))
+    assert np.array_equal(m, oracle.compute_valid_points(kat["pts"], kat["H"], kat["W"], kat["rmin"], kat["rmax"], ofe))
+    if "curvature" in kat:
+        for i, v in kat["curvature"].items():
+            assert abs(c[i] - v) < 1e-9
+    else:
+        for i in kat["invalid"]:
+            assert not m[i]
+        for i in kat["valid"]:
+            assert m[i]
+
+
+def test_empty_scan_and_size_mismatch():
+    lidar0 = capi.LidarParams(0, 0, 0.1, 100.0)
+    e, p = ctx().extract_features(np.zeros((0, 3)), lidar0)
+    assert len(e) == 0 and len(p) == 0
+    with pytest.raises(capi.LoamxError) as err:
+        ctx().compute_curvature(np.zeros((10, 3)), capi.LidarParams(1, 11, 0.1, 10.0))
+    assert err.value.status == capi.ERR_SCAN_SIZE
+    assert "does not match provided lidar parameters (1 x 11)" in str(err.value)
+
+
+PARAM_SETS = [(3, 6, 10, 50, 100.0, 1.0, 0.5, 1.0), (5, 4, 2, 7, 50.0, 0.5, 0.3, 0.5), (1, 3, 0, 3, 10.0, 2.0, 0.5, 1.0),
+              (2, 1, 1000, 1000, 20.0, 5.0, 0.5, 1.0)]
+
+
+@pytest.mark.parametrize("H,W,seed", [(64, 1024, 1), (16, 256, 3), (8, 100, 5), (4, 37, 9), (2, 2048, 11), (128, 2048, 2)])
+def test_extraction_parity_synthetic(oracle, H, W, seed):
+    xyz = capi.synth_scan_host(seed, 0, 0, H, W, 0.01)
+    lidar = capi.LidarParams(H, W, 1.0, 120.0)
+    for params in PARAM_SETS:
+        ofe = oracle.FeParams(*params)
+        fe = capi.FeatureExtractionParams(*params)
+        c = ctx().compute_curvature(xyz, lidar, fe)
+        m = ctx().compute_valid_points(xyz, lidar, fe)
+        assert np.array_equal(c.view(np.uint64), oracle.compute_curvature(xyz, H, W, ofe).view(np.uint64))
+        assert np.array_equal(m, oracle.compute_valid_points(xyz, H, W, 1.0, 120.0, ofe))
+        e, p = ctx().extract_features(xyz, lidar, fe)
+        se, sp, ties = oracle.extract_features(xyz, H, W, 1.0, 120.0, ofe, stable=True)
+        assert np.array_equal(e, se) and np.array_equal(p, sp)
+        if ties == 0:  # tie-free => also identical to the reference's std::sort order
+            oe, op = oracle.extract_features(xyz, H, W, 1.0, 120.0, ofe)
+            assert np.array_equal(e, oe) and np.array_equal(p, op)
+
+
+def test_dropouts_and_out_of_range(oracle):
+    xyz = capi.synth_scan_host(4, 0, 0, 16, 512, 0.01)
+    rng = np.random.default_rng(0)
+    xyz[rng.random(len(xyz)) < 0.05] = 0.0
+    xyz[rng.random(len(xyz)) < 0.02] *= 30.0
+    lidar = capi.LidarParams(16, 512, 1.0, 120.0)
+    c = ctx().compute_curvature(xyz, lidar)
+    m = ctx().compute_valid_points(xyz, lidar)
+    assert np.array_equal(c.view(np.uint64), oracle.compute_curvature(xyz, 16, 512).view(np.uint64))
+    assert np.array_equal(m, oracle.compute_valid_points(xyz, 16, 512, 1.0, 120.0))
+    e, p = ctx().extract_features(xyz, lidar)
+    se, sp, _ = oracle.extract_features(xyz, 16, 512, 1.0, 120.0, stable=True)
+    assert np.array_equal(e, se) and np.array_equal(p, sp)
+
+
+def test_tie_policy_noise_free(oracle):
+    xyz = capi.synth_scan_host(2, 0, 0, 32, 512, 0.0)
+    e, p = ctx().extract_features(xyz, capi.LidarParams(32, 512, 1.0, 120.0))
+    se, sp, ties = oracle.extract_features(xyz, 32, 512, 1.0, 120.0, stable=True)
+    assert np.array_equal(e, se) and np.array_equal(p, sp)
+
+
+def test_device_generator_bit_identical_and_batch_extract(oracle):
+    H, W, n_pairs, seed = 16, 256, 3, 21
+    N = H * W
+    c = ctx()
+    lidar = capi.LidarParams(H, W, 1.0, 120.0)
+    fe = capi.FeatureExtractionParams()
+    d_xyz = c.alloc(n_pairs * 2 * N * 24)
+    c.synth_scan_pairs_dev(seed, 5, n_pairs, H, W, 0.01, d_xyz.ptr)
+    c.synchronize()
+    dev = d_xyz.download(np.float64, n_pairs * 2 * N * 3).reshape(n_pairs * 2, N, 3)
+    for pr in range(n_pairs):
+        for which in (0, 1):
+            host = capi.synth_scan_host(seed, 5 + pr, which, H, W, 0.01)
+            assert np.array_equal(dev[2 * pr + which].view(np.uint64), host.view(np.uint64))
+    ecap, pcap = c.edge_capacity(lidar, fe), c.planar_capacity(lidar, fe)
+    ns = n_pairs * 2
+    d_ei, d_pi = c.alloc(ns * ecap * 4), c.alloc(ns * pcap * 4)
+    d_ne, d_np = c.alloc(ns * 4), c.alloc(ns * 4)
+    d_ex, d_px = c.alloc(ns * ecap * 24), c.alloc(ns * pcap * 24)
+    c.extract_features_batch_dev(d_xyz.ptr, ns, lidar, fe, d_ei.ptr, d_ne.ptr, d_ex.ptr, d_pi.ptr, d_np.ptr, d_px.ptr)
+    c.synchronize()
+    ne, npl = d_ne.download(np.uint32, ns), d_np.download(np.uint32, ns)
+    ei = d_ei.download(np.uint32, ns * ecap).reshape(ns, ecap)
+    pi = d_pi.download(np.uint32, ns * pcap).reshape(ns, pcap)
+    ex = d_ex.download(np.float64, ns * ecap * 3).reshape(ns, ecap, 3)
+    px = d_px.download(np.float64, ns * pcap * 3).reshape(ns, pcap, 3)
+    for s in range(ns):
+        oe, op = oracle.extract_features(dev[s], H, W, 1.0, 120.0)
+        assert np.array_equal(ei[s, :ne[s]], oe) and np.array_equal(pi[s, :npl[s]], op)
+        assert np.array_equal(ex[s, :ne[s]], dev[s][oe]) and np.array_equal(px[s, :npl[s]], dev[s][op])
+    for b in (d_xyz, d_ei, d_pi, d_ne, d_np, d_ex, d_px):
+        b.free()
