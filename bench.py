@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — scan-pair registrations per second on MI355X (BASELINE.json's metric).
+
+One "step" = one pass of the whole hot path over one batch of synthetic 64x1024 scan pairs that is
+already resident in HBM: extractFeatures(target scan) + extractFeatures(source scan) +
+registerFeatures(source, target, identity) for every pair of the batch, through the C ABI
+(loamx_register_scan_pairs_dev). Workload = BASELINE.json configs[2]/[3]: 1024 pairs per GPU
+(weak scaling: every rank gets its own 1024 pairs, sharded by pair id, no data-path collective;
+RCCL only gathers the 64-byte result records).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline     — dominant kernel: algorithmic bytes per launch / average launch duration measured
+                 with HIP events on the launch stream inside the timed region, vs 8 TB/s HBM peak
+  cpu_baseline — the CPU oracle (oracle/, a port of the reference path) timed on this host's cores
+                 on a bounded sample of the same pairs (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E peak (6.3 TB/s achievable)
+SEED = 20240311
+H, W = 64, 1024
+SIGMA = 0.01
+
+
+def cpu_baseline(scans, n_sample, threads):
+    """Times the oracle (extract x2 + register per pair) on `threads` host threads."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    import oracle_lib as O
+    O.build()
+    O.lib()
+
+    def one(pr):
+        A, B = scans[2 * pr], scans[2 * pr + 1]
+        ea, pa = O.extract_features(A, H, W, 1.0, 120.0)
+        eb, pb = O.extract_features(B, H, W, 1.0, 120.0)
+        pose, term, iters = O.register_features(B[eb], B[pb], A[ea], A[pa])
+        return (ea, pa, eb, pb), pose, term, iters
+
+    one(0)  # warm the caches / page in the library
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        out = list(ex.map(one, range(n_sample)))
+    dt = time.perf_counter() - t0
+    return out, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=1024, help="scan pairs per GPU per step")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="pairs timed on the CPU oracle (default: 8 per thread, <= 256)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+    n_gpus = world if world > 1 else 1
+
+    from loam_amd import capi
+    ctx = capi.Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    lidar = capi.LidarParams(H, W, 1.0, 120.0)  # reference README.md:45
+    fe, reg = capi.FeatureExtractionParams(), capi.RegistrationParams()
+
+    P = args.pairs
+    N = H * W
+    first_pair = rank * P  # shard by pair id: rank r owns pairs [r*P, (r+1)*P)
+    xyz = torch.empty(P * 2 * N * 3, dtype=torch.float64, device=dev)  # inputs resident in HBM
+    results = torch.zeros(P * 64, dtype=torch.uint8, device=dev)
+    gathered = torch.zeros(world * P * 64, dtype=torch.uint8, device=dev) if world > 1 else None
+    ctx.synth_scan_pairs_dev(SEED, first_pair, P, H, W, SIGMA, xyz.data_ptr())
+    torch.cuda.synchronize()
+
+    def step():
+        ctx.register_scan_pairs_dev(xyz.data_ptr(), P, lidar, fe, reg, results.data_ptr())
+        if world > 1:  # the only collective: gather of 64-byte result records (RCCL over xGMI)
+            dist.all_gather_into_tensor(gathered, results)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.enable_kernel_timing(True)
+    ctx.reset_kernel_stats()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stats = ctx.kernel_stats()
+    ctx.enable_kernel_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    res = results.cpu().numpy().view(capi.RESULT_DTYPE)
+    total_pairs = n_gpus * P * args.steps
+    value = total_pairs / elapsed
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (and the per-kernel table) ----------------------------
+        kern = {}
+        for name, s in stats.items():
+            if s["launches"] == 0:
+                continue
+            avg_ms = s["total_ms"] / s["launches"]
+            kern[name] = dict(launches=s["launches"], total_ms=round(s["total_ms"], 4), avg_ms=round(avg_ms, 5),
+                              algorithmic_bytes_per_launch=s["algorithmic_bytes"] / s["launches"])
+        for name, k in kern.items():
+            b = k["algorithmic_bytes_per_launch"]
+            k["achieved_GBs"] = round(b / (k["avg_ms"] * 1e-3) / 1e9, 2) if b > 0 and k["avg_ms"] > 0 else None
+            k["hbm_frac"] = round(k["achieved_GBs"] / HBM_PEAK_GBS, 4) if k["achieved_GBs"] else None
+        timed = {n: k for n, k in kern.items()}
+        dominant = max(timed, key=lambda n: timed[n]["total_ms"])
+        dk = kern[dominant]
+        roofline = dict(kernel=dominant, bound="hbm", achieved=dk["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=dk["hbm_frac"], traffic=None,
+                        avg_launch_ms=dk["avg_ms"], algorithmic_bytes_per_launch=dk["algorithmic_bytes_per_launch"],
+                        share_of_kernel_time=round(dk["total_ms"] / sum(k["total_ms"] for k in kern.values()), 4))
+
+        out = {
+            "metric": "scan-pair registrations/sec (64x1024 Ouster)", "value": round(value, 2), "unit": "pairs/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"batch of {P} independent 64x1024 scan pairs per GPU (BASELINE configs[2]/[3]); "
+                                   "step = extractFeatures x2 + registerFeatures per pair, inputs resident in HBM",
+                       "pairs_per_gpu": P, "scan": "64x1024", "sharding": "by pair id, no data-path collective",
+                       "seed": SEED, "range_noise_sigma_m": SIGMA},
+            "roofline": roofline,
+            "kernels": kern,
+            "results": {"converged": int((res["termination"] == 0).sum()), "max_iter": int((res["termination"] == 1).sum()),
+                        "insufficient": int((res["termination"] == 2).sum()),
+                        "mean_icf_iterations": round(float(res["iterations"].mean()), 3)},
+        }
+
+        # ---- CPU baseline + parity spot check (outside the timed region) -----------------------------
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            n_sample = args.cpu_sample if args.cpu_sample > 0 else min(256, 8 * threads, P)
+            scans = xyz[: n_sample * 2 * N * 3].cpu().numpy().reshape(n_sample * 2, N, 3)
+            import oracle_lib as O
+            cpu_out, dt = cpu_baseline(scans, n_sample, threads)
+            out["cpu_baseline"] = {"value": round(n_sample / dt, 3), "unit": "pairs/s", "cores": threads, "kind": "port",
+                                   "sample": f"first {n_sample} pairs of the GPU batch (same seeds), CPU oracle "
+                                             f"extract x2 + register per pair, one pair per thread, {dt:.2f} s wall"}
+            max_rot = max_trans = 0.0
+            term_equal = True
+            for pr, (_, pose, term, iters) in enumerate(cpu_out):
+                d = O.pose_compose(O.pose_inverse(pose), res[pr]["pose"])
+                max_rot = max(max_rot, O.quat_angular_distance(d[:4], [0, 0, 0, 1.0]))
+                max_trans = max(max_trans, float(np.linalg.norm(d[4:])))
+                term_equal &= (term == res[pr]["termination"] and iters == res[pr]["iterations"])
+            # feature index sets of a few sample scans, GPU vs oracle
+            idx_equal = True
+            for s in range(min(8, 2 * n_sample)):
+                e, p = ctx.extract_features(scans[s], lidar, fe)
+                oe, op = cpu_out[s // 2][0][2 * (s % 2)], cpu_out[s // 2][0][2 * (s % 2) + 1]
+                idx_equal &= bool(np.array_equal(e, oe) and np.array_equal(p, op))
+            out["parity"] = {"pairs_checked": n_sample, "se3_max_rot_err_rad": max_rot, "se3_max_trans_err_m": max_trans,
+                             "tolerance": 1e-5, "termination_and_iterations_equal": bool(term_equal),
+                             "feature_index_sequences_equal": idx_equal}
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -288,6 +288,7 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   // counters: [0] n_active (u32), [8..24) sweep slot counters (2 x u64)
   B.n_active = wsp<uint32_t>(ctx, WS_COUNTERS);
   B.sweep_slots = reinterpret_cast<unsigned long long*>(wsp<unsigned char>(ctx, WS_COUNTERS) + 8);
+  B.assoc_slots = B.sweep_slots + 2;
   B.iter_info = want_iter_info ? wsp<loamx_iter_info>(ctx, WS_ITERINFO) : nullptr;
   hipStream_t s = ctx->stream;
 
@@ -680,10 +681,10 @@ int loamx_ctx_enable_kernel_timing(loamx_ctx* ctx, int enable) {
   return LOAMX_OK;
 }
 
-static int read_sweep_slots(loamx_ctx* ctx, unsigned long long out[2]) {
-  out[0] = out[1] = 0;
+static int read_sweep_slots(loamx_ctx* ctx, unsigned long long out[4]) {
+  out[0] = out[1] = out[2] = out[3] = 0;
   if (!ctx->ws[WS_COUNTERS].p) return LOAMX_OK;
-  HIP_TRY(ctx, hipMemcpy(out, wsp<unsigned char>(ctx, WS_COUNTERS) + 8, 16, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(out, wsp<unsigned char>(ctx, WS_COUNTERS) + 8, 32, hipMemcpyDeviceToHost));
   return LOAMX_OK;
 }
 
@@ -695,7 +696,7 @@ int loamx_ctx_reset_kernel_stats(loamx_ctx* ctx) {
   if (rc != LOAMX_OK) return rc;
   memset(ctx->stats, 0, sizeof(ctx->stats));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->ws[WS_COUNTERS].p) HIP_TRY(ctx, hipMemset(wsp<unsigned char>(ctx, WS_COUNTERS) + 8, 0, 16));
+  if (ctx->ws[WS_COUNTERS].p) HIP_TRY(ctx, hipMemset(wsp<unsigned char>(ctx, WS_COUNTERS) + 8, 0, 32));
   return LOAMX_OK;
 }
 
@@ -706,11 +707,14 @@ int loamx_ctx_get_kernel_stats(loamx_ctx* ctx, loamx_kernel_stat* stats) {
   int rc = resolve_events(ctx);
   if (rc != LOAMX_OK) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  unsigned long long slots[2];
+  unsigned long long slots[4];
   rc = read_sweep_slots(ctx, slots);
   if (rc != LOAMX_OK) return rc;
   memcpy(stats, ctx->stats, sizeof(ctx->stats));
+  // sweep: one association record per slot (edge 72 B, plane 56 B)
   stats[LOAMX_K_SWEEP].algorithmic_bytes = 72.0 * (double)slots[0] + 56.0 * (double)slots[1];
+  // associate: read the 24 B source point, write the record + the 4 B nearest index
+  stats[LOAMX_K_ASSOC].algorithmic_bytes = 100.0 * (double)slots[2] + 84.0 * (double)slots[3];
   return LOAMX_OK;
 }
 

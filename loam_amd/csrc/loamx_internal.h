@@ -99,6 +99,7 @@ struct RegBatch {
   uint32_t blocks_per_pair;
   uint32_t* n_active;    // device counter read back by the host after every outer iteration
   unsigned long long* sweep_slots;  // [2] edge / plane association slots streamed by sweep_kernel (roofline bytes)
+  unsigned long long* assoc_slots;  // [2] edge / plane source features processed by associate_kernel
   loamx_iter_info* iter_info;  // optional [n_pairs][max_iterations]
 };
 

@@ -149,6 +149,8 @@ __global__ __launch_bounds__(kAssocThreads) void associate_kernel(RegBatch B, Re
   const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
   const uint32_t n_src = PLANE ? B.n_src_planar[pair * B.in_pitch] : B.n_src_edge[pair * B.in_pitch];
   const GridSet& gs = PLANE ? B.grid_plane : B.grid_edge;
+  if (blockIdx.x % blocks_per_pair == 0 && threadIdx.x == 0 && B.assoc_slots)
+    atomicAdd(&B.assoc_slots[PLANE ? 1 : 0], (unsigned long long)(n_src < stride ? n_src : stride));
   bool valid = false;
   if (i < n_src && i < stride) {
     const double* __restrict__ src = (PLANE ? B.src_planar : B.src_edge) + (pair * B.in_pitch * stride + i) * 3;
