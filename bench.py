@@ -96,14 +96,14 @@ def main():
     first_pair = rank * P  # shard by pair id: rank r owns pairs [r*P, (r+1)*P)
     xyz = torch.empty(P * 2 * N * 3, dtype=torch.float64, device=dev)  # inputs resident in HBM
     results = torch.zeros(P * 64, dtype=torch.uint8, device=dev)
-    gathered = torch.zeros(world * P * 64, dtype=torch.uint8, device=dev) if world > 1 else None
+    from loam_amd import distributed as D
     ctx.synth_scan_pairs_dev(SEED, first_pair, P, H, W, SIGMA, xyz.data_ptr())
     torch.cuda.synchronize()
 
     def step():
         ctx.register_scan_pairs_dev(xyz.data_ptr(), P, lidar, fe, reg, results.data_ptr())
         if world > 1:  # the only collective: gather of 64-byte result records (RCCL over xGMI)
-            dist.all_gather_into_tensor(gathered, results)
+            D.gather_results(results, world * P)
 
     def barrier():
         if world > 1:

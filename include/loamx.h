@@ -94,18 +94,18 @@ typedef struct {
 } loamx_iter_info;
 
 /* Optional detail capture for loamx_register_features (RegistrationDetail, registration.h:79-109).
- * iter_info: capacity >= params.max_iterations. Association pair lists [source idx, nearest target
- * idx] are written for iteration `pairs_iteration` only (set pairs capacity to 0 to skip). */
+ * iter_info: capacity >= params.max_iterations entries. Association pair lists [source idx, nearest
+ * target idx] of iteration i are written at edge_pairs + i * 2 * pairs_cap_edge (uint32 pairs) with
+ * their count in n_edge_pairs[i] (same for planes); pass NULL pair pointers to skip them. */
 typedef struct {
   loamx_iter_info* iter_info;
-  uint32_t n_iter_info; /* out */
-  uint32_t pairs_iteration;
-  uint32_t* edge_pairs; /* 2 * edge_pairs_cap uint32 */
-  size_t edge_pairs_cap;
-  size_t n_edge_pairs; /* out */
+  uint32_t n_iter_info;   /* out */
+  uint32_t* edge_pairs;   /* max_iterations x pairs_cap_edge x 2 */
+  size_t pairs_cap_edge;  /* >= number of source edge points */
+  uint32_t* n_edge_pairs; /* out, max_iterations entries */
   uint32_t* plane_pairs;
-  size_t plane_pairs_cap;
-  size_t n_plane_pairs; /* out */
+  size_t pairs_cap_plane;
+  uint32_t* n_plane_pairs;
 } loamx_reg_detail;
 
 void loamx_default_fe_params(loamx_fe_params* p);

@@ -44,5 +44,34 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+PY_DIR = os.path.join(HERE, "python")
+PY_SRC = os.path.join(PY_DIR, "loam_bindings.cpp")
+
+
+def pybind_path():
+    import sysconfig
+    return os.path.join(PY_DIR, "loam", "loam_python" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_pybind(force=False, verbose=False):
+    """Builds the pybind11 module loam_amd/python/loam/loam_python*.so (host code only; it calls the C ABI)."""
+    import sysconfig
+    import pybind11
+    out = pybind_path()
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    deps = [PY_SRC] + [os.path.join(inc, "loam", f) for f in os.listdir(os.path.join(inc, "loam"))] + [os.path.join(inc, "loamx.h")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    build(force=False, verbose=verbose)
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-I", inc, "-I", pybind11.get_include(),
+           "-I", sysconfig.get_paths()["include"], PY_SRC, "-o", out, "-L", LIB_DIR, "-lloamx",
+           "-Wl,-rpath,$ORIGIN/../../lib", f"-Wl,-rpath,{LIB_DIR}", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_pybind(force="--force" in sys.argv, verbose=True))

@@ -59,10 +59,10 @@ class IterInfo(C.Structure):
 
 
 class RegDetail(C.Structure):
-    _fields_ = [("iter_info", C.POINTER(IterInfo)), ("n_iter_info", C.c_uint32), ("pairs_iteration", C.c_uint32),
-                ("edge_pairs", C.POINTER(C.c_uint32)), ("edge_pairs_cap", C.c_size_t), ("n_edge_pairs", C.c_size_t),
-                ("plane_pairs", C.POINTER(C.c_uint32)), ("plane_pairs_cap", C.c_size_t),
-                ("n_plane_pairs", C.c_size_t)]
+    _fields_ = [("iter_info", C.POINTER(IterInfo)), ("n_iter_info", C.c_uint32),
+                ("edge_pairs", C.POINTER(C.c_uint32)), ("pairs_cap_edge", C.c_size_t),
+                ("n_edge_pairs", C.POINTER(C.c_uint32)), ("plane_pairs", C.POINTER(C.c_uint32)),
+                ("pairs_cap_plane", C.c_size_t), ("n_plane_pairs", C.POINTER(C.c_uint32))]
 
 
 class KernelStat(C.Structure):
@@ -267,7 +267,7 @@ class Context:
         return e[:ne.value].copy(), p[:npl.value].copy()
 
     def register_features(self, src_edge, src_planar, tgt_edge, tgt_planar, init_pose=None, reg=None,
-                          want_detail=False, pairs_iteration=0):
+                          want_detail=False):
         """Returns (pose7, termination, iterations[, detail dict])."""
         reg = reg or RegistrationParams()
         arrs = [_pts(a) for a in (src_edge, src_planar, tgt_edge, tgt_planar)]
@@ -275,12 +275,16 @@ class Context:
         res = RegResult()
         detail = None
         if want_detail:
-            info = (IterInfo * max(1, reg.max_iterations))()
-            ep = np.zeros((max(1, len(arrs[0])), 2), dtype=np.uint32)
-            pp = np.zeros((max(1, len(arrs[1])), 2), dtype=np.uint32)
+            mi = max(1, reg.max_iterations)
+            info = (IterInfo * mi)()
+            ce, cp = max(1, len(arrs[0])), max(1, len(arrs[1]))
+            ep = np.zeros((mi, ce, 2), dtype=np.uint32)
+            pp = np.zeros((mi, cp, 2), dtype=np.uint32)
+            nep = np.zeros(mi, dtype=np.uint32)
+            npp = np.zeros(mi, dtype=np.uint32)
             u32p = C.POINTER(C.c_uint32)
-            detail = RegDetail(info, 0, pairs_iteration, ep.ctypes.data_as(u32p), len(ep), 0,
-                               pp.ctypes.data_as(u32p), len(pp), 0)
+            detail = RegDetail(info, 0, ep.ctypes.data_as(u32p), ce, nep.ctypes.data_as(u32p),
+                               pp.ctypes.data_as(u32p), cp, npp.ctypes.data_as(u32p))
         self._check(self.lib.loamx_register_features(
             self.h, _dp(arrs[0]), len(arrs[0]), _dp(arrs[1]), len(arrs[1]), _dp(arrs[2]), len(arrs[2]),
             _dp(arrs[3]), len(arrs[3]), _dp(init), C.byref(reg), C.byref(res),
@@ -289,9 +293,9 @@ class Context:
         if want_detail:
             d = dict(iterations=[dict(target_T_source_init=np.array(list(info[i].target_T_source_init)),
                                       estimate_update=np.array(list(info[i].estimate_update)),
-                                      n_edge=info[i].n_edge_associations, n_plane=info[i].n_plane_associations)
-                                 for i in range(detail.n_iter_info)],
-                     edge_pairs=ep[:detail.n_edge_pairs].copy(), plane_pairs=pp[:detail.n_plane_pairs].copy())
+                                      n_edge=info[i].n_edge_associations, n_plane=info[i].n_plane_associations,
+                                      edge_pairs=ep[i, :nep[i]].copy(), plane_pairs=pp[i, :npp[i]].copy())
+                                 for i in range(detail.n_iter_info)])
             return pose, res.termination, res.iterations, d
         return pose, res.termination, res.iterations
 

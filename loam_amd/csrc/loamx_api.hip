@@ -532,14 +532,16 @@ struct DetailHook {
 int detail_hook(loamx_ctx* ctx, const RegBatch& B, uint32_t it, void* user) {
   DetailHook* h = static_cast<DetailHook*>(user);
   loamx_reg_detail* d = h->detail;
-  if (!d || it != d->pairs_iteration) return LOAMX_OK;
+  if (!d) return LOAMX_OK;
   for (int kind = 0; kind < 2; kind++) {
     const size_t n = kind ? h->n_sp : h->n_se;
-    uint32_t* out = kind ? d->plane_pairs : d->edge_pairs;
-    const size_t cap = kind ? d->plane_pairs_cap : d->edge_pairs_cap;
-    size_t* out_n = kind ? &d->n_plane_pairs : &d->n_edge_pairs;
-    *out_n = 0;
-    if (!out || cap == 0 || n == 0) continue;
+    uint32_t* base = kind ? d->plane_pairs : d->edge_pairs;
+    const size_t cap = kind ? d->pairs_cap_plane : d->pairs_cap_edge;
+    uint32_t* out_n = kind ? d->n_plane_pairs : d->n_edge_pairs;
+    if (!base || !out_n) continue;
+    out_n[it] = 0;
+    if (cap == 0 || n == 0) continue;
+    uint32_t* out = base + (size_t)it * 2 * cap;
     std::vector<uint32_t> nearest(n);
     HIP_TRY(ctx, hipMemcpyAsync(nearest.data(), kind ? B.assoc.nearest_plane : B.assoc.nearest_edge, n * sizeof(uint32_t),
                                 hipMemcpyDeviceToHost, ctx->stream));
@@ -550,7 +552,7 @@ int detail_hook(loamx_ctx* ctx, const RegBatch& B, uint32_t it, void* user) {
       if (m < cap) out[2 * m] = (uint32_t)i, out[2 * m + 1] = nearest[i];
       m++;
     }
-    *out_n = m;
+    out_n[it] = (uint32_t)(m < cap ? m : cap);
   }
   return LOAMX_OK;
 }
@@ -594,7 +596,7 @@ int loamx_register_features(loamx_ctx* ctx, const double* src_edge, size_t n_se,
   in.n_src_edge = fc, in.n_src_planar = fc + 1, in.n_tgt_edge = fc + 2, in.n_tgt_planar = fc + 3;
   in.init = wsp<double>(ctx, WS_INIT);
   DetailHook hook{detail, n_se, n_sp};
-  if (detail) detail->n_iter_info = 0, detail->n_edge_pairs = 0, detail->n_plane_pairs = 0;
+  if (detail) detail->n_iter_info = 0;
   rc = register_dev(ctx, in, C, wsp<loamx_reg_result>(ctx, WS_RESULTS), detail && detail->iter_info,
                     detail ? detail_hook : nullptr, &hook);
   if (rc != LOAMX_OK) return rc;

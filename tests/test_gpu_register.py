@@ -47,7 +47,7 @@ def test_synthetic_pair_with_detail(oracle, H, W, seed, pair):
     ea, pa = oracle.extract_features(A, H, W, 1.0, 120.0)
     eb, pb = oracle.extract_features(B, H, W, 1.0, 120.0)
     po, to, io, info = oracle.register_features(B[eb], B[pb], A[ea], A[pa], want_info=True)
-    pg, tg, ig, det = ctx().register_features(B[eb], B[pb], A[ea], A[pa], want_detail=True, pairs_iteration=0)
+    pg, tg, ig, det = ctx().register_features(B[eb], B[pb], A[ea], A[pa], want_detail=True)
     assert (tg, ig) == (to, io)
     rot, trans = pose_diff(oracle, po, pg)
     assert rot < SE3_TOL and trans < SE3_TOL, (rot, trans)
@@ -59,10 +59,13 @@ def test_synthetic_pair_with_detail(oracle, H, W, seed, pair):
         assert r < SE3_TOL and t < SE3_TOL
     # association pairs of iteration 0 = (source idx, nearest target idx)
     ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
-    for pairs, src, tgt, is_plane in ((det["edge_pairs"], B[eb], A[ea], False), (det["plane_pairs"], B[pb], A[pa], True)):
-        valid, nearest, _, _ = oracle.associate(src, tgt, ident, is_plane)
-        assert np.array_equal(pairs[:, 0], np.nonzero(valid)[0])
-        assert np.array_equal(pairs[:, 1], nearest[valid])
+    for it, d in enumerate(det["iterations"]):
+        est = d["target_T_source_init"] if it else ident
+        for pairs, src, tgt, is_plane in ((d["edge_pairs"], B[eb], A[ea], False), (d["plane_pairs"], B[pb], A[pa], True)):
+            valid, nearest, _, _ = oracle.associate(src, tgt, est, is_plane)
+            assert len(pairs) == (d["n_plane"] if is_plane else d["n_edge"])
+            assert np.array_equal(pairs[:, 0], np.nonzero(valid)[0])
+            assert np.array_equal(pairs[:, 1], nearest[valid])
     truth = capi.synth_pair_pose(seed, pair)
     rot, trans = pose_diff(oracle, truth, pg)
     assert rot < 1e-2 and trans < 3e-2
