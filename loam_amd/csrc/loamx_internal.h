@@ -46,8 +46,7 @@ struct RegConfig {
 struct GridSet {
   GridDesc* desc;        // [n_pairs]
   uint32_t* cell_start;  // [n_pairs][kGridCellsCap + 1]
-  double* sorted_xyz;    // [n_pairs][stride][3]
-  uint32_t* sorted_idx;  // [n_pairs][stride]
+  GridPoint* sorted;     // [n_pairs][stride] points re-ordered cell by cell (32 B each: xyz + original index)
   size_t stride;
 };
 
@@ -92,7 +91,8 @@ struct RegBatch {
   const double* tgt_planar;
   const uint32_t* n_tgt_planar;
   const double* init;  // may be null
-  GridSet grid_edge, grid_plane;
+  GridSet grid_edge, grid_plane;          // target sets: searched
+  GridSet src_grid_edge, src_grid_plane;  // source sets: only their cell-sorted order is used (coherent queries)
   AssocBuffers assoc;
   PairState* state;      // [n_pairs]
   double* partials;      // [n_pairs][blocks_per_pair][kAccSize]

@@ -135,11 +135,18 @@ LOAMX_HD void grid_choose(GridDesc& g, Vec3 lo, Vec3 hi, uint32_t n, double max_
   g.nx = nx, g.ny = ny, g.nz = nz;
 }
 
+// One indexed target point: 32 bytes so a candidate is two 16-byte loads.
+struct alignas(32) GridPoint {
+  double x, y, z;
+  uint32_t orig;  // index in the caller's array
+  uint32_t pad;
+};
+
 // k best neighbours, ascending by (squared distance, original index): a strict total order, so
 // the result does not depend on the storage order inside a cell.
 struct KnnResult {
   double d2[kMaxK];
-  uint32_t pos[kMaxK];   // position in the cell-sorted arrays
+  uint32_t pos[kMaxK];   // position in the cell-sorted array
   uint32_t orig[kMaxK];  // index in the caller's target array
   double worst;          // d2 of the k-th best once k are held, else DBL_MAX
   int count;
@@ -177,19 +184,54 @@ LOAMX_HD void knn_insert(KnnResult& r, int k, double d2, uint32_t pos, uint32_t 
   }
 }
 
-LOAMX_HD void knn_scan_range(KnnResult& r, int k, Vec3 q, const double* __restrict__ sx, const uint32_t* __restrict__ sorig,
-                             uint32_t begin, uint32_t end) {
+LOAMX_HD void knn_scan_range(KnnResult& r, int k, Vec3 q, const GridPoint* __restrict__ sp, uint32_t begin, uint32_t end) {
   for (uint32_t p = begin; p < end; p++) {
-    const double dx = q.x - sx[3 * p], dy = q.y - sx[3 * p + 1], dz = q.z - sx[3 * p + 2];
+    const GridPoint t = sp[p];
+    const double dx = q.x - t.x, dy = q.y - t.y, dz = q.z - t.z;
     const double d2 = dx * dx + dy * dy + dz * dz;  // nanoflann L2_Simple: ((dx^2 + dy^2) + dz^2)
-    if (d2 <= r.worst) knn_insert(r, k, d2, p, sorig[p]);
+    if (d2 <= r.worst) knn_insert(r, k, d2, p, t.orig);
   }
+}
+
+// distance from coordinate v to the slab of cell index c along one axis, shrunk by a safety margin
+// that covers the rounding of grid_cell_coord (never over-estimates the true distance)
+LOAMX_HD double slab_dist(double v, double origin, double h, int32_t c) {
+  const double lo = origin + (double)c * h, hi = lo + h;
+  double d = v < lo ? lo - v : (v > hi ? v - hi : 0.0);
+  d -= 1e-9 * h;
+  return d > 0.0 ? d : 0.0;
+}
+
+// Scans the cells [xlo, xhi] of row (iy, iz), skipping the row (or the part of it) whose slab is
+// farther than anything that could still enter the result: `bound` = min(k-th best d2, radius^2).
+LOAMX_HD void knn_scan_row(const GridDesc& g, const uint32_t* __restrict__ cell_start, const GridPoint* __restrict__ sp,
+                           Vec3 q, int k, double r2, int32_t iy, int32_t iz, int32_t xlo, int32_t xhi, KnnResult& r) {
+  if (iy < 0 || iy > g.ny - 1 || iz < 0 || iz > g.nz - 1) return;
+  if (xlo < 0) xlo = 0;
+  if (xhi > g.nx - 1) xhi = g.nx - 1;
+  if (xlo > xhi) return;
+  const double sy = slab_dist(q.y, g.oy, g.h, iy), sz = slab_dist(q.z, g.oz, g.h, iz);
+  const double rowmin2 = sy * sy + sz * sz;
+  const double bound = r.worst < r2 ? r.worst : r2;
+  if (rowmin2 > bound) return;
+  if (bound < kDblMax) {
+    // cells whose x slab is farther than sqrt(bound - rowmin2) cannot contribute
+    const double reach = sqrt(bound - rowmin2) + 1e-9 * g.h;
+    const int32_t xl = grid_cell_coord(q.x - reach, g.ox, g.inv_h), xh = grid_cell_coord(q.x + reach, g.ox, g.inv_h);
+    if (xl > xlo) xlo = xl;
+    if (xh < xhi) xhi = xh;
+    if (xlo > xhi) return;
+  }
+  const uint32_t row = (uint32_t)((iz * g.ny + iy) * g.nx);
+  knn_scan_range(r, k, q, sp, cell_start[row + xlo], cell_start[row + xhi + 1]);
 }
 
 // Exact k-NN of q among the indexed points, then the strict radius filter of kdtree.cpp:25
 // (max_dist <= 0 disables it). Returns the number of neighbours kept (prefix of r).
-LOAMX_HD int knn_search(const GridDesc& g, const uint32_t* __restrict__ cell_start, const double* __restrict__ sx,
-                        const uint32_t* __restrict__ sorig, Vec3 q, int k, double max_dist, KnnResult& r) {
+// Cubes of cells of growing half-width w around the query cell are visited (centre row first);
+// after round w every unvisited point is farther than w*h along some axis.
+LOAMX_HD int knn_search(const GridDesc& g, const uint32_t* __restrict__ cell_start, const GridPoint* __restrict__ sp,
+                        Vec3 q, int k, double max_dist, KnnResult& r) {
   r.count = 0;
   r.worst = kDblMax;
 #pragma unroll
@@ -213,29 +255,22 @@ LOAMX_HD int knn_search(const GridDesc& g, const uint32_t* __restrict__ cell_sta
   }
   // every point is at least (out-1)*h away: nothing can pass the radius filter
   if (max_dist > 0.0 && out >= 1 && (double)(out - 1) * g.h >= max_dist) return 0;
+  // points at distance >= max_dist are dropped by the radius filter anyway
+  const double r2 = max_dist > 0.0 ? max_dist * max_dist * (1.0 + 1e-12) : kDblMax;
   int32_t w = out > 1 ? out : 1;
   bool first = true;
   for (;;) {
-    // scan the cells at Chebyshev distance <= w (first round) or == w (later rounds)
-    const int32_t z0 = clampi(cz - w, 0, g.nz - 1), z1 = clampi(cz + w, 0, g.nz - 1);
-    const int32_t y0 = clampi(cy - w, 0, g.ny - 1), y1 = clampi(cy + w, 0, g.ny - 1);
-    const int32_t x0 = cx - w, x1 = cx + w;
-    const bool z_hit = (cz + w >= 0) && (cz - w <= g.nz - 1);
-    const bool y_hit = (cy + w >= 0) && (cy - w <= g.ny - 1);
-    const bool x_hit = (x1 >= 0) && (x0 <= g.nx - 1);
-    if (z_hit && y_hit && x_hit) {
-      const int32_t xa = x0 < 0 ? 0 : x0, xb = x1 > g.nx - 1 ? g.nx - 1 : x1;
-      for (int32_t iz = z0; iz <= z1; iz++) {
-        const int32_t adz = iz > cz ? iz - cz : cz - iz;
-        for (int32_t iy = y0; iy <= y1; iy++) {
-          const int32_t ady = iy > cy ? iy - cy : cy - iy;
-          const uint32_t row = (uint32_t)((iz * g.ny + iy) * g.nx);
-          if (first || adz == w || ady == w) {
-            knn_scan_range(r, k, q, sx, sorig, cell_start[row + xa], cell_start[row + xb + 1]);
-          } else {
-            if (x0 >= 0 && x0 <= g.nx - 1) knn_scan_range(r, k, q, sx, sorig, cell_start[row + x0], cell_start[row + x0 + 1]);
-            if (x1 >= 0 && x1 <= g.nx - 1) knn_scan_range(r, k, q, sx, sorig, cell_start[row + x1], cell_start[row + x1 + 1]);
-          }
+    if (first) knn_scan_row(g, cell_start, sp, q, k, r2, cy, cz, cx - w, cx + w, r);  // centre row first
+    for (int32_t dz = -w; dz <= w; dz++) {
+      for (int32_t dy = -w; dy <= w; dy++) {
+        const int32_t ady = dy < 0 ? -dy : dy, adz = dz < 0 ? -dz : dz;
+        if (first) {
+          if (dy != 0 || dz != 0) knn_scan_row(g, cell_start, sp, q, k, r2, cy + dy, cz + dz, cx - w, cx + w, r);
+        } else if (ady == w || adz == w) {
+          knn_scan_row(g, cell_start, sp, q, k, r2, cy + dy, cz + dz, cx - w, cx + w, r);
+        } else {
+          knn_scan_row(g, cell_start, sp, q, k, r2, cy + dy, cz + dz, cx - w, cx - w, r);
+          knn_scan_row(g, cell_start, sp, q, k, r2, cy + dy, cz + dz, cx + w, cx + w, r);
         }
       }
     }

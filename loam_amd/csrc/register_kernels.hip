@@ -111,14 +111,28 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
   }
   if (tid == 0) cs[ncell] = n;
   __syncthreads();
-  double* __restrict__ sx = gs.sorted_xyz + pair * gs.stride * 3;
-  uint32_t* __restrict__ si = gs.sorted_idx + pair * gs.stride;
+  GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
   for (uint32_t i = tid; i < n; i += kBuildThreads) {
     const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
     const uint32_t cell = grid_cell_of_point(g, v3(x, y, z));
     const uint32_t pos = atomicAdd(&s_cells[cell], 1u);
-    sx[3 * (size_t)pos] = x, sx[3 * (size_t)pos + 1] = y, sx[3 * (size_t)pos + 2] = z;
-    si[pos] = i;
+    sp[pos] = GridPoint{x, y, z, i, 0u};
+  }
+  __syncthreads();
+  // The scatter order inside a cell depends on the atomics; order every cell by original index so
+  // that the layout (and with it every later summation order) is reproducible run to run.
+  // After the scatter s_cells[c] holds the END of cell c; its start is the end of cell c-1.
+  for (uint32_t c = tid; c < ncell; c += kBuildThreads) {
+    const uint32_t b = c ? s_cells[c - 1] : 0u, e = s_cells[c];
+    for (uint32_t i = b + 1; i < e; i++) {
+      const GridPoint key = sp[i];
+      uint32_t j = i;
+      while (j > b && sp[j - 1].orig > key.orig) {
+        sp[j] = sp[j - 1];
+        j--;
+      }
+      sp[j] = key;
+    }
   }
 }
 
@@ -139,35 +153,54 @@ __global__ void state_init_kernel(RegBatch B, RegConfig C) {
 
 constexpr int kAssocThreads = 256;
 
+// Workgroup -> (pair, chunk) mapping: workgroups are dealt round-robin over the 8 XCDs, so all
+// chunks of one pair are given ids with the same id % 8 and share one XCD's L2 (the pair's target
+// index + points are ~0.5 MB). Placement only affects speed, never results.
+__device__ __forceinline__ bool xcd_pair_map(uint32_t block, uint32_t blocks_per_pair, size_t n_pairs, size_t& pair,
+                                             uint32_t& chunk) {
+  const uint32_t xcd = block & 7u, slot = block >> 3;
+  pair = (size_t)xcd + 8u * (size_t)(slot / blocks_per_pair);
+  chunk = slot % blocks_per_pair;
+  return pair < n_pairs;
+}
+
 template <bool PLANE>
 __global__ __launch_bounds__(kAssocThreads) void associate_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
   __shared__ uint32_t s_count[kAssocThreads / 64];
-  const size_t pair = blockIdx.x / blocks_per_pair;
-  const uint32_t i = (blockIdx.x % blocks_per_pair) * kAssocThreads + threadIdx.x;
+  size_t pair;
+  uint32_t chunk;
+  if (!xcd_pair_map(blockIdx.x, blocks_per_pair, B.n_pairs, pair, chunk)) return;
+  const uint32_t i = chunk * kAssocThreads + threadIdx.x;
   const PairState& S = B.state[pair];
   if (!S.active) return;  // uniform per workgroup
   const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
   const uint32_t n_src = PLANE ? B.n_src_planar[pair * B.in_pitch] : B.n_src_edge[pair * B.in_pitch];
   const GridSet& gs = PLANE ? B.grid_plane : B.grid_edge;
-  if (blockIdx.x % blocks_per_pair == 0 && threadIdx.x == 0 && B.assoc_slots)
+  const GridSet& src_gs = PLANE ? B.src_grid_plane : B.src_grid_edge;
+  if (chunk == 0 && threadIdx.x == 0 && B.assoc_slots)
     atomicAdd(&B.assoc_slots[PLANE ? 1 : 0], (unsigned long long)(n_src < stride ? n_src : stride));
   bool valid = false;
   if (i < n_src && i < stride) {
-    const double* __restrict__ src = (PLANE ? B.src_planar : B.src_edge) + (pair * B.in_pitch * stride + i) * 3;
-    const Vec3 p = pose_act(S.est, v3(src[0], src[1], src[2]));  // registration.cpp:34 / :75
+    // queries are taken in the source set's own cell order: neighbouring lanes look at neighbouring
+    // target cells (shared cache lines, similar trip counts)
+    const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
+    const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));  // registration.cpp:34 / :75
     const GridDesc g = gs.desc[pair];
     const uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
-    const double* __restrict__ sx = gs.sorted_xyz + pair * gs.stride * 3;
-    const uint32_t* __restrict__ si = gs.sorted_idx + pair * gs.stride;
+    const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
     KnnResult r;
-    const int kept = knn_search(g, cs, sx, si, p, PLANE ? C.k_plane : C.k_edge, PLANE ? C.r_plane : C.r_edge, r);
+    const int kept = knn_search(g, cs, sp, p, PLANE ? C.k_plane : C.k_edge, PLANE ? C.r_plane : C.r_edge, r);
     double prim[6] = {0, 0, 0, 0, 0, 0};
     if (kept >= (PLANE ? C.min_plane_pts : C.min_line_pts)) {  // registration.cpp:39 / :80
       Vec3 nb[kMaxK];
 #pragma unroll
       for (int j = 0; j < kMaxK; j++) {
-        if (j < kept) nb[j] = v3(sx[3 * (size_t)r.pos[j]], sx[3 * (size_t)r.pos[j] + 1], sx[3 * (size_t)r.pos[j] + 2]);
-        else nb[j] = v3(0, 0, 0);
+        if (j < kept) {
+          const GridPoint t = sp[r.pos[j]];
+          nb[j] = v3(t.x, t.y, t.z);
+        } else {
+          nb[j] = v3(0, 0, 0);
+        }
       }
       if (PLANE) {
         Vec3 nrm;
@@ -189,7 +222,8 @@ __global__ __launch_bounds__(kAssocThreads) void associate_kernel(RegBatch B, Re
     rec[2 * field + slot] = p.z;
 #pragma unroll
     for (int f = 0; f < (PLANE ? 4 : 6); f++) rec[(3 + f) * field + slot] = prim[f];
-    (PLANE ? B.assoc.nearest_plane : B.assoc.nearest_edge)[slot] = valid ? r.orig[0] : 0xFFFFFFFFu;
+    // detail capture is indexed by the caller's source index
+    (PLANE ? B.assoc.nearest_plane : B.assoc.nearest_edge)[pair * stride + sq.orig] = valid ? r.orig[0] : 0xFFFFFFFFu;
   }
   const unsigned long long m = __ballot(valid);
   if ((threadIdx.x & 63) == 0) s_count[threadIdx.x >> 6] = (uint32_t)__popcll(m);
@@ -362,6 +396,11 @@ void launch_grid_build(const RegBatch& B, const RegConfig& C, hipStream_t s) {
                      B.edge_stride, B.in_pitch, C.r_edge, B.grid_edge);
   hipLaunchKernelGGL(grid_build_kernel, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.tgt_planar,
                      B.n_tgt_planar, B.planar_stride, B.in_pitch, C.r_plane, B.grid_plane);
+  // source sets: only the cell-sorted order is used
+  hipLaunchKernelGGL(grid_build_kernel, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.src_edge, B.n_src_edge,
+                     B.edge_stride, B.in_pitch, C.r_edge, B.src_grid_edge);
+  hipLaunchKernelGGL(grid_build_kernel, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.src_planar,
+                     B.n_src_planar, B.planar_stride, B.in_pitch, C.r_plane, B.src_grid_plane);
 }
 
 void launch_state_init(const RegBatch& B, const RegConfig& C, hipStream_t s) {
@@ -373,8 +412,9 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   if (B.n_pairs == 0) return;
   const uint32_t be = (uint32_t)((B.edge_stride + kAssocThreads - 1) / kAssocThreads);
   const uint32_t bp = (uint32_t)((B.planar_stride + kAssocThreads - 1) / kAssocThreads);
-  if (be) hipLaunchKernelGGL(associate_kernel<false>, dim3((unsigned)(B.n_pairs * be)), dim3(kAssocThreads), 0, s, B, C, be);
-  if (bp) hipLaunchKernelGGL(associate_kernel<true>, dim3((unsigned)(B.n_pairs * bp)), dim3(kAssocThreads), 0, s, B, C, bp);
+  const size_t pair_groups = (B.n_pairs + 7) / 8;  // grid covers 8 XCD lanes x pair_groups x chunks
+  if (be) hipLaunchKernelGGL(associate_kernel<false>, dim3((unsigned)(pair_groups * 8 * be)), dim3(kAssocThreads), 0, s, B, C, be);
+  if (bp) hipLaunchKernelGGL(associate_kernel<true>, dim3((unsigned)(pair_groups * 8 * bp)), dim3(kAssocThreads), 0, s, B, C, bp);
 }
 
 void launch_sweep(const RegBatch& B, hipStream_t s) {

@@ -93,8 +93,7 @@ int hostcheck_select(const double* curv, const uint8_t* mask_in, uint64_t H, uin
 struct HostGrid {
   GridDesc g;
   std::vector<uint32_t> cell_start;
-  std::vector<double> sx;
-  std::vector<uint32_t> sorig;
+  std::vector<GridPoint> sp;
 };
 
 static void build_grid(const double* pts, uint32_t n, double max_dist, HostGrid& G) {
@@ -115,14 +114,12 @@ static void build_grid(const double* pts, uint32_t n, double max_dist, HostGrid&
   }
   for (uint32_t c = 0; c < ncell; c++) G.cell_start[c + 1] += G.cell_start[c];
   std::vector<uint32_t> cursor(G.cell_start.begin(), G.cell_start.end() - 1);
-  G.sx.resize(3 * (size_t)n);
-  G.sorig.resize(n);
-  // fill in reverse original order: the GPU fill order is arbitrary (atomics); the search result
-  // must not depend on it
-  for (uint32_t k = n; k-- > 0;) {
+  G.sp.resize(n);
+  // the GPU scatters with atomics and then orders every cell by original index; ascending fill
+  // order gives the same layout
+  for (uint32_t k = 0; k < n; k++) {
     const uint32_t pos = cursor[cell[k]]++;
-    G.sx[3 * pos] = pts[3 * k], G.sx[3 * pos + 1] = pts[3 * k + 1], G.sx[3 * pos + 2] = pts[3 * k + 2];
-    G.sorig[pos] = k;
+    G.sp[pos] = GridPoint{pts[3 * k], pts[3 * k + 1], pts[3 * k + 2], k, 0};
   }
 }
 
@@ -130,8 +127,7 @@ uint64_t hostcheck_knn(const double* pts, uint64_t n, const double q[3], uint64_
   HostGrid G;
   build_grid(pts, (uint32_t)n, max_dist, G);
   KnnResult r;
-  const int kept = knn_search(G.g, G.cell_start.data(), G.sx.data(), G.sorig.data(), v3(q[0], q[1], q[2]), (int)k,
-                              max_dist, r);
+  const int kept = knn_search(G.g, G.cell_start.data(), G.sp.data(), v3(q[0], q[1], q[2]), (int)k, max_dist, r);
   for (int j = 0; j < kept; j++) idx_out[j] = r.orig[j];
   return (uint64_t)kept;
 }
@@ -173,11 +169,11 @@ static uint32_t associate(const double* src, uint32_t n_src, const double* tgt, 
     s.valid = false;
     s.p = pose_act(est, v3(src[3 * i], src[3 * i + 1], src[3 * i + 2]));
     KnnResult r;
-    const int kept = knn_search(G.g, G.cell_start.data(), G.sx.data(), G.sorig.data(), s.p, k, maxd, r);
+    const int kept = knn_search(G.g, G.cell_start.data(), G.sp.data(), s.p, k, maxd, r);
     if (kept < minfit) continue;
     Vec3 nb[kMaxK];
     for (int j = 0; j < kMaxK; j++)
-      if (j < kept) nb[j] = v3(G.sx[3 * r.pos[j]], G.sx[3 * r.pos[j] + 1], G.sx[3 * r.pos[j] + 2]);
+      if (j < kept) nb[j] = v3(G.sp[r.pos[j]].x, G.sp[r.pos[j]].y, G.sp[r.pos[j]].z);
     if (is_plane) {
       Vec3 n;
       double d;
