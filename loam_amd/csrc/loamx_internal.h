@@ -93,6 +93,7 @@ struct RegBatch {
   const double* init;  // may be null
   GridSet grid_edge, grid_plane;          // target sets: searched
   GridSet src_grid_edge, src_grid_plane;  // source sets: only their cell-sorted order is used (coherent queries)
+  GridPoint* sort_scratch;  // [n_pairs][max(edge_stride, planar_stride)] scratch of the ordered source build
   AssocBuffers assoc;
   PairState* state;      // [n_pairs]
   double* partials;      // [n_pairs][blocks_per_pair][kAccSize]

@@ -144,24 +144,26 @@ struct alignas(32) GridPoint {
 
 // k best neighbours, ascending by (squared distance, original index): a strict total order, so
 // the result does not depend on the storage order inside a cell.
+template <int KM>
 struct KnnResult {
-  double d2[kMaxK];
-  uint32_t pos[kMaxK];   // position in the cell-sorted array
-  uint32_t orig[kMaxK];  // index in the caller's target array
+  double d2[KM];
+  uint32_t pos[KM];   // position in the cell-sorted array
+  uint32_t orig[KM];  // index in the caller's target array
   double worst;          // d2 of the k-th best once k are held, else DBL_MAX
   int count;
 };
 
-LOAMX_HD void knn_insert(KnnResult& r, int k, double d2, uint32_t pos, uint32_t orig) {
+template <int KM>
+LOAMX_HD void knn_insert(KnnResult<KM>& r, int k, double d2, uint32_t pos, uint32_t orig) {
   // find insertion slot: first j with (d2, orig) < (r.d2[j], r.orig[j]) among the filled ones
   int slot = r.count;
 #pragma unroll
-  for (int j = kMaxK - 1; j >= 0; j--) {
+  for (int j = KM - 1; j >= 0; j--) {
     if (j < r.count && (d2 < r.d2[j] || (d2 == r.d2[j] && orig < r.orig[j]))) slot = j;
   }
   if (slot >= k) return;
 #pragma unroll
-  for (int j = kMaxK - 1; j >= 1; j--) {
+  for (int j = KM - 1; j >= 1; j--) {
     if (j > slot && j < k) {
       r.d2[j] = r.d2[j - 1];
       r.pos[j] = r.pos[j - 1];
@@ -169,7 +171,7 @@ LOAMX_HD void knn_insert(KnnResult& r, int k, double d2, uint32_t pos, uint32_t 
     }
   }
 #pragma unroll
-  for (int j = 0; j < kMaxK; j++) {
+  for (int j = 0; j < KM; j++) {
     if (j == slot) {
       r.d2[j] = d2;
       r.pos[j] = pos;
@@ -179,17 +181,35 @@ LOAMX_HD void knn_insert(KnnResult& r, int k, double d2, uint32_t pos, uint32_t 
   if (r.count < k) r.count++;
   if (r.count == k) {
 #pragma unroll
-    for (int j = 0; j < kMaxK; j++)
+    for (int j = 0; j < KM; j++)
       if (j == k - 1) r.worst = r.d2[j];
   }
 }
 
-LOAMX_HD void knn_scan_range(KnnResult& r, int k, Vec3 q, const GridPoint* __restrict__ sp, uint32_t begin, uint32_t end) {
-  for (uint32_t p = begin; p < end; p++) {
+template <int KM>
+LOAMX_HD void knn_consider(KnnResult<KM>& r, int k, Vec3 q, const GridPoint& t, uint32_t p) {
+#if defined(LOAMX_KNN_STATS)
+  g_cand++;
+#endif
+  const double dx = q.x - t.x, dy = q.y - t.y, dz = q.z - t.z;
+  const double d2 = dx * dx + dy * dy + dz * dz;  // nanoflann L2_Simple: ((dx^2 + dy^2) + dz^2)
+  if (d2 <= r.worst) knn_insert(r, k, d2, p, t.orig);
+}
+
+// candidates are fetched four at a time so that four 32-byte loads are in flight per lane
+template <int KM>
+LOAMX_HD void knn_scan_range(KnnResult<KM>& r, int k, Vec3 q, const GridPoint* __restrict__ sp, uint32_t begin, uint32_t end) {
+  uint32_t p = begin;
+  for (; p + 4 <= end; p += 4) {
+    const GridPoint t0 = sp[p], t1 = sp[p + 1], t2 = sp[p + 2], t3 = sp[p + 3];
+    knn_consider(r, k, q, t0, p);
+    knn_consider(r, k, q, t1, p + 1);
+    knn_consider(r, k, q, t2, p + 2);
+    knn_consider(r, k, q, t3, p + 3);
+  }
+  for (; p < end; p++) {
     const GridPoint t = sp[p];
-    const double dx = q.x - t.x, dy = q.y - t.y, dz = q.z - t.z;
-    const double d2 = dx * dx + dy * dy + dz * dz;  // nanoflann L2_Simple: ((dx^2 + dy^2) + dz^2)
-    if (d2 <= r.worst) knn_insert(r, k, d2, p, t.orig);
+    knn_consider(r, k, q, t, p);
   }
 }
 
@@ -204,8 +224,9 @@ LOAMX_HD double slab_dist(double v, double origin, double h, int32_t c) {
 
 // Scans the cells [xlo, xhi] of row (iy, iz), skipping the row (or the part of it) whose slab is
 // farther than anything that could still enter the result: `bound` = min(k-th best d2, radius^2).
+template <int KM>
 LOAMX_HD void knn_scan_row(const GridDesc& g, const uint32_t* __restrict__ cell_start, const GridPoint* __restrict__ sp,
-                           Vec3 q, int k, double r2, int32_t iy, int32_t iz, int32_t xlo, int32_t xhi, KnnResult& r) {
+                           Vec3 q, int k, double r2, int32_t iy, int32_t iz, int32_t xlo, int32_t xhi, KnnResult<KM>& r) {
   if (iy < 0 || iy > g.ny - 1 || iz < 0 || iz > g.nz - 1) return;
   if (xlo < 0) xlo = 0;
   if (xhi > g.nx - 1) xhi = g.nx - 1;
@@ -223,6 +244,9 @@ LOAMX_HD void knn_scan_row(const GridDesc& g, const uint32_t* __restrict__ cell_
     if (xlo > xhi) return;
   }
   const uint32_t row = (uint32_t)((iz * g.ny + iy) * g.nx);
+#if defined(LOAMX_KNN_STATS)
+  g_rows++;
+#endif
   knn_scan_range(r, k, q, sp, cell_start[row + xlo], cell_start[row + xhi + 1]);
 }
 
@@ -230,12 +254,13 @@ LOAMX_HD void knn_scan_row(const GridDesc& g, const uint32_t* __restrict__ cell_
 // (max_dist <= 0 disables it). Returns the number of neighbours kept (prefix of r).
 // Cubes of cells of growing half-width w around the query cell are visited (centre row first);
 // after round w every unvisited point is farther than w*h along some axis.
+template <int KM>
 LOAMX_HD int knn_search(const GridDesc& g, const uint32_t* __restrict__ cell_start, const GridPoint* __restrict__ sp,
-                        Vec3 q, int k, double max_dist, KnnResult& r) {
+                        Vec3 q, int k, double max_dist, KnnResult<KM>& r) {
   r.count = 0;
   r.worst = kDblMax;
 #pragma unroll
-  for (int j = 0; j < kMaxK; j++) {
+  for (int j = 0; j < KM; j++) {
     r.d2[j] = kDblMax;
     r.pos[j] = 0;
     r.orig[j] = 0xFFFFFFFFu;
@@ -260,6 +285,36 @@ LOAMX_HD int knn_search(const GridDesc& g, const uint32_t* __restrict__ cell_sta
   int32_t w = out > 1 ? out : 1;
   bool first = true;
   for (;;) {
+    if (first && w == 1) {
+      // Common case. The cell_start entries of all nine rows of the 3x3x3 block are fetched up
+      // front (18 independent loads instead of nine dependent round trips); the rows are then
+      // walked centre first, then faces, then corners, as one flattened candidate loop, each row
+      // skipped if its slab is already farther than the current bound.
+      uint32_t rb[9], re[9];
+      double rm[9];
+      const int32_t xa = cx - 1 < 0 ? 0 : cx - 1, xb = cx + 1 > g.nx - 1 ? g.nx - 1 : cx + 1;
+#pragma unroll
+      for (int j = 0; j < 9; j++) {
+        const int32_t iy = cy + (j % 3) - 1, iz = cz + (j / 3) - 1;
+        const bool ok = xa <= xb && iy >= 0 && iy <= g.ny - 1 && iz >= 0 && iz <= g.nz - 1;
+        const uint32_t row = ok ? (uint32_t)((iz * g.ny + iy) * g.nx) : 0u;
+        rb[j] = ok ? cell_start[row + xa] : 0u;
+        re[j] = ok ? cell_start[row + xb + 1] : 0u;
+        const double sy = slab_dist(q.y, g.oy, g.h, iy), sz = slab_dist(q.z, g.oz, g.h, iz);
+        rm[j] = sy * sy + sz * sz;
+      }
+#pragma unroll
+      for (int o = 0; o < 9; o++) {
+        const int j = o == 0 ? 4 : (o == 1 ? 1 : (o == 2 ? 3 : (o == 3 ? 5 : (o == 4 ? 7 : (o == 5 ? 0 : (o == 6 ? 2 : (o == 7 ? 6 : 8)))))));
+        const double bound = r.worst < r2 ? r.worst : r2;
+        if (rb[j] < re[j] && rm[j] <= bound) {
+#if defined(LOAMX_KNN_STATS)
+          g_rows++;
+#endif
+          knn_scan_range(r, k, q, sp, rb[j], re[j]);
+        }
+      }
+    } else {
     if (first) knn_scan_row(g, cell_start, sp, q, k, r2, cy, cz, cx - w, cx + w, r);  // centre row first
     for (int32_t dz = -w; dz <= w; dz++) {
       for (int32_t dy = -w; dy <= w; dy++) {
@@ -274,6 +329,7 @@ LOAMX_HD int knn_search(const GridDesc& g, const uint32_t* __restrict__ cell_sta
         }
       }
     }
+    }
     first = false;
     // unscanned points are farther than (w*h) along some axis; keep a relative safety margin for
     // the rounding in grid_cell_coord
@@ -285,7 +341,7 @@ LOAMX_HD int knn_search(const GridDesc& g, const uint32_t* __restrict__ cell_sta
   }
   int kept = 0;
 #pragma unroll
-  for (int j = 0; j < kMaxK; j++) {
+  for (int j = 0; j < KM; j++) {
     if (j < r.count && kept == j && (max_dist <= 0.0 || sqrt(r.d2[j]) < max_dist)) kept = j + 1;
   }
   return kept;
@@ -311,15 +367,16 @@ LOAMX_HD void jacobi_rotate(double& app, double& aqq, double& apq, double& arp, 
   a = vp2, b = vq2, vp2 = c * a - s * b, vq2 = s * a + c * b;
 }
 
-LOAMX_HD void fit_line(const Vec3 pts[kMaxK], int K, Vec3& a, Vec3& b) {
+template <int KM>
+LOAMX_HD void fit_line(const Vec3 pts[KM], int K, Vec3& a, Vec3& b) {
   Vec3 sum = v3(0, 0, 0);
 #pragma unroll
-  for (int i = 0; i < kMaxK; i++)
+  for (int i = 0; i < KM; i++)
     if (i < K) sum = vadd(sum, pts[i]);
   const Vec3 center = v3(sum.x / (double)K, sum.y / (double)K, sum.z / (double)K);
   double a00 = 0, a11 = 0, a22 = 0, a01 = 0, a02 = 0, a12 = 0;
 #pragma unroll
-  for (int i = 0; i < kMaxK; i++) {
+  for (int i = 0; i < KM; i++) {
     if (i < K) {
       const Vec3 d = vsub(pts[i], center);
       a00 += d.x * d.x, a11 += d.y * d.y, a22 += d.z * d.z;
@@ -347,17 +404,18 @@ LOAMX_HD void fit_line(const Vec3 pts[kMaxK], int K, Vec3& a, Vec3& b) {
  * (Eigen ColPivHouseholderQR semantics incl. its near-zero pivot cut-off), n = abc/|abc|,
  * d = 1/|abc|, returns the signed mean of P n - d.
  * ---------------------------------------------------------------------------------------------- */
-LOAMX_HD double fit_plane(const Vec3 pts[kMaxK], int K, Vec3& normal, double& d_out) {
-  double c0[kMaxK], c1[kMaxK], c2[kMaxK];  // columns of the K x 3 matrix
+template <int KM>
+LOAMX_HD double fit_plane(const Vec3 pts[KM], int K, Vec3& normal, double& d_out) {
+  double c0[KM], c1[KM], c2[KM];  // columns of the K x 3 matrix
 #pragma unroll
-  for (int r = 0; r < kMaxK; r++) {
+  for (int r = 0; r < KM; r++) {
     c0[r] = r < K ? pts[r].x : 0.0;
     c1[r] = r < K ? pts[r].y : 0.0;
     c2[r] = r < K ? pts[r].z : 0.0;
   }
   double nu0 = 0, nu1 = 0, nu2 = 0;
 #pragma unroll
-  for (int r = 0; r < kMaxK; r++) nu0 += c0[r] * c0[r], nu1 += c1[r] * c1[r], nu2 += c2[r] * c2[r];
+  for (int r = 0; r < KM; r++) nu0 += c0[r] * c0[r], nu1 += c1[r] * c1[r], nu2 += c2[r] * c2[r];
   nu0 = sqrt(nu0), nu1 = sqrt(nu1), nu2 = sqrt(nu2);
   double nd0 = nu0, nd1 = nu1, nd2 = nu2;
   double maxn = nu0 > nu1 ? nu0 : nu1;
@@ -369,7 +427,7 @@ LOAMX_HD double fit_plane(const Vec3 pts[kMaxK], int K, Vec3& normal, double& d_
   double tau0 = 0, tau1 = 0, tau2 = 0;
 
 #define LOAMX_SWAP(a_, b_) { double t_ = a_; a_ = b_; b_ = t_; }
-#define LOAMX_SWAPCOL(ca, cb) { _Pragma("unroll") for (int r_ = 0; r_ < kMaxK; r_++) LOAMX_SWAP(ca[r_], cb[r_]) }
+#define LOAMX_SWAPCOL(ca, cb) { _Pragma("unroll") for (int r_ = 0; r_ < KM; r_++) LOAMX_SWAP(ca[r_], cb[r_]) }
   // ---- k = 0
   {
     int big = 0;
@@ -381,28 +439,28 @@ LOAMX_HD double fit_plane(const Vec3 pts[kMaxK], int K, Vec3& normal, double& d_
     if (big == 2) { LOAMX_SWAPCOL(c0, c2) LOAMX_SWAP(nu0, nu2) LOAMX_SWAP(nd0, nd2) int t = p0; p0 = p2; p2 = t; }
     double tail = 0;
 #pragma unroll
-    for (int r = 1; r < kMaxK; r++) tail += c0[r] * c0[r];
+    for (int r = 1; r < KM; r++) tail += c0[r] * c0[r];
     const double x0 = c0[0];
     double beta;
     if (tail <= kDblMin) {
       tau0 = 0, beta = x0;
 #pragma unroll
-      for (int r = 1; r < kMaxK; r++) c0[r] = 0;
+      for (int r = 1; r < KM; r++) c0[r] = 0;
     } else {
       beta = sqrt(x0 * x0 + tail);
       if (x0 >= 0) beta = -beta;
 #pragma unroll
-      for (int r = 1; r < kMaxK; r++) c0[r] = c0[r] / (x0 - beta);
+      for (int r = 1; r < KM; r++) c0[r] = c0[r] / (x0 - beta);
       tau0 = (beta - x0) / beta;
     }
     c0[0] = beta;
     if (tau0 != 0) {
       double t1 = c1[0], t2 = c2[0];
 #pragma unroll
-      for (int r = 1; r < kMaxK; r++) t1 += c0[r] * c1[r], t2 += c0[r] * c2[r];
+      for (int r = 1; r < KM; r++) t1 += c0[r] * c1[r], t2 += c0[r] * c2[r];
       c1[0] -= tau0 * t1, c2[0] -= tau0 * t2;
 #pragma unroll
-      for (int r = 1; r < kMaxK; r++) c1[r] -= tau0 * c0[r] * t1, c2[r] -= tau0 * c0[r] * t2;
+      for (int r = 1; r < KM; r++) c1[r] -= tau0 * c0[r] * t1, c2[r] -= tau0 * c0[r] * t2;
     }
     // norm down-dating for columns 1, 2
     if (nu1 != 0) {
@@ -413,7 +471,7 @@ LOAMX_HD double fit_plane(const Vec3 pts[kMaxK], int K, Vec3& normal, double& d_
       if (temp * ratio * ratio <= downdate_thr) {
         double s = 0;
 #pragma unroll
-        for (int r = 1; r < kMaxK; r++) s += c1[r] * c1[r];
+        for (int r = 1; r < KM; r++) s += c1[r] * c1[r];
         nd1 = sqrt(s), nu1 = nd1;
       } else {
         nu1 *= sqrt(temp);
@@ -427,7 +485,7 @@ LOAMX_HD double fit_plane(const Vec3 pts[kMaxK], int K, Vec3& normal, double& d_
       if (temp * ratio * ratio <= downdate_thr) {
         double s = 0;
 #pragma unroll
-        for (int r = 1; r < kMaxK; r++) s += c2[r] * c2[r];
+        for (int r = 1; r < KM; r++) s += c2[r] * c2[r];
         nd2 = sqrt(s), nu2 = nd2;
       } else {
         nu2 *= sqrt(temp);
@@ -443,28 +501,28 @@ LOAMX_HD double fit_plane(const Vec3 pts[kMaxK], int K, Vec3& normal, double& d_
     if (big == 2) { LOAMX_SWAPCOL(c1, c2) LOAMX_SWAP(nu1, nu2) LOAMX_SWAP(nd1, nd2) int t = p1; p1 = p2; p2 = t; }
     double tail = 0;
 #pragma unroll
-    for (int r = 2; r < kMaxK; r++) tail += c1[r] * c1[r];
+    for (int r = 2; r < KM; r++) tail += c1[r] * c1[r];
     const double x0 = c1[1];
     double beta;
     if (tail <= kDblMin) {
       tau1 = 0, beta = x0;
 #pragma unroll
-      for (int r = 2; r < kMaxK; r++) c1[r] = 0;
+      for (int r = 2; r < KM; r++) c1[r] = 0;
     } else {
       beta = sqrt(x0 * x0 + tail);
       if (x0 >= 0) beta = -beta;
 #pragma unroll
-      for (int r = 2; r < kMaxK; r++) c1[r] = c1[r] / (x0 - beta);
+      for (int r = 2; r < KM; r++) c1[r] = c1[r] / (x0 - beta);
       tau1 = (beta - x0) / beta;
     }
     c1[1] = beta;
     if (tau1 != 0) {
       double t2 = c2[1];
 #pragma unroll
-      for (int r = 2; r < kMaxK; r++) t2 += c1[r] * c2[r];
+      for (int r = 2; r < KM; r++) t2 += c1[r] * c2[r];
       c2[1] -= tau1 * t2;
 #pragma unroll
-      for (int r = 2; r < kMaxK; r++) c2[r] -= tau1 * c1[r] * t2;
+      for (int r = 2; r < KM; r++) c2[r] -= tau1 * c1[r] * t2;
     }
     if (nu2 != 0) {
       double temp = fabs(c2[1]) / nu2;
@@ -474,7 +532,7 @@ LOAMX_HD double fit_plane(const Vec3 pts[kMaxK], int K, Vec3& normal, double& d_
       if (temp * ratio * ratio <= downdate_thr) {
         double s = 0;
 #pragma unroll
-        for (int r = 2; r < kMaxK; r++) s += c2[r] * c2[r];
+        for (int r = 2; r < KM; r++) s += c2[r] * c2[r];
         nd2 = sqrt(s), nu2 = nd2;
       } else {
         nu2 *= sqrt(temp);
@@ -486,18 +544,18 @@ LOAMX_HD double fit_plane(const Vec3 pts[kMaxK], int K, Vec3& normal, double& d_
     if (nonzero_pivots == 3 && nu2 * nu2 < threshold_helper * (double)(K - 2)) nonzero_pivots = 2;
     double tail = 0;
 #pragma unroll
-    for (int r = 3; r < kMaxK; r++) tail += c2[r] * c2[r];
+    for (int r = 3; r < KM; r++) tail += c2[r] * c2[r];
     const double x0 = c2[2];
     double beta;
     if (tail <= kDblMin) {
       tau2 = 0, beta = x0;
 #pragma unroll
-      for (int r = 3; r < kMaxK; r++) c2[r] = 0;
+      for (int r = 3; r < KM; r++) c2[r] = 0;
     } else {
       beta = sqrt(x0 * x0 + tail);
       if (x0 >= 0) beta = -beta;
 #pragma unroll
-      for (int r = 3; r < kMaxK; r++) c2[r] = c2[r] / (x0 - beta);
+      for (int r = 3; r < KM; r++) c2[r] = c2[r] / (x0 - beta);
       tau2 = (beta - x0) / beta;
     }
     c2[2] = beta;
@@ -506,24 +564,24 @@ LOAMX_HD double fit_plane(const Vec3 pts[kMaxK], int K, Vec3& normal, double& d_
 #undef LOAMX_SWAP
   // ---- solve: c = Q^T * ones (first nonzero_pivots reflectors), back substitution, un-permute.
   // Rows >= K of the zero-padded columns are zero, so they never contribute.
-  double rhs[kMaxK];
+  double rhs[KM];
 #pragma unroll
-  for (int r = 0; r < kMaxK; r++) rhs[r] = r < K ? 1.0 : 0.0;
+  for (int r = 0; r < KM; r++) rhs[r] = r < K ? 1.0 : 0.0;
   if (nonzero_pivots > 0 && tau0 != 0) {
     double t = rhs[0];
 #pragma unroll
-    for (int r = 1; r < kMaxK; r++) t += c0[r] * rhs[r];
+    for (int r = 1; r < KM; r++) t += c0[r] * rhs[r];
     rhs[0] -= tau0 * t;
 #pragma unroll
-    for (int r = 1; r < kMaxK; r++) rhs[r] -= tau0 * c0[r] * t;
+    for (int r = 1; r < KM; r++) rhs[r] -= tau0 * c0[r] * t;
   }
   if (nonzero_pivots > 1 && tau1 != 0) {
     double t = rhs[1];
 #pragma unroll
-    for (int r = 2; r < kMaxK; r++) t += c1[r] * rhs[r];
+    for (int r = 2; r < KM; r++) t += c1[r] * rhs[r];
     rhs[1] -= tau1 * t;
 #pragma unroll
-    for (int r = 2; r < kMaxK; r++) rhs[r] -= tau1 * c1[r] * t;
+    for (int r = 2; r < KM; r++) rhs[r] -= tau1 * c1[r] * t;
   }
   if (nonzero_pivots > 2) {
     if (K - 2 == 1) {
@@ -531,7 +589,7 @@ LOAMX_HD double fit_plane(const Vec3 pts[kMaxK], int K, Vec3& normal, double& d_
     } else if (tau2 != 0) {
       double t = rhs[2];
 #pragma unroll
-      for (int r = 3; r < kMaxK; r++) t += c2[r] * rhs[r];
+      for (int r = 3; r < KM; r++) t += c2[r] * rhs[r];
       rhs[2] -= tau2 * t;
     }
   }
@@ -552,7 +610,7 @@ LOAMX_HD double fit_plane(const Vec3 pts[kMaxK], int K, Vec3& normal, double& d_
   d_out = 1.0 / n;
   double sum = 0;
 #pragma unroll
-  for (int r = 0; r < kMaxK; r++)
+  for (int r = 0; r < KM; r++)
     if (r < K) sum += (pts[r].x * normal.x + pts[r].y * normal.y + pts[r].z * normal.z) - d_out;
   return sum / (double)K;
 }

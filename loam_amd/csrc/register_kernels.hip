@@ -39,9 +39,10 @@ constexpr int kBuildThreads = 1024;
 // One workgroup builds the whole index of one target set: bounding box, cell size, counting sort by
 // cell with the cell table in LDS (128 KiB), exclusive scan, scatter. Deterministic in everything
 // but the order of points inside a cell, which the search does not depend on.
+template <bool ORDERED>
 __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double* __restrict__ pts_base,
                                                                    const uint32_t* __restrict__ n_pts, size_t stride,
-                                                                   uint32_t in_pitch, double max_dist, GridSet gs) {
+                                                                   uint32_t in_pitch, double max_dist, GridSet gs, GridPoint* __restrict__ scratch) {
   __shared__ uint32_t s_cells[kGridCellsCap];
   __shared__ double s_red[6][kBuildThreads / 64];
   __shared__ uint32_t s_wave_sum[kBuildThreads / 64];
@@ -112,26 +113,27 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
   if (tid == 0) cs[ncell] = n;
   __syncthreads();
   GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
+  // ORDERED: scatter into the scratch copy first, then place every point at (cell begin + number of
+  // cell mates with a smaller original index): the final layout does not depend on the order in
+  // which the atomics were served, so every later summation order is reproducible run to run.
+  GridPoint* __restrict__ dst = ORDERED ? scratch + pair * gs.stride : sp;
   for (uint32_t i = tid; i < n; i += kBuildThreads) {
     const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
     const uint32_t cell = grid_cell_of_point(g, v3(x, y, z));
     const uint32_t pos = atomicAdd(&s_cells[cell], 1u);
-    sp[pos] = GridPoint{x, y, z, i, 0u};
+    dst[pos] = GridPoint{x, y, z, i, 0u};
   }
-  __syncthreads();
-  // The scatter order inside a cell depends on the atomics; order every cell by original index so
-  // that the layout (and with it every later summation order) is reproducible run to run.
-  // After the scatter s_cells[c] holds the END of cell c; its start is the end of cell c-1.
-  for (uint32_t c = tid; c < ncell; c += kBuildThreads) {
-    const uint32_t b = c ? s_cells[c - 1] : 0u, e = s_cells[c];
-    for (uint32_t i = b + 1; i < e; i++) {
-      const GridPoint key = sp[i];
-      uint32_t j = i;
-      while (j > b && sp[j - 1].orig > key.orig) {
-        sp[j] = sp[j - 1];
-        j--;
-      }
-      sp[j] = key;
+  if (ORDERED) {
+    __syncthreads();  // also makes this workgroup's global writes visible to itself
+    __threadfence_block();
+    // after the scatter s_cells[c] holds the END of cell c; its begin is the end of cell c-1
+    for (uint32_t p = tid; p < n; p += kBuildThreads) {
+      const GridPoint e = dst[p];
+      const uint32_t cell = grid_cell_of_point(g, v3(e.x, e.y, e.z));
+      const uint32_t b = cell ? s_cells[cell - 1] : 0u, en = s_cells[cell];
+      uint32_t rank = 0;
+      for (uint32_t j = b; j < en; j++) rank += dst[j].orig < e.orig ? 1u : 0u;
+      sp[b + rank] = e;
     }
   }
 }
@@ -164,7 +166,7 @@ __device__ __forceinline__ bool xcd_pair_map(uint32_t block, uint32_t blocks_per
   return pair < n_pairs;
 }
 
-template <bool PLANE>
+template <bool PLANE, int KM>
 __global__ __launch_bounds__(kAssocThreads) void associate_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
   __shared__ uint32_t s_count[kAssocThreads / 64];
   size_t pair;
@@ -188,13 +190,13 @@ __global__ __launch_bounds__(kAssocThreads) void associate_kernel(RegBatch B, Re
     const GridDesc g = gs.desc[pair];
     const uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
     const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
-    KnnResult r;
+    KnnResult<KM> r;
     const int kept = knn_search(g, cs, sp, p, PLANE ? C.k_plane : C.k_edge, PLANE ? C.r_plane : C.r_edge, r);
     double prim[6] = {0, 0, 0, 0, 0, 0};
     if (kept >= (PLANE ? C.min_plane_pts : C.min_line_pts)) {  // registration.cpp:39 / :80
-      Vec3 nb[kMaxK];
+      Vec3 nb[KM];
 #pragma unroll
-      for (int j = 0; j < kMaxK; j++) {
+      for (int j = 0; j < KM; j++) {
         if (j < kept) {
           const GridPoint t = sp[r.pos[j]];
           nb[j] = v3(t.x, t.y, t.z);
@@ -205,12 +207,12 @@ __global__ __launch_bounds__(kAssocThreads) void associate_kernel(RegBatch B, Re
       if (PLANE) {
         Vec3 nrm;
         double d;
-        const double avg = fit_plane(nb, kept, nrm, d);
+        const double avg = fit_plane<KM>(nb, kept, nrm, d);
         valid = !(avg > C.max_avg_plane_dist);  // registration.cpp:90
         prim[0] = nrm.x, prim[1] = nrm.y, prim[2] = nrm.z, prim[3] = d;
       } else {
         Vec3 a, b;
-        fit_line(nb, kept, a, b);
+        fit_line<KM>(nb, kept, a, b);
         valid = !(kDblMax < C.min_line_cond);  // registration.cpp:49 (condition number is always DBL_MAX)
         prim[0] = a.x, prim[1] = a.y, prim[2] = a.z, prim[3] = b.x, prim[4] = b.y, prim[5] = b.z;
       }
@@ -392,15 +394,15 @@ inline unsigned per_pair_grid(size_t n_pairs) { return (unsigned)((n_pairs + 63)
 
 void launch_grid_build(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   if (B.n_pairs == 0) return;
-  hipLaunchKernelGGL(grid_build_kernel, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.tgt_edge, B.n_tgt_edge,
-                     B.edge_stride, B.in_pitch, C.r_edge, B.grid_edge);
-  hipLaunchKernelGGL(grid_build_kernel, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.tgt_planar,
-                     B.n_tgt_planar, B.planar_stride, B.in_pitch, C.r_plane, B.grid_plane);
+  hipLaunchKernelGGL(grid_build_kernel<false>, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.tgt_edge, B.n_tgt_edge,
+                     B.edge_stride, B.in_pitch, C.r_edge, B.grid_edge, (GridPoint*)nullptr);
+  hipLaunchKernelGGL(grid_build_kernel<false>, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.tgt_planar,
+                     B.n_tgt_planar, B.planar_stride, B.in_pitch, C.r_plane, B.grid_plane, (GridPoint*)nullptr);
   // source sets: only the cell-sorted order is used
-  hipLaunchKernelGGL(grid_build_kernel, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.src_edge, B.n_src_edge,
-                     B.edge_stride, B.in_pitch, C.r_edge, B.src_grid_edge);
-  hipLaunchKernelGGL(grid_build_kernel, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.src_planar,
-                     B.n_src_planar, B.planar_stride, B.in_pitch, C.r_plane, B.src_grid_plane);
+  hipLaunchKernelGGL(grid_build_kernel<true>, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.src_edge, B.n_src_edge,
+                     B.edge_stride, B.in_pitch, C.r_edge, B.src_grid_edge, B.sort_scratch);
+  hipLaunchKernelGGL(grid_build_kernel<true>, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.src_planar,
+                     B.n_src_planar, B.planar_stride, B.in_pitch, C.r_plane, B.src_grid_plane, B.sort_scratch);
 }
 
 void launch_state_init(const RegBatch& B, const RegConfig& C, hipStream_t s) {
@@ -413,8 +415,19 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   const uint32_t be = (uint32_t)((B.edge_stride + kAssocThreads - 1) / kAssocThreads);
   const uint32_t bp = (uint32_t)((B.planar_stride + kAssocThreads - 1) / kAssocThreads);
   const size_t pair_groups = (B.n_pairs + 7) / 8;  // grid covers 8 XCD lanes x pair_groups x chunks
-  if (be) hipLaunchKernelGGL(associate_kernel<false>, dim3((unsigned)(pair_groups * 8 * be)), dim3(kAssocThreads), 0, s, B, C, be);
-  if (bp) hipLaunchKernelGGL(associate_kernel<true>, dim3((unsigned)(pair_groups * 8 * bp)), dim3(kAssocThreads), 0, s, B, C, bp);
+  // register-resident neighbour lists are instantiated for K <= 5 (the reference's default) and K <= 8
+  if (be) {
+    if (C.k_edge <= 5)
+      hipLaunchKernelGGL((associate_kernel<false, 5>), dim3((unsigned)(pair_groups * 8 * be)), dim3(kAssocThreads), 0, s, B, C, be);
+    else
+      hipLaunchKernelGGL((associate_kernel<false, 8>), dim3((unsigned)(pair_groups * 8 * be)), dim3(kAssocThreads), 0, s, B, C, be);
+  }
+  if (bp) {
+    if (C.k_plane <= 5)
+      hipLaunchKernelGGL((associate_kernel<true, 5>), dim3((unsigned)(pair_groups * 8 * bp)), dim3(kAssocThreads), 0, s, B, C, bp);
+    else
+      hipLaunchKernelGGL((associate_kernel<true, 8>), dim3((unsigned)(pair_groups * 8 * bp)), dim3(kAssocThreads), 0, s, B, C, bp);
+  }
 }
 
 void launch_sweep(const RegBatch& B, hipStream_t s) {

@@ -126,7 +126,13 @@ static void build_grid(const double* pts, uint32_t n, double max_dist, HostGrid&
 uint64_t hostcheck_knn(const double* pts, uint64_t n, const double q[3], uint64_t k, double max_dist, uint64_t* idx_out) {
   HostGrid G;
   build_grid(pts, (uint32_t)n, max_dist, G);
-  KnnResult r;
+  if (k <= 5) {  // the kernels are instantiated for KM = 5 (default parameters) and KM = 8
+    KnnResult<5> r;
+    const int kept = knn_search(G.g, G.cell_start.data(), G.sp.data(), v3(q[0], q[1], q[2]), (int)k, max_dist, r);
+    for (int j = 0; j < kept; j++) idx_out[j] = r.orig[j];
+    return (uint64_t)kept;
+  }
+  KnnResult<8> r;
   const int kept = knn_search(G.g, G.cell_start.data(), G.sp.data(), v3(q[0], q[1], q[2]), (int)k, max_dist, r);
   for (int j = 0; j < kept; j++) idx_out[j] = r.orig[j];
   return (uint64_t)kept;
@@ -137,7 +143,7 @@ double hostcheck_fit_plane(const double* pts, uint64_t k, double out[4]) {
   for (uint64_t i = 0; i < k; i++) P[i] = v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
   Vec3 n;
   double d;
-  const double avg = fit_plane(P, (int)k, n, d);
+  const double avg = k <= 5 ? fit_plane<5>(P, (int)k, n, d) : fit_plane<8>(P, (int)k, n, d);
   out[0] = n.x, out[1] = n.y, out[2] = n.z, out[3] = d;
   return avg;
 }
@@ -145,7 +151,7 @@ void hostcheck_fit_line(const double* pts, uint64_t k, double out[6]) {
   Vec3 P[kMaxK];
   for (uint64_t i = 0; i < k; i++) P[i] = v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
   Vec3 a, b;
-  fit_line(P, (int)k, a, b);
+  if (k <= 5) fit_line<5>(P, (int)k, a, b); else fit_line<8>(P, (int)k, a, b);
   out[0] = a.x, out[1] = a.y, out[2] = a.z, out[3] = b.x, out[4] = b.y, out[5] = b.z;
 }
 
@@ -156,7 +162,9 @@ struct Slot {
   uint32_t nearest;
 };
 
-static uint32_t associate(const double* src, uint32_t n_src, const double* tgt, const HostGrid& G, const double est[7],
+extern "C++" {
+template <int KM>
+static uint32_t associate_t(const double* src, uint32_t n_src, const double* tgt, const HostGrid& G, const double est[7],
                           bool is_plane, const loamx_reg_params* prm, std::vector<Slot>& slots) {
   const int k = (int)(is_plane ? prm->num_plane_neighbors : prm->num_edge_neighbors);
   const double maxd = is_plane ? prm->max_plane_neighbor_dist : prm->max_edge_neighbor_dist;
@@ -168,21 +176,21 @@ static uint32_t associate(const double* src, uint32_t n_src, const double* tgt, 
     Slot& s = slots[i];
     s.valid = false;
     s.p = pose_act(est, v3(src[3 * i], src[3 * i + 1], src[3 * i + 2]));
-    KnnResult r;
+    KnnResult<KM> r;
     const int kept = knn_search(G.g, G.cell_start.data(), G.sp.data(), s.p, k, maxd, r);
     if (kept < minfit) continue;
-    Vec3 nb[kMaxK];
-    for (int j = 0; j < kMaxK; j++)
+    Vec3 nb[KM];
+    for (int j = 0; j < KM; j++)
       if (j < kept) nb[j] = v3(G.sp[r.pos[j]].x, G.sp[r.pos[j]].y, G.sp[r.pos[j]].z);
     if (is_plane) {
       Vec3 n;
       double d;
-      const double avg = fit_plane(nb, kept, n, d);
+      const double avg = fit_plane<KM>(nb, kept, n, d);
       if (avg > prm->max_avg_point_plane_dist) continue;
       s.prim[0] = n.x, s.prim[1] = n.y, s.prim[2] = n.z, s.prim[3] = d;
     } else {
       Vec3 a, b;
-      fit_line(nb, kept, a, b);
+      fit_line<KM>(nb, kept, a, b);
       // min_line_condition_number guard is dead code in the reference (condition number == DBL_MAX)
       if (kDblMax < prm->min_line_condition_number) continue;
       s.prim[0] = a.x, s.prim[1] = a.y, s.prim[2] = a.z, s.prim[3] = b.x, s.prim[4] = b.y, s.prim[5] = b.z;
@@ -193,6 +201,14 @@ static uint32_t associate(const double* src, uint32_t n_src, const double* tgt, 
   }
   return count;
 }
+
+static uint32_t associate(const double* src, uint32_t n_src, const double* tgt, const HostGrid& G, const double est[7],
+                          bool is_plane, const loamx_reg_params* prm, std::vector<Slot>& slots) {
+  const uint64_t k = is_plane ? prm->num_plane_neighbors : prm->num_edge_neighbors;
+  return k <= 5 ? associate_t<5>(src, n_src, tgt, G, est, is_plane, prm, slots)
+                : associate_t<8>(src, n_src, tgt, G, est, is_plane, prm, slots);
+}
+}  // extern "C++"
 
 int hostcheck_associate(const double* src, uint64_t n_src, const double* tgt, uint64_t n_tgt, const double est[7],
                         int is_plane, const loamx_reg_params* prm, uint8_t* valid, uint64_t* nearest, double* moved,
