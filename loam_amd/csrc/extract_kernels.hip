@@ -142,6 +142,159 @@ __global__ __launch_bounds__(WAVES * 64) void select_kernel(const double* __rest
   }
 }
 
+
+/* ------------------------------------------------------------------------------------------------
+ * select_mis_kernel — the same selection as select_kernel, restated as a lexicographically-first
+ * maximal independent set on 64-bit lane masks (extract_math.h) instead of one wave-wide arg-max per
+ * pick: per (sector, pass) a few rounds of bit operations + 4 neighbour shuffles, one 64-lane
+ * bitonic sort of the picks (gives the reference's output order and the max+1 cap), one more
+ * shuffle pair for the suppression. Used when np-1 = R in 1..4, R <= CH, CH + 2R <= 64 and a sector
+ * can hold at most 64 picks; select_kernel remains the general fallback (identical results).
+ * ---------------------------------------------------------------------------------------------- */
+__device__ __forceinline__ uint64_t shfl_prev(uint64_t v, int lane) {
+  const uint64_t t = (uint64_t)__shfl_up((unsigned long long)v, 1);
+  return lane == 0 ? 0ull : t;
+}
+__device__ __forceinline__ uint64_t shfl_next(uint64_t v, int lane) {
+  const uint64_t t = (uint64_t)__shfl_down((unsigned long long)v, 1);
+  return lane == 63 ? 0ull : t;
+}
+
+template <bool EDGE>
+__device__ __forceinline__ bool before_or_invalid(double ca, int32_t ia, double cb, int32_t ib) {
+  if (ia < 0) return false;  // padding sorts last
+  if (ib < 0) return true;
+  return EDGE ? edge_before(ca, ia, cb, ib) : planar_before(ca, ia, cb, ib);
+}
+
+template <int R, bool EDGE>
+__device__ __forceinline__ uint32_t mis_pass(int lane, int CH, int base, int start, int end, uint64_t& V, uint64_t T,
+                                             const uint64_t gt[R], const double* s_c, double* m_c, int32_t* m_i,
+                                             uint32_t cap, uint32_t line_base, uint32_t* __restrict__ stage) {
+  const uint64_t cm = low_mask(CH);
+  int lo = start - base, hi = end - base;
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > CH ? CH : hi;
+  const uint64_t sm = hi > lo ? (low_mask(hi) & ~low_mask(lo)) : 0ull;
+  uint64_t U = V & T & sm;
+  if (__ballot(U != 0) == 0) return 0;
+  uint64_t Pk = 0;
+  do {  // rounds of "local maxima win, their neighbours leave"
+    const uint64_t Uw = mis_window<R>(U, shfl_prev(U, lane), shfl_next(U, lane), CH);
+    const uint64_t win = (mis_winners<R, EDGE>(Uw, gt) >> R) & cm;
+    const uint64_t Ww = mis_window<R>(win, shfl_prev(win, lane), shfl_next(win, lane), CH);
+    Pk |= win;
+    U &= ~((mis_spread<R>(Ww) >> R) & cm);
+  } while (__ballot(U != 0) != 0);
+  // compact the picks into LDS slots (at most 64 by construction of the launch condition)
+  const uint32_t cnt = (uint32_t)__popcll(Pk);
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  const uint32_t total = __shfl(incl, 63);
+  uint32_t slot = incl - cnt;
+  for (uint64_t bits = Pk; bits; bits &= bits - 1) {
+    const int j = __ffsll((unsigned long long)bits) - 1;
+    if (slot < 64) {
+      m_c[slot] = s_c[base + j];
+      m_i[slot] = base + j;
+    }
+    slot++;
+  }
+  wave_lds_sync();
+  double c = (uint32_t)lane < total ? m_c[lane] : 0.0;
+  int32_t i = (uint32_t)lane < total ? m_i[lane] : -1;
+  wave_lds_sync();
+  // 64-lane bitonic sort into the walk order of the reference (edge: descending, planar: ascending)
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const double oc = __shfl_xor(c, j);
+      const int32_t oi = __shfl_xor(i, j);
+      const bool keep_first = ((lane & j) == 0) == ((lane & k) == 0);
+      const bool other_first = before_or_invalid<EDGE>(oc, oi, c, i);
+      const bool me_first = before_or_invalid<EDGE>(c, i, oc, oi);
+      if (keep_first ? other_first : me_first) c = oc, i = oi;
+    }
+  }
+  const uint32_t kept = total < cap ? total : cap;  // features-inl.h:155/:177: at most max+1 picks
+  if ((uint32_t)lane < kept) stage[lane] = line_base + (uint32_t)i;
+  // which of my picks survive the cap: those not after the last kept one
+  uint64_t K = Pk;
+  if (kept < total) {
+    const double tc = __shfl(c, (int)kept - 1);
+    const int32_t ti = __shfl(i, (int)kept - 1);
+    K = 0;
+    for (uint64_t bits = Pk; bits; bits &= bits - 1) {
+      const int j = __ffsll((unsigned long long)bits) - 1;
+      const double cj = s_c[base + j];
+      if (!(EDGE ? edge_before(tc, ti, cj, base + j) : planar_before(tc, ti, cj, base + j))) K |= 1ull << j;
+    }
+  }
+  // suppression of +-(np-1) around every kept pick (features-inl.h:148-151 / :170-173)
+  const uint64_t Kw = mis_window<R>(K, shfl_prev(K, lane), shfl_next(K, lane), CH);
+  V &= ~((mis_spread<R>(Kw) >> R) & cm);
+  return kept;
+}
+
+template <int R, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __restrict__ curv,
+                                                                const uint8_t* __restrict__ mask, size_t n_lines,
+                                                                ExtractParams P, ExtractStage st) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t line = (size_t)blockIdx.x * WAVES + wave;
+  if (line >= n_lines) return;  // whole wavefront leaves; no workgroup barrier below
+  const int W = (int)P.W, CH = (W + 63) / 64, base = lane * CH;
+  const size_t per_wave = (size_t)W * 8 + 64 * 8 + 64 * 4 + (((size_t)W + 7) & ~(size_t)7);
+  double* s_c = reinterpret_cast<double*>(smem + wave * per_wave);
+  double* m_c = s_c + W;
+  int32_t* m_i = reinterpret_cast<int32_t*>(m_c + 64);
+  uint8_t* s_v = reinterpret_cast<uint8_t*>(m_i + 64);
+  for (int i = lane; i < W; i += 64) {
+    s_c[i] = curv[line * (size_t)W + i];
+    s_v[i] = mask[line * (size_t)W + i];
+  }
+  wave_lds_sync();
+  uint64_t V = 0, ET = 0, PT = 0, gt[R];
+  for (int j = 0; j < CH; j++) {
+    const int i = base + j;
+    if (i < W) {
+      const double c = s_c[i];
+      V |= (uint64_t)(s_v[i] != 0) << j;
+      ET |= (uint64_t)(c > P.edge_thr) << j;
+      PT |= (uint64_t)(c < P.planar_thr) << j;
+    }
+  }
+#pragma unroll
+  for (int d = 1; d <= R; d++) {
+    uint64_t g = 0;
+    for (int t = 0; t < CH + 2 * R; t++) {
+      const int i = base - R + t;
+      if (i >= 0 && i + d < W) g |= (uint64_t)(s_c[i] > s_c[i + d]) << t;
+    }
+    gt[d - 1] = g;
+  }
+  const uint32_t line_base = (uint32_t)(line % P.H) * P.W;
+  for (uint32_t s = 0; s < P.S; s++) {
+    const int start = (int)(s * P.pps);
+    const int end = (s == P.S - 1) ? W : start + (int)P.pps;  // features-inl.h:31-35
+    const size_t group = line * P.S + s;
+    const uint32_t ne = mis_pass<R, true>(lane, CH, base, start, end, V, ET, gt, s_c, m_c, m_i, P.cap_edge, line_base,
+                                          st.edge_stage + group * P.cap_edge);
+    const uint32_t npl = mis_pass<R, false>(lane, CH, base, start, end, V, PT, gt, s_c, m_c, m_i, P.cap_planar,
+                                            line_base, st.planar_stage + group * P.cap_planar);
+    if (lane == 0) {
+      st.edge_cnt[group] = ne;
+      st.planar_cnt[group] = npl;
+    }
+  }
+}
+
 // block-wide exclusive scan of one value per thread (256 threads); returns the exclusive prefix and
 // writes the block total to *total
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_scan, uint32_t* total) {
@@ -224,10 +377,37 @@ void launch_curvature_valid(const double* d_xyz, size_t n_scans, const ExtractPa
   hipLaunchKernelGGL(curvature_valid_kernel, grid, dim3(256), 0, s, d_xyz, P, d_curv, d_mask);
 }
 
+
+template <int R>
+static void launch_select_mis(const double* d_curv, const uint8_t* d_mask, size_t n_lines, const ExtractParams& P,
+                              const ExtractStage& st, hipStream_t s) {
+  const size_t per_wave = (size_t)P.W * 8 + 64 * 8 + 64 * 4 + (((size_t)P.W + 7) & ~(size_t)7);
+  if (per_wave * 4 <= 48 * 1024) {
+    hipLaunchKernelGGL((select_mis_kernel<R, 4>), dim3((unsigned)((n_lines + 3) / 4)), dim3(256), per_wave * 4, s, d_curv,
+                       d_mask, n_lines, P, st);
+  } else {
+    hipLaunchKernelGGL((select_mis_kernel<R, 1>), dim3((unsigned)n_lines), dim3(64), per_wave, s, d_curv, d_mask, n_lines,
+                       P, st);
+  }
+}
+
 void launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, const ExtractParams& P,
                    const ExtractStage& st, hipStream_t s) {
   const size_t n_lines = n_scans * P.H;
   if (n_lines == 0 || P.W == 0) return;
+  // bitmask-MIS fast path: R = np-1 in 1..4, lane chunk wide enough for the halo, at most 64 picks
+  // per sector (picks are >= R+1 points apart), the cap itself at most 64
+  const int R = (int)P.np - 1, CH = ((int)P.W + 63) / 64;
+  const uint32_t longest = P.W - (P.S - 1) * P.pps;
+  const bool mis_ok = R >= 1 && R <= 4 && CH >= R && CH + 2 * R <= 64 && (longest + R) / (R + 1) <= 64;
+  if (mis_ok) {
+    switch (R) {
+      case 1: launch_select_mis<1>(d_curv, d_mask, n_lines, P, st, s); return;
+      case 2: launch_select_mis<2>(d_curv, d_mask, n_lines, P, st, s); return;
+      case 3: launch_select_mis<3>(d_curv, d_mask, n_lines, P, st, s); return;
+      default: launch_select_mis<4>(d_curv, d_mask, n_lines, P, st, s); return;
+    }
+  }
   const size_t per_wave = (size_t)P.W * 8 + (((size_t)P.W + 7) & ~(size_t)7);
   if (P.W <= 1024) {
     constexpr int WAVES = 4;

@@ -100,4 +100,54 @@ LOAMX_EHD bool valid_from_codes(const uint8_t* code, int i, uint32_t col, uint32
 LOAMX_EHD bool edge_before(double ca, int32_t ia, double cb, int32_t ib) { return ca > cb || (ca == cb && ia > ib); }
 LOAMX_EHD bool planar_before(double ca, int32_t ia, double cb, int32_t ib) { return ca < cb || (ca == cb && ia < ib); }
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Selection as a lexicographically-first maximal independent set on lane bitmasks.
+ *
+ * The reference's greedy walk over the sorted sector (features-inl.h:138-180) picks a candidate iff
+ * no higher-priority candidate within +-(np-1) points was picked before it. Without the per-sector
+ * cap that is the lexicographically-first MIS of the "within R = np-1 points" graph, which the
+ * classic parallel rule computes exactly: in every round each remaining candidate that beats all of
+ * its remaining neighbours is picked and its neighbours are removed. The cap (max+1 picks) then
+ * keeps the first max+1 picks in priority order, because a pick never depends on lower priorities.
+ *
+ * One wavefront owns a scan line; lane l owns the CH = ceil(W/64) consecutive points
+ * [l*CH, (l+1)*CH) as bits of a 64-bit mask. A lane's "window" adds R halo bits from each
+ * neighbouring lane: window bit t <-> point l*CH - R + t, t in [0, CH + 2R). Needs R <= CH,
+ * CH + 2R <= 64.
+ * ---------------------------------------------------------------------------------------------- */
+LOAMX_EHD uint64_t low_mask(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+
+template <int R>
+LOAMX_EHD uint64_t mis_window(uint64_t own, uint64_t prev, uint64_t next, int CH) {
+  const uint64_t mR = low_mask(R);
+  return ((prev >> (CH - R)) & mR) | (own << R) | ((next & mR) << (R + CH));
+}
+
+// gt[d-1] bit t: curvature(window point t) > curvature(window point t+d).
+// Returns the window bits that beat every remaining neighbour (only the own bits are meaningful).
+template <int R, bool EDGE>
+LOAMX_EHD uint64_t mis_winners(uint64_t Uw, const uint64_t gt[R]) {
+  uint64_t blocked = 0;
+#pragma unroll
+  for (int d = 1; d <= R; d++) {
+    const uint64_t g = gt[d - 1];
+    const uint64_t gs = g << d;                      // bit t: c(t-d) > c(t)
+    const uint64_t beats_up = EDGE ? g : ~g;         // t is before t+d in the walk order
+    const uint64_t beats_dn = EDGE ? ~gs : gs;       // t is before t-d
+    blocked |= (Uw >> d) & ~beats_up;
+    blocked |= (Uw << d) & ~beats_dn;
+  }
+  return Uw & ~blocked;
+}
+
+// every window bit within R of a set bit of Ww
+template <int R>
+LOAMX_EHD uint64_t mis_spread(uint64_t Ww) {
+  uint64_t r = Ww;
+#pragma unroll
+  for (int d = 1; d <= R; d++) r |= (Ww << d) | (Ww >> d);
+  return r;
+}
+
 }  // namespace loamx

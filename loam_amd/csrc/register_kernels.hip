@@ -154,6 +154,9 @@ __global__ void state_init_kernel(RegBatch B, RegConfig C) {
 }
 
 constexpr int kAssocThreads = 256;
+#ifndef LOAMX_ASSOC_WAVES
+#define LOAMX_ASSOC_WAVES 4  // measured: 2 -> 12.3 ms, 3 -> 9.3, 4 -> 8.1 (320 B scratch), 5+ spills badly
+#endif
 
 // Workgroup -> (pair, chunk) mapping: workgroups are dealt round-robin over the 8 XCDs, so all
 // chunks of one pair are given ids with the same id % 8 and share one XCD's L2 (the pair's target
@@ -167,7 +170,7 @@ __device__ __forceinline__ bool xcd_pair_map(uint32_t block, uint32_t blocks_per
 }
 
 template <bool PLANE, int KM>
-__global__ __launch_bounds__(kAssocThreads) void associate_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
+__global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
   __shared__ uint32_t s_count[kAssocThreads / 64];
   size_t pair;
   uint32_t chunk;

@@ -89,6 +89,122 @@ int hostcheck_select(const double* curv, const uint8_t* mask_in, uint64_t H, uin
   return 0;
 }
 
+
+/* ---- lane-level emulation of select_mis_kernel (bitmask MIS + cap by priority order) -------------- */
+}  // extern "C"
+namespace {
+template <int R>
+void select_mis_line(const double* c, std::vector<uint8_t>& valid, const ExtractParams& P, uint32_t line,
+                     std::vector<uint32_t>& edge, std::vector<uint32_t>& planar, bool* ok) {
+  const int W = (int)P.W, CH = (W + 63) / 64;
+  if (CH < R || CH + 2 * R > 64) {
+    *ok = false;
+    return;
+  }
+  uint64_t V[64], ET[64], PT[64], GT[64][R > 0 ? R : 1];
+  for (int l = 0; l < 64; l++) {
+    V[l] = ET[l] = PT[l] = 0;
+    for (int j = 0; j < CH; j++) {
+      const int i = l * CH + j;
+      if (i >= W) continue;
+      if (valid[i]) V[l] |= 1ull << j;
+      if (c[i] > P.edge_thr) ET[l] |= 1ull << j;
+      if (c[i] < P.planar_thr) PT[l] |= 1ull << j;
+    }
+    for (int d = 1; d <= R; d++) {
+      uint64_t g = 0;
+      for (int t = 0; t < CH + 2 * R; t++) {
+        const int i = l * CH - R + t;
+        if (i >= 0 && i + d < W && c[i] > c[i + d]) g |= 1ull << t;
+      }
+      GT[l][d - 1] = g;
+    }
+  }
+  const uint64_t cm = low_mask(CH);
+  for (uint32_t s = 0; s < P.S; s++) {
+    const int start = (int)(s * P.pps), end = (s == P.S - 1) ? W : start + (int)P.pps;
+    for (int pass = 0; pass < 2; pass++) {
+      const bool EDGE = pass == 0;
+      const uint32_t maxf = EDGE ? P.max_edge : P.max_planar;
+      uint64_t U[64], Pk[64];
+      bool any = false;
+      for (int l = 0; l < 64; l++) {
+        uint64_t sm = 0;
+        for (int j = 0; j < CH; j++) {
+          const int i = l * CH + j;
+          if (i >= start && i < end) sm |= 1ull << j;
+        }
+        U[l] = V[l] & (EDGE ? ET[l] : PT[l]) & sm;
+        Pk[l] = 0;
+        any |= U[l] != 0;
+      }
+      while (any) {
+        uint64_t win[64];
+        for (int l = 0; l < 64; l++) {
+          const uint64_t Uw = mis_window<R>(U[l], l ? U[l - 1] : 0, l < 63 ? U[l + 1] : 0, CH);
+          const uint64_t w = EDGE ? mis_winners<R, true>(Uw, GT[l]) : mis_winners<R, false>(Uw, GT[l]);
+          win[l] = (w >> R) & cm;
+        }
+        any = false;
+        uint64_t nU[64];
+        for (int l = 0; l < 64; l++) {
+          const uint64_t Ww = mis_window<R>(win[l], l ? win[l - 1] : 0, l < 63 ? win[l + 1] : 0, CH);
+          const uint64_t rem = (mis_spread<R>(Ww) >> R) & cm;
+          Pk[l] |= win[l];
+          nU[l] = U[l] & ~rem;
+          any |= nU[l] != 0;
+        }
+        for (int l = 0; l < 64; l++) U[l] = nU[l];
+      }
+      // members in priority order, keep the first max+1
+      std::vector<std::pair<double, int>> mem;
+      for (int l = 0; l < 64; l++)
+        for (int j = 0; j < CH; j++)
+          if (Pk[l] >> j & 1) mem.push_back({c[l * CH + j], l * CH + j});
+      std::sort(mem.begin(), mem.end(), [&](const std::pair<double, int>& a, const std::pair<double, int>& b) {
+        return EDGE ? edge_before(a.first, a.second, b.first, b.second) : planar_before(a.first, a.second, b.first, b.second);
+      });
+      const size_t kept = std::min<size_t>(mem.size(), (size_t)maxf + 1);
+      uint64_t K[64] = {0};
+      for (size_t k = 0; k < kept; k++) {
+        (EDGE ? edge : planar).push_back(line * P.W + (uint32_t)mem[k].second);
+        K[mem[k].second / CH] |= 1ull << (mem[k].second % CH);
+      }
+      for (int l = 0; l < 64; l++) {
+        const uint64_t Kw = mis_window<R>(K[l], l ? K[l - 1] : 0, l < 63 ? K[l + 1] : 0, CH);
+        V[l] &= ~((mis_spread<R>(Kw) >> R) & cm);
+      }
+    }
+  }
+  *ok = true;
+}
+}  // namespace
+extern "C" {
+
+// returns 0 if the MIS formulation applies to these parameters (else 1: kernel falls back)
+int hostcheck_select_mis(const double* curv, const uint8_t* mask_in, uint64_t H, uint64_t W, const loamx_fe_params* fe,
+                         uint32_t* edge_idx, uint64_t* n_edge, uint32_t* planar_idx, uint64_t* n_planar) {
+  const ExtractParams P = make_params(H, W, 0, 0, fe);
+  std::vector<uint32_t> e, p;
+  std::vector<uint8_t> valid(W);
+  for (uint64_t line = 0; line < H; line++) {
+    for (uint32_t i = 0; i < W; i++) valid[i] = mask_in[line * W + i];
+    bool ok = false;
+    switch (P.np) {
+      case 2: select_mis_line<1>(curv + line * W, valid, P, (uint32_t)line, e, p, &ok); break;
+      case 3: select_mis_line<2>(curv + line * W, valid, P, (uint32_t)line, e, p, &ok); break;
+      case 4: select_mis_line<3>(curv + line * W, valid, P, (uint32_t)line, e, p, &ok); break;
+      case 5: select_mis_line<4>(curv + line * W, valid, P, (uint32_t)line, e, p, &ok); break;
+      default: break;
+    }
+    if (!ok) return 1;
+  }
+  std::copy(e.begin(), e.end(), edge_idx);
+  std::copy(p.begin(), p.end(), planar_idx);
+  *n_edge = e.size(), *n_planar = p.size();
+  return 0;
+}
+
 /* ---- registration ------------------------------------------------------------------------------ */
 struct HostGrid {
   GridDesc g;

@@ -88,6 +88,21 @@ def select(curv, mask, H, W, fe):
     return e[:ne.value].copy(), p[:npl.value].copy()
 
 
+def select_mis(curv, mask, H, W, fe):
+    """Lane-level emulation of the bitmask-MIS selection kernel; None if the parameters need the fallback."""
+    curv = np.ascontiguousarray(curv, dtype=np.float64)
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    e = np.empty(H * W + 1, dtype=np.uint32)
+    p = np.empty(H * W + 1, dtype=np.uint32)
+    ne, npl = C.c_uint64(0), C.c_uint64(0)
+    rc = lib().hostcheck_select_mis(_dp(curv), mask.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_uint64(H), C.c_uint64(W),
+                                    C.byref(fe), e.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(ne),
+                                    p.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(npl))
+    if rc:
+        return None
+    return e[:ne.value].copy(), p[:npl.value].copy()
+
+
 def knn(pts, q, k, max_dist):
     pts = np.ascontiguousarray(pts, dtype=np.float64)
     q = np.ascontiguousarray(q, dtype=np.float64)
