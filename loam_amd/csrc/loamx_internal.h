@@ -58,6 +58,8 @@ struct GridSet {
 struct AssocBuffers {
   double* edge;       // [9][n_pairs * edge_stride]
   double* plane;      // [7][n_pairs * planar_stride]
+  uint32_t* nn_edge;        // [1 + kMaxK][n_pairs * edge_stride]   neighbour count, then positions in the sorted target
+  uint32_t* nn_plane;       // [1 + kMaxK][n_pairs * planar_stride]
   uint32_t* nearest_edge;   // [n_pairs * edge_stride]   nearest target index (detail capture)
   uint32_t* nearest_plane;  // [n_pairs * planar_stride]
   uint32_t* n_assoc;  // [n_pairs][2] valid edge / plane associations of the current iteration

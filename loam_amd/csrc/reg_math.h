@@ -186,30 +186,36 @@ LOAMX_HD void knn_insert(KnnResult<KM>& r, int k, double d2, uint32_t pos, uint3
   }
 }
 
-template <int KM>
-LOAMX_HD void knn_consider(KnnResult<KM>& r, int k, Vec3 q, const GridPoint& t, uint32_t p) {
-#if defined(LOAMX_KNN_STATS)
-  g_cand++;
-#endif
-  const double dx = q.x - t.x, dy = q.y - t.y, dz = q.z - t.z;
-  const double d2 = dx * dx + dy * dy + dz * dz;  // nanoflann L2_Simple: ((dx^2 + dy^2) + dz^2)
-  if (d2 <= r.worst) knn_insert(r, k, d2, p, t.orig);
-}
-
-// candidates are fetched four at a time so that four 32-byte loads are in flight per lane
+// Candidates are fetched four at a time (four independent 32-byte loads in flight per lane); the
+// insertion code exists once, in a rolled loop that only runs when one of the four can enter.
 template <int KM>
 LOAMX_HD void knn_scan_range(KnnResult<KM>& r, int k, Vec3 q, const GridPoint* __restrict__ sp, uint32_t begin, uint32_t end) {
-  uint32_t p = begin;
-  for (; p + 4 <= end; p += 4) {
-    const GridPoint t0 = sp[p], t1 = sp[p + 1], t2 = sp[p + 2], t3 = sp[p + 3];
-    knn_consider(r, k, q, t0, p);
-    knn_consider(r, k, q, t1, p + 1);
-    knn_consider(r, k, q, t2, p + 2);
-    knn_consider(r, k, q, t3, p + 3);
-  }
-  for (; p < end; p++) {
-    const GridPoint t = sp[p];
-    knn_consider(r, k, q, t, p);
+  for (uint32_t p = begin; p < end; p += 4) {
+    const uint32_t n = end - p < 4u ? end - p : 4u, last = end - 1;
+    const GridPoint t0 = sp[p];
+    const GridPoint t1 = sp[p + 1 < last ? p + 1 : last];
+    const GridPoint t2 = sp[p + 2 < last ? p + 2 : last];
+    const GridPoint t3 = sp[p + 3 < last ? p + 3 : last];
+#if defined(LOAMX_KNN_STATS)
+    g_cand += n;
+#endif
+    // nanoflann L2_Simple: ((dx^2 + dy^2) + dz^2)
+    double dx = q.x - t0.x, dy = q.y - t0.y, dz = q.z - t0.z;
+    const double d0 = dx * dx + dy * dy + dz * dz;
+    dx = q.x - t1.x, dy = q.y - t1.y, dz = q.z - t1.z;
+    const double d1 = dx * dx + dy * dy + dz * dz;
+    dx = q.x - t2.x, dy = q.y - t2.y, dz = q.z - t2.z;
+    const double d2 = dx * dx + dy * dy + dz * dz;
+    dx = q.x - t3.x, dy = q.y - t3.y, dz = q.z - t3.z;
+    const double d3 = dx * dx + dy * dy + dz * dz;
+    if (d0 <= r.worst || (n > 1 && d1 <= r.worst) || (n > 2 && d2 <= r.worst) || (n > 3 && d3 <= r.worst)) {
+#pragma unroll 1
+      for (uint32_t u = 0; u < n; u++) {
+        const double d = u == 0 ? d0 : (u == 1 ? d1 : (u == 2 ? d2 : d3));
+        const uint32_t orig = u == 0 ? t0.orig : (u == 1 ? t1.orig : (u == 2 ? t2.orig : t3.orig));
+        if (d <= r.worst) knn_insert(r, k, d, p + u, orig);
+      }
+    }
   }
 }
 
@@ -288,10 +294,10 @@ LOAMX_HD int knn_search(const GridDesc& g, const uint32_t* __restrict__ cell_sta
     if (first && w == 1) {
       // Common case. The cell_start entries of all nine rows of the 3x3x3 block are fetched up
       // front (18 independent loads instead of nine dependent round trips); the rows are then
-      // walked centre first, then faces, then corners, as one flattened candidate loop, each row
-      // skipped if its slab is already farther than the current bound.
+      // walked centre first, then faces, then corners, each row skipped if its slab is already
+      // farther than the current bound. The row loop is kept rolled (one copy of the candidate
+      // loop) to hold the register count down.
       uint32_t rb[9], re[9];
-      double rm[9];
       const int32_t xa = cx - 1 < 0 ? 0 : cx - 1, xb = cx + 1 > g.nx - 1 ? g.nx - 1 : cx + 1;
 #pragma unroll
       for (int j = 0; j < 9; j++) {
@@ -300,35 +306,40 @@ LOAMX_HD int knn_search(const GridDesc& g, const uint32_t* __restrict__ cell_sta
         const uint32_t row = ok ? (uint32_t)((iz * g.ny + iy) * g.nx) : 0u;
         rb[j] = ok ? cell_start[row + xa] : 0u;
         re[j] = ok ? cell_start[row + xb + 1] : 0u;
-        const double sy = slab_dist(q.y, g.oy, g.h, iy), sz = slab_dist(q.z, g.oz, g.h, iz);
-        rm[j] = sy * sy + sz * sz;
       }
-#pragma unroll
+#pragma unroll 1
       for (int o = 0; o < 9; o++) {
-        const int j = o == 0 ? 4 : (o == 1 ? 1 : (o == 2 ? 3 : (o == 3 ? 5 : (o == 4 ? 7 : (o == 5 ? 0 : (o == 6 ? 2 : (o == 7 ? 6 : 8)))))));
-        const double bound = r.worst < r2 ? r.worst : r2;
-        if (rb[j] < re[j] && rm[j] <= bound) {
-#if defined(LOAMX_KNN_STATS)
-          g_rows++;
-#endif
-          knn_scan_range(r, k, q, sp, rb[j], re[j]);
+        const int j = (int)((0x862075314ull >> (4 * o)) & 0xFull);  // 4, 1, 3, 5, 7, 0, 2, 6, 8
+        uint32_t b = rb[0], e = re[0];
+#pragma unroll
+        for (int t = 1; t < 9; t++) {
+          if (j == t) b = rb[t], e = re[t];
         }
+        if (b >= e) continue;
+        const double sy = slab_dist(q.y, g.oy, g.h, cy + (j % 3) - 1), sz = slab_dist(q.z, g.oz, g.h, cz + (j / 3) - 1);
+        const double bound = r.worst < r2 ? r.worst : r2;
+        if (sy * sy + sz * sz > bound) continue;
+#if defined(LOAMX_KNN_STATS)
+        g_rows++;
+#endif
+        knn_scan_range(r, k, q, sp, b, e);
       }
     } else {
-    if (first) knn_scan_row(g, cell_start, sp, q, k, r2, cy, cz, cx - w, cx + w, r);  // centre row first
-    for (int32_t dz = -w; dz <= w; dz++) {
-      for (int32_t dy = -w; dy <= w; dy++) {
-        const int32_t ady = dy < 0 ? -dy : dy, adz = dz < 0 ? -dz : dz;
-        if (first) {
-          if (dy != 0 || dz != 0) knn_scan_row(g, cell_start, sp, q, k, r2, cy + dy, cz + dz, cx - w, cx + w, r);
-        } else if (ady == w || adz == w) {
-          knn_scan_row(g, cell_start, sp, q, k, r2, cy + dy, cz + dz, cx - w, cx + w, r);
-        } else {
-          knn_scan_row(g, cell_start, sp, q, k, r2, cy + dy, cz + dz, cx - w, cx - w, r);
-          knn_scan_row(g, cell_start, sp, q, k, r2, cy + dy, cz + dz, cx + w, cx + w, r);
+      // general round: cells at Chebyshev distance <= w (first round) or == w (later rounds)
+#pragma unroll 1
+      for (int32_t dz = -w; dz <= w; dz++) {
+#pragma unroll 1
+        for (int32_t dy = -w; dy <= w; dy++) {
+          const int32_t ady = dy < 0 ? -dy : dy, adz = dz < 0 ? -dz : dz;
+          const int nseg = (first || ady == w || adz == w) ? 1 : 2;  // full row, or just its two end cells
+#pragma unroll 1
+          for (int sg = 0; sg < nseg; sg++) {
+            const int32_t xlo = (nseg == 2 && sg == 1) ? cx + w : cx - w;
+            const int32_t xhi = (nseg == 2 && sg == 0) ? cx - w : cx + w;
+            knn_scan_row(g, cell_start, sp, q, k, r2, cy + dy, cz + dz, xlo, xhi, r);
+          }
         }
       }
-    }
     }
     first = false;
     // unscanned points are farther than (w*h) along some axis; keep a relative safety margin for

@@ -169,9 +169,14 @@ __device__ __forceinline__ bool xcd_pair_map(uint32_t block, uint32_t blocks_per
   return pair < n_pairs;
 }
 
+// Association is split in two kernels so that each runs at its own register budget:
+//   associate_knn_kernel : the latency-bound grid walk; writes the neighbour count and the positions
+//                          (in the cell-sorted target array) of the k nearest, ascending.
+//   associate_fit_kernel : pure FP64 arithmetic — gathers the neighbours, fitLine / fitPlane, guards,
+//                          writes the association record.
 template <bool PLANE, int KM>
-__global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
-  __shared__ uint32_t s_count[kAssocThreads / 64];
+__global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_knn_kernel(RegBatch B, RegConfig C,
+                                                                                         uint32_t blocks_per_pair) {
   size_t pair;
   uint32_t chunk;
   if (!xcd_pair_map(blockIdx.x, blocks_per_pair, B.n_pairs, pair, chunk)) return;
@@ -184,25 +189,54 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_ke
   const GridSet& src_gs = PLANE ? B.src_grid_plane : B.src_grid_edge;
   if (chunk == 0 && threadIdx.x == 0 && B.assoc_slots)
     atomicAdd(&B.assoc_slots[PLANE ? 1 : 0], (unsigned long long)(n_src < stride ? n_src : stride));
+  if (i >= n_src || i >= stride) return;
+  // queries are taken in the source set's own cell order: neighbouring lanes look at neighbouring
+  // target cells (shared cache lines, similar trip counts)
+  const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
+  const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));  // registration.cpp:34 / :75
+  const GridDesc g = gs.desc[pair];
+  const uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
+  const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
+  KnnResult<KM> r;
+  const int kept = knn_search(g, cs, sp, p, PLANE ? C.k_plane : C.k_edge, PLANE ? C.r_plane : C.r_edge, r);
+  const size_t field = B.n_pairs * stride, slot = pair * stride + i;
+  uint32_t* __restrict__ nn = PLANE ? B.assoc.nn_plane : B.assoc.nn_edge;  // [1 + KM][n_pairs * stride]
+  nn[slot] = (uint32_t)kept;
+#pragma unroll
+  for (int j = 0; j < KM; j++) nn[(1 + j) * field + slot] = r.pos[j];
+}
+
+template <bool PLANE, int KM>
+__global__ __launch_bounds__(kAssocThreads) void associate_fit_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
+  __shared__ uint32_t s_count[kAssocThreads / 64];
+  size_t pair;
+  uint32_t chunk;
+  if (!xcd_pair_map(blockIdx.x, blocks_per_pair, B.n_pairs, pair, chunk)) return;
+  const uint32_t i = chunk * kAssocThreads + threadIdx.x;
+  const PairState& S = B.state[pair];
+  if (!S.active) return;  // uniform per workgroup
+  const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
+  const uint32_t n_src = PLANE ? B.n_src_planar[pair * B.in_pitch] : B.n_src_edge[pair * B.in_pitch];
+  const GridSet& gs = PLANE ? B.grid_plane : B.grid_edge;
+  const GridSet& src_gs = PLANE ? B.src_grid_plane : B.src_grid_edge;
   bool valid = false;
   if (i < n_src && i < stride) {
-    // queries are taken in the source set's own cell order: neighbouring lanes look at neighbouring
-    // target cells (shared cache lines, similar trip counts)
     const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
-    const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));  // registration.cpp:34 / :75
-    const GridDesc g = gs.desc[pair];
-    const uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
+    const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));
     const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
-    KnnResult<KM> r;
-    const int kept = knn_search(g, cs, sp, p, PLANE ? C.k_plane : C.k_edge, PLANE ? C.r_plane : C.r_edge, r);
+    const size_t field = B.n_pairs * stride, slot = pair * stride + i;
+    const uint32_t* __restrict__ nn = PLANE ? B.assoc.nn_plane : B.assoc.nn_edge;
+    const int kept = (int)nn[slot];
     double prim[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t nearest = 0xFFFFFFFFu;
     if (kept >= (PLANE ? C.min_plane_pts : C.min_line_pts)) {  // registration.cpp:39 / :80
       Vec3 nb[KM];
 #pragma unroll
       for (int j = 0; j < KM; j++) {
         if (j < kept) {
-          const GridPoint t = sp[r.pos[j]];
+          const GridPoint t = sp[nn[(1 + j) * field + slot]];
           nb[j] = v3(t.x, t.y, t.z);
+          if (j == 0) nearest = t.orig;
         } else {
           nb[j] = v3(0, 0, 0);
         }
@@ -220,7 +254,6 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_ke
         prim[0] = a.x, prim[1] = a.y, prim[2] = a.z, prim[3] = b.x, prim[4] = b.y, prim[5] = b.z;
       }
     }
-    const size_t field = B.n_pairs * stride, slot = pair * stride + i;
     double* __restrict__ rec = PLANE ? B.assoc.plane : B.assoc.edge;
     rec[slot] = valid ? p.x : __longlong_as_double(0x7FF8000000000000ll);
     rec[field + slot] = p.y;
@@ -228,7 +261,7 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_ke
 #pragma unroll
     for (int f = 0; f < (PLANE ? 4 : 6); f++) rec[(3 + f) * field + slot] = prim[f];
     // detail capture is indexed by the caller's source index
-    (PLANE ? B.assoc.nearest_plane : B.assoc.nearest_edge)[pair * stride + sq.orig] = valid ? r.orig[0] : 0xFFFFFFFFu;
+    (PLANE ? B.assoc.nearest_plane : B.assoc.nearest_edge)[pair * stride + sq.orig] = valid ? nearest : 0xFFFFFFFFu;
   }
   const unsigned long long m = __ballot(valid);
   if ((threadIdx.x & 63) == 0) s_count[threadIdx.x >> 6] = (uint32_t)__popcll(m);
@@ -419,18 +452,22 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   const uint32_t bp = (uint32_t)((B.planar_stride + kAssocThreads - 1) / kAssocThreads);
   const size_t pair_groups = (B.n_pairs + 7) / 8;  // grid covers 8 XCD lanes x pair_groups x chunks
   // register-resident neighbour lists are instantiated for K <= 5 (the reference's default) and K <= 8
+#define LOAMX_LAUNCH_ASSOC(PL, KMV, nblk)                                                                              \
+  do {                                                                                                                 \
+    hipLaunchKernelGGL((associate_knn_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * (nblk))), dim3(kAssocThreads), \
+                       0, s, B, C, (nblk));                                                                            \
+    hipLaunchKernelGGL((associate_fit_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * (nblk))), dim3(kAssocThreads), \
+                       0, s, B, C, (nblk));                                                                            \
+  } while (0)
   if (be) {
-    if (C.k_edge <= 5)
-      hipLaunchKernelGGL((associate_kernel<false, 5>), dim3((unsigned)(pair_groups * 8 * be)), dim3(kAssocThreads), 0, s, B, C, be);
-    else
-      hipLaunchKernelGGL((associate_kernel<false, 8>), dim3((unsigned)(pair_groups * 8 * be)), dim3(kAssocThreads), 0, s, B, C, be);
+    if (C.k_edge <= 5) LOAMX_LAUNCH_ASSOC(false, 5, be);
+    else LOAMX_LAUNCH_ASSOC(false, 8, be);
   }
   if (bp) {
-    if (C.k_plane <= 5)
-      hipLaunchKernelGGL((associate_kernel<true, 5>), dim3((unsigned)(pair_groups * 8 * bp)), dim3(kAssocThreads), 0, s, B, C, bp);
-    else
-      hipLaunchKernelGGL((associate_kernel<true, 8>), dim3((unsigned)(pair_groups * 8 * bp)), dim3(kAssocThreads), 0, s, B, C, bp);
+    if (C.k_plane <= 5) LOAMX_LAUNCH_ASSOC(true, 5, bp);
+    else LOAMX_LAUNCH_ASSOC(true, 8, bp);
   }
+#undef LOAMX_LAUNCH_ASSOC
 }
 
 void launch_sweep(const RegBatch& B, hipStream_t s) {
