@@ -488,7 +488,10 @@ __global__ void lm_begin_kernel(RegBatch B, RegConfig C, uint32_t iteration) {
 }
 
 /* ------------------------------------------------------------------------------------------------ */
-__global__ __launch_bounds__(kSweepThreads) void sweep_kernel(RegBatch B) {
+#ifndef LOAMX_SWEEP_WAVES
+#define LOAMX_SWEEP_WAVES 3  // measured: 2 waves/SIMD (178 VGPRs) 0.31 ms, 3 (166) 0.24 ms, 4 (spills) 0.44 ms
+#endif
+__global__ __launch_bounds__(kSweepThreads, LOAMX_SWEEP_WAVES) void sweep_kernel(RegBatch B) {
   __shared__ double s_part[kSweepThreads / 64][kAccSize];
   const size_t pair = blockIdx.x / B.blocks_per_pair;
   const uint32_t blk = blockIdx.x % B.blocks_per_pair;
@@ -513,29 +516,41 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(RegBatch B) {
     atomicAdd(&B.sweep_slots[0], (unsigned long long)n_se);
     atomicAdd(&B.sweep_slots[1], (unsigned long long)n_sp);
   }
-#pragma unroll 1
-  for (int it = 0; it < kSweepItems; it++) {
-    const uint32_t v = base + it * kSweepThreads + threadIdx.x;
-    if (v >= total) break;
-    if (v < n_se) {
-      const double px = E[v];
-      if (px == px) {
-        double prim[6];
+  // software-pipelined: the record of item it+1 is in flight while item it is evaluated
+  struct Rec {
+    double f[9];
+    int kind;  // 0 none / invalid, 1 edge, 2 plane
+  };
+  auto load_rec = [&](uint32_t v) {
+    Rec R;
+    R.kind = 0;
 #pragma unroll
-        for (int f = 0; f < 6; f++) prim[f] = E[(3 + f) * efield + v];
-        residual_accumulate(false, v3(px, E[efield + v], E[2 * efield + v]), prim, x, acc);
-      }
-    } else {
-      const uint32_t q = v - n_se;
-      const double px = Pl[q];
-      if (px == px) {
-        double prim[6];
+    for (int f = 0; f < 9; f++) R.f[f] = 0.0;
+    if (v < total) {
+      if (v < n_se) {
+        R.kind = 1;
 #pragma unroll
-        for (int f = 0; f < 4; f++) prim[f] = Pl[(3 + f) * pfield + q];
-        prim[4] = prim[5] = 0.0;
-        residual_accumulate(true, v3(px, Pl[pfield + q], Pl[2 * pfield + q]), prim, x, acc);
+        for (int f = 0; f < 9; f++) R.f[f] = E[f * efield + v];
+      } else {
+        const uint32_t q = v - n_se;
+        R.kind = 2;
+#pragma unroll
+        for (int f = 0; f < 7; f++) R.f[f] = Pl[f * pfield + q];
       }
     }
+    return R;
+  };
+  Rec cur = load_rec(base + threadIdx.x);
+#pragma unroll 1
+  for (int it = 0; it < kSweepItems; it++) {
+    const Rec nxt = (it + 1 < kSweepItems) ? load_rec(base + (it + 1) * kSweepThreads + threadIdx.x) : Rec{{0, 0, 0, 0, 0, 0, 0, 0, 0}, 0};
+    if (cur.kind != 0 && cur.f[0] == cur.f[0]) {  // NaN in field 0 marks an invalid slot
+      double prim[6];
+#pragma unroll
+      for (int f = 0; f < 6; f++) prim[f] = cur.f[3 + f];
+      residual_accumulate(cur.kind == 2, v3(cur.f[0], cur.f[1], cur.f[2]), prim, x, acc);
+    }
+    cur = nxt;
   }
   // wavefront shuffle reduction, then LDS across the 4 wavefronts, fixed order => deterministic
 #pragma unroll
