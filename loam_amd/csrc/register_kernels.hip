@@ -43,7 +43,7 @@ template <bool ORDERED>
 __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double* __restrict__ pts_base,
                                                                    const uint32_t* __restrict__ n_pts, size_t stride,
                                                                    uint32_t in_pitch, double max_dist, GridSet gs, GridPoint* __restrict__ scratch) {
-  __shared__ uint32_t s_cells[kGridCellsCap];
+  __shared__ uint32_t s_cells[kGridLdsCells];
   __shared__ double s_red[6][kBuildThreads / 64];
   __shared__ uint32_t s_wave_sum[kBuildThreads / 64];
   __shared__ GridDesc s_g;
@@ -81,54 +81,66 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
   __syncthreads();
   const GridDesc g = s_g;
   const uint32_t ncell = (uint32_t)(g.nx * g.ny * g.nz);
-  for (uint32_t c = tid; c < ncell; c += kBuildThreads) s_cells[c] = 0;
-  __syncthreads();
-  for (uint32_t i = tid; i < n; i += kBuildThreads) {
-    const Vec3 pt = v3(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]);
-    const uint32_t cell = ORDERED ? grid_morton_of_point(g, pt) : grid_cell_of_point(g, pt);
-    atomicAdd(&s_cells[cell], 1u);
-  }
-  __syncthreads();
-  // exclusive scan of s_cells[0..ncell): contiguous chunk per thread + block scan of chunk sums
-  const uint32_t per = (ncell + kBuildThreads - 1) / kBuildThreads;
-  const uint32_t c0 = tid * per, c1 = c0 + per < ncell ? c0 + per : ncell;
-  uint32_t local = 0;
-  for (uint32_t c = c0; c < c1; c++) local += s_cells[c];
-  uint32_t incl = local;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t t = __shfl_up(incl, off);
-    if (lane >= off) incl += t;
-  }
-  if (lane == 63) s_wave_sum[wave] = incl;
-  __syncthreads();
-  uint32_t wave_off = 0;
-  for (int w = 0; w < wave; w++) wave_off += s_wave_sum[w];
-  uint32_t run = wave_off + incl - local;
   uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
-  for (uint32_t c = c0; c < c1; c++) {
-    const uint32_t cnt = s_cells[c];
-    s_cells[c] = run;
-    cs[c] = run;
-    run += cnt;
-  }
-  if (tid == 0) cs[ncell] = n;
-  __syncthreads();
   GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
   // ORDERED: scatter into the scratch copy first, then place every point at (cell begin + number of
   // cell mates with a smaller original index): the final layout does not depend on the order in
   // which the atomics were served, so every later summation order is reproducible run to run.
   GridPoint* __restrict__ dst = ORDERED ? scratch + pair * gs.stride : sp;
-  for (uint32_t i = tid; i < n; i += kBuildThreads) {
-    const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
-    const uint32_t cell = ORDERED ? grid_morton_of_point(g, v3(x, y, z)) : grid_cell_of_point(g, v3(x, y, z));
-    const uint32_t pos = atomicAdd(&s_cells[cell], 1u);
-    dst[pos] = GridPoint{x, y, z, i, 0u};
+  // The LDS table holds kGridLdsCells cells; larger grids are built in passes over cell ranges
+  // (every pass re-reads the points; the running total carries the exclusive scan across passes).
+  uint32_t carry = 0;
+  for (uint32_t c_lo = 0; c_lo < ncell; c_lo += kGridLdsCells) {
+    const uint32_t nc = ncell - c_lo < kGridLdsCells ? ncell - c_lo : kGridLdsCells;
+    for (uint32_t c = tid; c < nc; c += kBuildThreads) s_cells[c] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += kBuildThreads) {
+      const Vec3 pt = v3(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]);
+      const uint32_t cell = (ORDERED ? grid_morton_of_point(g, pt) : grid_cell_of_point(g, pt)) - c_lo;
+      if (cell < nc) atomicAdd(&s_cells[cell], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of s_cells[0..nc): contiguous chunk per thread + block scan of chunk sums
+    const uint32_t per = (nc + kBuildThreads - 1) / kBuildThreads;
+    const uint32_t c0 = tid * per, c1 = c0 + per < nc ? c0 + per : nc;
+    uint32_t local = 0;
+    for (uint32_t c = c0; c < c1; c++) local += s_cells[c];
+    uint32_t incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_wave_sum[wave] = incl;
+    __syncthreads();
+    uint32_t wave_off = carry;
+    for (int w = 0; w < wave; w++) wave_off += s_wave_sum[w];
+    uint32_t pass_total = 0;
+    for (int w = 0; w < kBuildThreads / 64; w++) pass_total += s_wave_sum[w];
+    uint32_t run = wave_off + incl - local;
+    for (uint32_t c = c0; c < c1; c++) {
+      const uint32_t cnt = s_cells[c];
+      s_cells[c] = run;
+      cs[c_lo + c] = run;
+      run += cnt;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += kBuildThreads) {
+      const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+      const uint32_t cell = (ORDERED ? grid_morton_of_point(g, v3(x, y, z)) : grid_cell_of_point(g, v3(x, y, z))) - c_lo;
+      if (cell < nc) {
+        const uint32_t pos = atomicAdd(&s_cells[cell], 1u);
+        dst[pos] = GridPoint{x, y, z, i, 0u};
+      }
+    }
+    carry += pass_total;
+    __syncthreads();
   }
+  if (tid == 0) cs[ncell] = n;
   if (ORDERED) {
-    __syncthreads();  // also makes this workgroup's global writes visible to itself
+    // single pass here (Morton grid = kGridLdsCells cells): after the scatter s_cells[c] holds the
+    // END of cell c; its begin is the end of cell c-1
     __threadfence_block();
-    // after the scatter s_cells[c] holds the END of cell c; its begin is the end of cell c-1
     for (uint32_t p = tid; p < n; p += kBuildThreads) {
       const GridPoint e = dst[p];
       const uint32_t cell = grid_morton_of_point(g, v3(e.x, e.y, e.z));
@@ -165,9 +177,14 @@ constexpr int kAssocThreads = 256;
 // index + points are ~0.5 MB). Placement only affects speed, never results.
 __device__ __forceinline__ bool xcd_pair_map(uint32_t block, uint32_t blocks_per_pair, size_t n_pairs, size_t& pair,
                                              uint32_t& chunk) {
+#ifdef LOAMX_LINEAR_PAIR_MAP
+  pair = block / blocks_per_pair;
+  chunk = block % blocks_per_pair;
+#else
   const uint32_t xcd = block & 7u, slot = block >> 3;
   pair = (size_t)xcd + 8u * (size_t)(slot / blocks_per_pair);
   chunk = slot % blocks_per_pair;
+#endif
   return pair < n_pairs;
 }
 
