@@ -153,6 +153,20 @@ def main():
                         avg_launch_ms=dk["avg_ms"], algorithmic_bytes_per_launch=dk["algorithmic_bytes_per_launch"],
                         share_of_kernel_time=round(dk["total_ms"] / sum(k["total_ms"] for k in kern.values()), 4))
 
+        # HBM traffic per launch of the dominant kernel, from the committed rocprofv3 PMC passes of this
+        # same command (profiles/r01_pmc.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); null if absent
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+            if pmc.get("bench_config", {}).get("pairs_per_gpu") == P:
+                names = [k for k in pmc["kernels"] if k.startswith(dominant.replace("_kernel", ""))]
+                tr = sum(pmc["kernels"][k]["traffic_bytes_per_dispatch"] * pmc["kernels"][k]["dispatches"] for k in names)
+                n_scopes = pmc.get("event_scopes", {}).get(dominant)
+                if names and n_scopes:
+                    roofline["traffic"] = tr / n_scopes
+                    roofline["traffic_source"] = "profiles/r01_pmc.json (rocprofv3 --pmc, separate passes)"
+        except Exception:
+            pass
+
         out = {
             "metric": "scan-pair registrations/sec (64x1024 Ouster)", "value": round(value, 2), "unit": "pairs/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,

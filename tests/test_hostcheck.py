@@ -39,6 +39,25 @@ def test_extraction_bit_exact_on_synthetic(oracle, H, W, seed):
             assert np.array_equal(e, oe) and np.array_equal(p, op)
 
 
+@pytest.mark.parametrize("H,W,seed,sigma", [(16, 1024, 1, 0.01), (8, 256, 3, 0.01), (8, 512, 2, 0.0), (4, 2048, 4, 0.01), (4, 700, 6, 0.01)])
+def test_bitmask_mis_selection_matches_oracle(oracle, H, W, seed, sigma):
+    """Lane-level emulation of select_mis_kernel (64-bit lane masks, local-maxima rounds, cap by
+    priority order) against the oracle's sort + greedy walk, including tied curvatures."""
+    xyz = Hc.synth_scan(seed, 0, 0, H, W, sigma)
+    checked = 0
+    for params in [(3, 6, 10, 50, 100.0, 1.0, 0.5, 1.0), (5, 4, 2, 7, 50.0, 0.5, 0.3, 0.5), (2, 3, 0, 3, 10.0, 2.0, 0.5, 1.0),
+                   (4, 6, 10, 20, 50.0, 0.8, 0.5, 1.0), (3, 1, 1000, 1000, 20.0, 5.0, 0.5, 1.0), (3, 6, 10, 5, 100.0, 1.0, 0.5, 1.0)]:
+        fe = Hc.fe_params(*params)
+        curv, mask = Hc.curvature_valid(xyz, H, W, 1.0, 120.0, fe)
+        r = Hc.select_mis(curv, mask, H, W, fe)
+        if r is None:  # parameters outside the MIS kernel's domain: the general kernel is used
+            continue
+        se, sp, _ = oracle.extract_features(xyz, H, W, 1.0, 120.0, oracle.FeParams(*params), stable=True)
+        assert np.array_equal(r[0], se) and np.array_equal(r[1], sp)
+        checked += 1
+    assert checked >= 4
+
+
 def test_extraction_tie_policy_on_noise_free_scan(oracle):
     # noise-free synthetic scans contain exact curvature ties (SURVEY Q3): the kernels' documented
     # policy is the stable ascending order

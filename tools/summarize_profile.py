@@ -19,7 +19,7 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(\w+_kernel(?:<\w+>)?)", name)
+    m = re.search(r"(\w+_kernel(?:<[\w, ]+>)?)", name)
     return m.group(1) if m else name[:48]
 
 
@@ -81,7 +81,7 @@ def main():
                "|---|---|---|---|---|---|---|"]
         out = {}
         alias = {"curvature_valid_kernel": "curvature_valid_kernel", "sweep_kernel": "sweep_kernel",
-                 "select_kernel<4>": "select_kernel"}
+                 "select_kernel<4>": "select_kernel", "select_mis_kernel<2, 4>": "select_kernel"}
         for k in sorted(pmc):
             f = pmc[k].get("FETCH_SIZE", {"dispatches": 0, "kib_total_reported": 0.0})
             w = pmc[k].get("WRITE_SIZE", {"dispatches": 0, "kib_total_reported": 0.0})
@@ -102,7 +102,9 @@ def main():
             md.append(f"| {k} | {n} | {fetch/1e6:.2f} | {write/1e6:.2f} | {(fetch+write)/1e6:.2f} | "
                       f"{'' if algo is None else f'{algo/1e6:.2f}'} | {'' if ratio is None else f'{ratio:.3f}'} |")
         cfg = bj.get("config", {})
-        json.dump({"source": os.path.basename(src), "bench_config": cfg, "kernels": out}, open(dst + "_pmc.json", "w"), indent=1)
+        scopes = {k: v["launches"] for k, v in kern.items()}  # HIP-event scopes of that run (associate = kNN + fit, edge + plane)
+        json.dump({"source": os.path.basename(src), "bench_config": cfg, "event_scopes": scopes, "kernels": out},
+                  open(dst + "_pmc.json", "w"), indent=1)
     open(dst + "_summary.md", "w").write("\n".join(md) + "\n")
     print("\n".join(md))
 
