@@ -186,7 +186,7 @@ def main():
         # ---- CPU baseline + parity spot check (outside the timed region) -----------------------------
         if n_gpus == 1 and not args.no_cpu_baseline:
             threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))  # the GPU box's CPU share for one GPU is 16 cores
-            n_sample = args.cpu_sample if args.cpu_sample > 0 else min(256, 8 * threads, P)
+            n_sample = args.cpu_sample if args.cpu_sample > 0 else min(256, 16 * threads, P)  # ~13 s of CPU work at 51 ms/pair
             scans = xyz[: n_sample * 2 * N * 3].cpu().numpy().reshape(n_sample * 2, N, 3)
             import oracle_lib as O
             cpu_out, dt = cpu_baseline(scans, n_sample, threads)
