@@ -187,37 +187,28 @@ struct KnnResult {
   int count;
 };
 
+// Branch-free insertion: the list is sorted ascending by (d2, orig) and padded with
+// (DBL_MAX, 0xFFFFFFFF); the newcomer is pushed down a chain of compare-exchanges. `count` is not
+// maintained here (knn_finish counts the non-padding entries).
 template <int KM>
 LOAMX_HD void knn_insert(KnnResult<KM>& r, int k, double d2, uint32_t pos, uint32_t orig) {
-  // find insertion slot: first j with (d2, orig) < (r.d2[j], r.orig[j]) among the filled ones
-  int slot = r.count;
-#pragma unroll
-  for (int j = KM - 1; j >= 0; j--) {
-    if (j < r.count && (d2 < r.d2[j] || (d2 == r.d2[j] && orig < r.orig[j]))) slot = j;
-  }
-  if (slot >= k) return;
-#pragma unroll
-  for (int j = KM - 1; j >= 1; j--) {
-    if (j > slot && j < k) {
-      r.d2[j] = r.d2[j - 1];
-      r.pos[j] = r.pos[j - 1];
-      r.orig[j] = r.orig[j - 1];
-    }
-  }
 #pragma unroll
   for (int j = 0; j < KM; j++) {
-    if (j == slot) {
-      r.d2[j] = d2;
-      r.pos[j] = pos;
-      r.orig[j] = orig;
-    }
+    const bool lt = d2 < r.d2[j] || (d2 == r.d2[j] && orig < r.orig[j]);
+    const double td = r.d2[j];
+    const uint32_t tp = r.pos[j], to = r.orig[j];
+    r.d2[j] = lt ? d2 : td;
+    r.pos[j] = lt ? pos : tp;
+    r.orig[j] = lt ? orig : to;
+    d2 = lt ? td : d2;
+    pos = lt ? tp : pos;
+    orig = lt ? to : orig;
   }
-  if (r.count < k) r.count++;
-  if (r.count == k) {
+  double w = r.d2[KM - 1];
 #pragma unroll
-    for (int j = 0; j < KM; j++)
-      if (j == k - 1) r.worst = r.d2[j];
-  }
+  for (int j = 0; j < KM - 1; j++)
+    if (j == k - 1) w = r.d2[j];
+  r.worst = w;  // DBL_MAX until k points have been seen
 }
 
 // Candidates are fetched four at a time (four independent 32-byte loads in flight per lane).
@@ -376,7 +367,7 @@ LOAMX_HD void knn_rounds(const GridDesc& g, const uint32_t* __restrict__ cell_st
     // unscanned points are farther than (w*h) along some axis; keep a relative safety margin for
     // the rounding in grid_cell_coord
     const double guard = (double)w * g.h * (1.0 - 1e-9);
-    if (r.count == k && r.worst < guard * guard) break;
+    if (r.worst < guard * guard) break;  // k found (worst is DBL_MAX otherwise) and all closer than the unvisited region
     if (max_dist > 0.0 && guard >= max_dist) break;
     if (cx - w <= 0 && cx + w >= g.nx - 1 && cy - w <= 0 && cy + w >= g.ny - 1 && cz - w <= 0 && cz + w >= g.nz - 1) break;
     w++;
@@ -385,11 +376,16 @@ LOAMX_HD void knn_rounds(const GridDesc& g, const uint32_t* __restrict__ cell_st
 
 // strict radius filter of kdtree.cpp:25 (max_dist <= 0 disables it): number of neighbours kept (prefix of r)
 template <int KM>
-LOAMX_HD int knn_finish(const KnnResult<KM>& r, double max_dist) {
-  int kept = 0;
+LOAMX_HD int knn_finish(KnnResult<KM>& r, int k, double max_dist) {
+  int count = 0, kept = 0;
 #pragma unroll
   for (int j = 0; j < KM; j++) {
-    if (j < r.count && kept == j && (max_dist <= 0.0 || sqrt(r.d2[j]) < max_dist)) kept = j + 1;
+    if (j < k && r.orig[j] != 0xFFFFFFFFu) count = j + 1;
+  }
+  r.count = count;
+#pragma unroll
+  for (int j = 0; j < KM; j++) {
+    if (j < count && kept == j && (max_dist <= 0.0 || sqrt(r.d2[j]) < max_dist)) kept = j + 1;
   }
   return kept;
 }
@@ -408,7 +404,7 @@ LOAMX_HD int knn_search(const GridDesc& g, const uint32_t* __restrict__ cell_sta
   // every point is at least (out-1)*h away: nothing can pass the radius filter
   if (max_dist > 0.0 && out >= 1 && (double)(out - 1) * g.h >= max_dist) return 0;
   knn_rounds(g, cell_start, sp, q, k, max_dist, cx, cy, cz, r, out > 1 ? out : 1, true, false);
-  return knn_finish(r, max_dist);
+  return knn_finish(r, k, max_dist);
 }
 
 /* ------------------------------------------------------------------------------------------------

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(kAssocThreads) void associate_knn_lds_kernel(RegBat
       scanned = true;
     }
     knn_rounds(g, cs, sp, p, k, max_dist, cx, cy, cz, r, out > 1 ? out : 1, true, scanned);
-    kept = knn_finish(r, max_dist);
+    kept = knn_finish(r, k, max_dist);
   }
   const size_t field = B.n_pairs * stride, slot = pair * stride + i;
   uint32_t* __restrict__ nn = PLANE ? B.assoc.nn_plane : B.assoc.nn_edge;  // [1 + KM][n_pairs * stride]
