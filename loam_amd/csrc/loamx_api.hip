@@ -260,8 +260,8 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   ENSURE(ctx, WS_GRID_DESC_P, np * sizeof(GridDesc));
   ENSURE(ctx, WS_CELLS_E, np * (size_t)(kGridCellsCap + 1) * sizeof(uint32_t));
   ENSURE(ctx, WS_CELLS_P, np * (size_t)(kGridCellsCap + 1) * sizeof(uint32_t));
-  ENSURE(ctx, WS_SORTED_E, np * es * sizeof(GridPoint));
-  ENSURE(ctx, WS_SORTED_P, np * ps * sizeof(GridPoint));
+  ENSURE(ctx, WS_SORTED_E, np * (es + kGridPad) * sizeof(GridPoint));
+  ENSURE(ctx, WS_SORTED_P, np * (ps + kGridPad) * sizeof(GridPoint));
   ENSURE(ctx, WS_SGRID_DESC_E, np * sizeof(GridDesc));
   ENSURE(ctx, WS_SGRID_DESC_P, np * sizeof(GridDesc));
   ENSURE(ctx, WS_SCELLS_E, np * (size_t)(kGridCellsCap + 1) * sizeof(uint32_t));
@@ -286,8 +286,8 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
     if (fresh) HIP_TRY(ctx, hipMemsetAsync(ctx->ws[WS_COUNTERS].p, 0, 64, ctx->stream));
   }
   if (want_iter_info) ENSURE(ctx, WS_ITERINFO, np * (size_t)(C.max_iterations ? C.max_iterations : 1) * sizeof(loamx_iter_info));
-  B.grid_edge = GridSet{wsp<GridDesc>(ctx, WS_GRID_DESC_E), wsp<uint32_t>(ctx, WS_CELLS_E), wsp<GridPoint>(ctx, WS_SORTED_E), es};
-  B.grid_plane = GridSet{wsp<GridDesc>(ctx, WS_GRID_DESC_P), wsp<uint32_t>(ctx, WS_CELLS_P), wsp<GridPoint>(ctx, WS_SORTED_P), ps};
+  B.grid_edge = GridSet{wsp<GridDesc>(ctx, WS_GRID_DESC_E), wsp<uint32_t>(ctx, WS_CELLS_E), wsp<GridPoint>(ctx, WS_SORTED_E), es + kGridPad};
+  B.grid_plane = GridSet{wsp<GridDesc>(ctx, WS_GRID_DESC_P), wsp<uint32_t>(ctx, WS_CELLS_P), wsp<GridPoint>(ctx, WS_SORTED_P), ps + kGridPad};
   B.src_grid_edge = GridSet{wsp<GridDesc>(ctx, WS_SGRID_DESC_E), wsp<uint32_t>(ctx, WS_SCELLS_E), wsp<GridPoint>(ctx, WS_SSORTED_E), es};
   B.src_grid_plane = GridSet{wsp<GridDesc>(ctx, WS_SGRID_DESC_P), wsp<uint32_t>(ctx, WS_SCELLS_P), wsp<GridPoint>(ctx, WS_SSORTED_P), ps};
   B.sort_scratch = wsp<GridPoint>(ctx, WS_SORT_SCRATCH);

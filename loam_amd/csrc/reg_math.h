@@ -103,6 +103,7 @@ LOAMX_HD uint32_t grid_cell_of_point(const GridDesc& g, Vec3 p) {
 
 constexpr uint32_t kGridLdsCells = 32768;  // cells counted per pass of grid_build_kernel (LDS table)
 constexpr uint32_t kGridCellsCap = 65536;  // cells of one target grid (two build passes)
+constexpr uint32_t kGridPad = 4;           // spare GridPoint entries after every sorted set (unclamped 4-wide candidate loads)
 
 // Chooses the cell edge and grid dimensions for a target set with bounding box [lo, hi].
 // Cell edge: a quarter of the search radius (measured on 64x1024 feature sets: R/4 -> 48 candidates
@@ -215,14 +216,16 @@ LOAMX_HD void knn_insert(KnnResult<KM>& r, int k, double d2, uint32_t pos, uint3
 template <int KM>
 LOAMX_HD void knn_scan_range(KnnResult<KM>& r, int k, Vec3 q, const GridPoint* __restrict__ sp, uint32_t begin, uint32_t end,
                              uint32_t pos_delta) {
+  // The array is allocated with kGridPad spare entries, so the four loads never need clamping;
+  // entries at or beyond `end` belong to the next cell (or are padding) and are masked by `n`.
   for (uint32_t p = begin; p < end; p += 4) {
-    const uint32_t n = end - p < 4u ? end - p : 4u, last = end - 1;
+    const uint32_t n = end - p;
     const GridPoint t0 = sp[p];
-    const GridPoint t1 = sp[p + 1 < last ? p + 1 : last];
-    const GridPoint t2 = sp[p + 2 < last ? p + 2 : last];
-    const GridPoint t3 = sp[p + 3 < last ? p + 3 : last];
+    const GridPoint t1 = sp[p + 1];
+    const GridPoint t2 = sp[p + 2];
+    const GridPoint t3 = sp[p + 3];
 #if defined(LOAMX_KNN_STATS)
-    g_cand += n;
+    g_cand += n < 4u ? n : 4u;
 #endif
     // nanoflann L2_Simple: ((dx^2 + dy^2) + dz^2)
     double dx = q.x - t0.x, dy = q.y - t0.y, dz = q.z - t0.z;
@@ -329,6 +332,10 @@ LOAMX_HD void knn_rounds(const GridDesc& g, const uint32_t* __restrict__ cell_st
         rb[j] = ok ? cell_start[row + xa] : 0u;
         re[j] = ok ? cell_start[row + xb + 1] : 0u;
       }
+      // squared slab distances to the neighbouring rows (the query's own row is at distance 0)
+      double sy2m = slab_dist(q.y, g.oy, g.h, cy - 1), sy2p = slab_dist(q.y, g.oy, g.h, cy + 1);
+      double sz2m = slab_dist(q.z, g.oz, g.h, cz - 1), sz2p = slab_dist(q.z, g.oz, g.h, cz + 1);
+      sy2m *= sy2m, sy2p *= sy2p, sz2m *= sz2m, sz2p *= sz2p;
 #pragma unroll 1
       for (int o = 0; o < 9; o++) {
         const int j = (int)((0x862075314ull >> (4 * o)) & 0xFull);  // 4, 1, 3, 5, 7, 0, 2, 6, 8
@@ -338,9 +345,10 @@ LOAMX_HD void knn_rounds(const GridDesc& g, const uint32_t* __restrict__ cell_st
           if (j == t) b = rb[t], e = re[t];
         }
         if (b >= e) continue;
-        const double sy = slab_dist(q.y, g.oy, g.h, cy + (j % 3) - 1), sz = slab_dist(q.z, g.oz, g.h, cz + (j / 3) - 1);
+        const int jy = j % 3, jz = j / 3;
+        const double sy2 = jy == 0 ? sy2m : (jy == 1 ? 0.0 : sy2p), sz2 = jz == 0 ? sz2m : (jz == 1 ? 0.0 : sz2p);
         const double bound = r.worst < r2 ? r.worst : r2;
-        if (sy * sy + sz * sz > bound) continue;
+        if (sy2 + sz2 > bound) continue;
 #if defined(LOAMX_KNN_STATS)
         g_rows++;
 #endif

@@ -240,7 +240,7 @@ constexpr int kStageRows = 256;
 
 template <bool PLANE, int KM>
 __global__ __launch_bounds__(kAssocThreads) void associate_knn_lds_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
-  __shared__ GridPoint s_pts[kStagePts];
+  __shared__ GridPoint s_pts[kStagePts + kGridPad];
   __shared__ uint32_t s_cs[kStageCells];
   __shared__ uint32_t s_rowb[kStageRows];
   __shared__ uint32_t s_rowoff[kStageRows + 1];

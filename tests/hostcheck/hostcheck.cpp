@@ -230,7 +230,7 @@ static void build_grid(const double* pts, uint32_t n, double max_dist, HostGrid&
   }
   for (uint32_t c = 0; c < ncell; c++) G.cell_start[c + 1] += G.cell_start[c];
   std::vector<uint32_t> cursor(G.cell_start.begin(), G.cell_start.end() - 1);
-  G.sp.resize(n);
+  G.sp.assign((size_t)n + kGridPad, GridPoint{0, 0, 0, 0xFFFFFFFFu, 0});
   // the GPU scatters with atomics and then orders every cell by original index; ascending fill
   // order gives the same layout
   for (uint32_t k = 0; k < n; k++) {
