@@ -213,35 +213,39 @@ LOAMX_HD void knn_insert(KnnResult<KM>& r, int k, double d2, uint32_t pos, uint3
 }
 
 // Candidates are fetched four at a time (four independent 32-byte loads in flight per lane).
+// The array is allocated with kGridPad spare entries, so the four loads never need clamping;
+// entries at or beyond the range end belong to the next cell (or are padding) and are masked by n
+// (= entries left in the range, may exceed 4).
+template <int KM>
+LOAMX_HD void knn_scan_batch(KnnResult<KM>& r, int k, Vec3 q, const GridPoint* __restrict__ sp, uint32_t p, uint32_t n,
+                             uint32_t pos_delta) {
+  const GridPoint t0 = sp[p];
+  const GridPoint t1 = sp[p + 1];
+  const GridPoint t2 = sp[p + 2];
+  const GridPoint t3 = sp[p + 3];
+#if defined(LOAMX_KNN_STATS)
+  g_cand += n < 4u ? n : 4u;
+#endif
+  // nanoflann L2_Simple: ((dx^2 + dy^2) + dz^2)
+  double dx = q.x - t0.x, dy = q.y - t0.y, dz = q.z - t0.z;
+  const double d0 = dx * dx + dy * dy + dz * dz;
+  dx = q.x - t1.x, dy = q.y - t1.y, dz = q.z - t1.z;
+  const double d1 = dx * dx + dy * dy + dz * dz;
+  dx = q.x - t2.x, dy = q.y - t2.y, dz = q.z - t2.z;
+  const double d2 = dx * dx + dy * dy + dz * dz;
+  dx = q.x - t3.x, dy = q.y - t3.y, dz = q.z - t3.z;
+  const double d3 = dx * dx + dy * dy + dz * dz;
+  // (measured: four straight-line insert sites beat one rolled insert loop, 7.3 vs 9.1 ms per launch)
+  if (d0 <= r.worst) knn_insert(r, k, d0, p + pos_delta, t0.orig);
+  if (n > 1 && d1 <= r.worst) knn_insert(r, k, d1, p + 1 + pos_delta, t1.orig);
+  if (n > 2 && d2 <= r.worst) knn_insert(r, k, d2, p + 2 + pos_delta, t2.orig);
+  if (n > 3 && d3 <= r.worst) knn_insert(r, k, d3, p + 3 + pos_delta, t3.orig);
+}
+
 template <int KM>
 LOAMX_HD void knn_scan_range(KnnResult<KM>& r, int k, Vec3 q, const GridPoint* __restrict__ sp, uint32_t begin, uint32_t end,
                              uint32_t pos_delta) {
-  // The array is allocated with kGridPad spare entries, so the four loads never need clamping;
-  // entries at or beyond `end` belong to the next cell (or are padding) and are masked by `n`.
-  for (uint32_t p = begin; p < end; p += 4) {
-    const uint32_t n = end - p;
-    const GridPoint t0 = sp[p];
-    const GridPoint t1 = sp[p + 1];
-    const GridPoint t2 = sp[p + 2];
-    const GridPoint t3 = sp[p + 3];
-#if defined(LOAMX_KNN_STATS)
-    g_cand += n < 4u ? n : 4u;
-#endif
-    // nanoflann L2_Simple: ((dx^2 + dy^2) + dz^2)
-    double dx = q.x - t0.x, dy = q.y - t0.y, dz = q.z - t0.z;
-    const double d0 = dx * dx + dy * dy + dz * dz;
-    dx = q.x - t1.x, dy = q.y - t1.y, dz = q.z - t1.z;
-    const double d1 = dx * dx + dy * dy + dz * dz;
-    dx = q.x - t2.x, dy = q.y - t2.y, dz = q.z - t2.z;
-    const double d2 = dx * dx + dy * dy + dz * dz;
-    dx = q.x - t3.x, dy = q.y - t3.y, dz = q.z - t3.z;
-    const double d3 = dx * dx + dy * dy + dz * dz;
-    // (measured: four straight-line insert sites beat one rolled insert loop, 7.3 vs 9.1 ms per launch)
-    if (d0 <= r.worst) knn_insert(r, k, d0, p + pos_delta, t0.orig);
-    if (n > 1 && d1 <= r.worst) knn_insert(r, k, d1, p + 1 + pos_delta, t1.orig);
-    if (n > 2 && d2 <= r.worst) knn_insert(r, k, d2, p + 2 + pos_delta, t2.orig);
-    if (n > 3 && d3 <= r.worst) knn_insert(r, k, d3, p + 3 + pos_delta, t3.orig);
-  }
+  for (uint32_t p = begin; p < end; p += 4) knn_scan_batch(r, k, q, sp, p, end - p, pos_delta);
 }
 
 // distance from coordinate v to the slab of cell index c along one axis, shrunk by a safety margin
@@ -311,17 +315,19 @@ LOAMX_HD double knn_radius_bound(double max_dist) { return max_dist > 0.0 ? max_
 template <int KM>
 LOAMX_HD void knn_rounds(const GridDesc& g, const uint32_t* __restrict__ cell_start, const GridPoint* __restrict__ sp, Vec3 q,
                          int k, double max_dist, int32_t cx, int32_t cy, int32_t cz, KnnResult<KM>& r, int32_t w, bool first,
-                         bool scanned) {
+                         bool scanned, uint32_t* row_scratch, int row_stride) {
   const double r2 = knn_radius_bound(max_dist);
   for (;;) {
     if (scanned) {
       scanned = false;
     } else if (first && w == 1) {
-      // Common case. The cell_start entries of all nine rows of the 3x3x3 block are fetched up
-      // front (18 independent loads instead of nine dependent round trips); the rows are then
-      // walked centre first, then faces, then corners, each row skipped if its slab is already
-      // farther than the current bound. The row loop is kept rolled (one copy of the candidate
-      // loop) to hold the register count down.
+      // Common case: the 3x3x3 block. The cell_start entries of its nine rows are fetched up front
+      // (18 independent loads instead of nine dependent round trips). The non-empty rows are written
+      // to a small per-thread list (LDS in the kernels) in the order centre, faces, corners, and the
+      // lane then walks ONE flattened stream of 4-wide candidate batches over that list, skipping a
+      // row when its slab is already farther than the current bound. Flattening matters on the GPU:
+      // a wavefront then runs for max_lanes(sum of batches) instead of sum_rows(max_lanes(batches))
+      // (measured on the 64x1024 workload: 20.4 vs 37.0 batch steps per wavefront).
       uint32_t rb[9], re[9];
       const int32_t xa = cx - 1 < 0 ? 0 : cx - 1, xb = cx + 1 > g.nx - 1 ? g.nx - 1 : cx + 1;
 #pragma unroll
@@ -332,27 +338,40 @@ LOAMX_HD void knn_rounds(const GridDesc& g, const uint32_t* __restrict__ cell_st
         rb[j] = ok ? cell_start[row + xa] : 0u;
         re[j] = ok ? cell_start[row + xb + 1] : 0u;
       }
+      int nrow = 0;
+#pragma unroll
+      for (int o = 0; o < 9; o++) {
+        constexpr int kOrder[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
+        const int j = kOrder[o];
+        if (rb[j] < re[j]) {
+          row_scratch[(2 * nrow) * row_stride] = rb[j] | ((uint32_t)j << 28);  // set sizes stay below 2^28
+          row_scratch[(2 * nrow + 1) * row_stride] = re[j];
+          nrow++;
+        }
+      }
       // squared slab distances to the neighbouring rows (the query's own row is at distance 0)
       double sy2m = slab_dist(q.y, g.oy, g.h, cy - 1), sy2p = slab_dist(q.y, g.oy, g.h, cy + 1);
       double sz2m = slab_dist(q.z, g.oz, g.h, cz - 1), sz2p = slab_dist(q.z, g.oz, g.h, cz + 1);
       sy2m *= sy2m, sy2p *= sy2p, sz2m *= sz2m, sz2p *= sz2p;
-#pragma unroll 1
-      for (int o = 0; o < 9; o++) {
-        const int j = (int)((0x862075314ull >> (4 * o)) & 0xFull);  // 4, 1, 3, 5, 7, 0, 2, 6, 8
-        uint32_t b = rb[0], e = re[0];
-#pragma unroll
-        for (int t = 1; t < 9; t++) {
-          if (j == t) b = rb[t], e = re[t];
-        }
-        if (b >= e) continue;
-        const int jy = j % 3, jz = j / 3;
-        const double sy2 = jy == 0 ? sy2m : (jy == 1 ? 0.0 : sy2p), sz2 = jz == 0 ? sz2m : (jz == 1 ? 0.0 : sz2p);
-        const double bound = r.worst < r2 ? r.worst : r2;
-        if (sy2 + sz2 > bound) continue;
+      uint32_t p = 0, e = 0;
+      int ri = 0;
+      for (;;) {
+        while (p >= e && ri < nrow) {  // next admissible row
+          const uint32_t bj = row_scratch[(2 * ri) * row_stride], e2 = row_scratch[(2 * ri + 1) * row_stride];
+          ri++;
+          const int j = (int)(bj >> 28), jy = j % 3, jz = j / 3;
+          const double sy2 = jy == 0 ? sy2m : (jy == 1 ? 0.0 : sy2p), sz2 = jz == 0 ? sz2m : (jz == 1 ? 0.0 : sz2p);
+          const double bound = r.worst < r2 ? r.worst : r2;
+          if (sy2 + sz2 <= bound) {
 #if defined(LOAMX_KNN_STATS)
-        g_rows++;
+            g_rows++;
 #endif
-        knn_scan_range(r, k, q, sp, b, e, 0u);
+            p = bj & 0x0FFFFFFFu, e = e2;
+          }
+        }
+        if (p >= e) break;
+        knn_scan_batch(r, k, q, sp, p, e - p, 0u);
+        p += 4;
       }
     } else {
       // general round: cells at Chebyshev distance <= w (first round) or == w (later rounds)
@@ -402,7 +421,7 @@ LOAMX_HD int knn_finish(KnnResult<KM>& r, int k, double max_dist) {
 // Returns the number of neighbours kept (prefix of r).
 template <int KM>
 LOAMX_HD int knn_search(const GridDesc& g, const uint32_t* __restrict__ cell_start, const GridPoint* __restrict__ sp,
-                        Vec3 q, int k, double max_dist, KnnResult<KM>& r) {
+                        Vec3 q, int k, double max_dist, KnnResult<KM>& r, uint32_t* row_scratch, int row_stride) {
   knn_init(r);
   if (g.n_points == 0 || k <= 0) return 0;
   const int32_t cx = grid_cell_coord(q.x, g.ox, g.inv_h);
@@ -411,7 +430,7 @@ LOAMX_HD int knn_search(const GridDesc& g, const uint32_t* __restrict__ cell_sta
   const int32_t out = grid_outside_distance(g, cx, cy, cz);
   // every point is at least (out-1)*h away: nothing can pass the radius filter
   if (max_dist > 0.0 && out >= 1 && (double)(out - 1) * g.h >= max_dist) return 0;
-  knn_rounds(g, cell_start, sp, q, k, max_dist, cx, cy, cz, r, out > 1 ? out : 1, true, false);
+  knn_rounds(g, cell_start, sp, q, k, max_dist, cx, cy, cz, r, out > 1 ? out : 1, true, false, row_scratch, row_stride);
   return knn_finish(r, k, max_dist);
 }
 

@@ -217,8 +217,10 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_kn
   const GridDesc g = gs.desc[pair];
   const uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
   const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
+  __shared__ uint32_t s_rows[18 * kAssocThreads];  // per-thread list of non-empty rows, [word][thread] (conflict free)
   KnnResult<KM> r;
-  const int kept = knn_search(g, cs, sp, p, PLANE ? C.k_plane : C.k_edge, PLANE ? C.r_plane : C.r_edge, r);
+  const int kept = knn_search(g, cs, sp, p, PLANE ? C.k_plane : C.k_edge, PLANE ? C.r_plane : C.r_edge, r,
+                              s_rows + threadIdx.x, kAssocThreads);
   const size_t field = B.n_pairs * stride, slot = pair * stride + i;
   uint32_t* __restrict__ nn = PLANE ? B.assoc.nn_plane : B.assoc.nn_edge;  // [1 + KM][n_pairs * stride]
   nn[slot] = (uint32_t)kept;
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(kAssocThreads) void associate_knn_lds_kernel(RegBat
   __shared__ uint32_t s_rowoff[kStageRows + 1];
   __shared__ int32_t s_red[6][kAssocThreads / 64];
   __shared__ int32_t s_box[6];
-  __shared__ uint32_t s_scan[kAssocThreads];
+  __shared__ uint32_t s_scan[18 * kAssocThreads];  // block scan scratch, later the per-thread row list
   __shared__ int32_t s_mode;  // 0 = global path, 1 = staged
   size_t pair;
   uint32_t chunk;
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(kAssocThreads) void associate_knn_lds_kernel(RegBat
       }
       scanned = true;
     }
-    knn_rounds(g, cs, sp, p, k, max_dist, cx, cy, cz, r, out > 1 ? out : 1, true, scanned);
+    knn_rounds(g, cs, sp, p, k, max_dist, cx, cy, cz, r, out > 1 ? out : 1, true, scanned, s_scan + tid, kAssocThreads);
     kept = knn_finish(r, k, max_dist);
   }
   const size_t field = B.n_pairs * stride, slot = pair * stride + i;

@@ -243,13 +243,15 @@ uint64_t hostcheck_knn(const double* pts, uint64_t n, const double q[3], uint64_
   HostGrid G;
   build_grid(pts, (uint32_t)n, max_dist, G);
   if (k <= 5) {  // the kernels are instantiated for KM = 5 (default parameters) and KM = 8
+    uint32_t rows[18];
     KnnResult<5> r;
-    const int kept = knn_search(G.g, G.cell_start.data(), G.sp.data(), v3(q[0], q[1], q[2]), (int)k, max_dist, r);
+    const int kept = knn_search(G.g, G.cell_start.data(), G.sp.data(), v3(q[0], q[1], q[2]), (int)k, max_dist, r, rows, 1);
     for (int j = 0; j < kept; j++) idx_out[j] = r.orig[j];
     return (uint64_t)kept;
   }
+  uint32_t rows[18];
   KnnResult<8> r;
-  const int kept = knn_search(G.g, G.cell_start.data(), G.sp.data(), v3(q[0], q[1], q[2]), (int)k, max_dist, r);
+  const int kept = knn_search(G.g, G.cell_start.data(), G.sp.data(), v3(q[0], q[1], q[2]), (int)k, max_dist, r, rows, 1);
   for (int j = 0; j < kept; j++) idx_out[j] = r.orig[j];
   return (uint64_t)kept;
 }
@@ -292,8 +294,9 @@ static uint32_t associate_t(const double* src, uint32_t n_src, const double* tgt
     Slot& s = slots[i];
     s.valid = false;
     s.p = pose_act(est, v3(src[3 * i], src[3 * i + 1], src[3 * i + 2]));
+    uint32_t rows[18];
     KnnResult<KM> r;
-    const int kept = knn_search(G.g, G.cell_start.data(), G.sp.data(), s.p, k, maxd, r);
+    const int kept = knn_search(G.g, G.cell_start.data(), G.sp.data(), s.p, k, maxd, r, rows, 1);
     if (kept < minfit) continue;
     Vec3 nb[KM];
     for (int j = 0; j < KM; j++)
