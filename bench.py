@@ -158,12 +158,12 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
             if pmc.get("bench_config", {}).get("pairs_per_gpu") == P:
+                # an event scope holds one dispatch of every kernel of that family (e.g. associate = kNN + fit,
+                # edge + plane): traffic per scope = sum of the per-dispatch averages
                 names = [k for k in pmc["kernels"] if k.startswith(dominant.replace("_kernel", ""))]
-                tr = sum(pmc["kernels"][k]["traffic_bytes_per_dispatch"] * pmc["kernels"][k]["dispatches"] for k in names)
-                n_scopes = pmc.get("event_scopes", {}).get(dominant)
-                if names and n_scopes:
-                    roofline["traffic"] = tr / n_scopes
-                    roofline["traffic_source"] = "profiles/r01_pmc.json (rocprofv3 --pmc, separate passes)"
+                if names:
+                    roofline["traffic"] = sum(pmc["kernels"][k]["traffic_bytes_per_dispatch"] for k in names)
+                    roofline["traffic_source"] = "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
         except Exception:
             pass
 
