@@ -105,3 +105,29 @@ def test_run_to_run_determinism():
     a = ctx().register_features(src_e, src_p, e, p)[0]
     b = ctx().register_features(src_e, src_p, e, p)[0]
     assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+def test_scan_to_map_registration(oracle):
+    """BASELINE config 5 in small: a 128x2048 scan registered against a local map accumulated from
+    several scans (the target is a map, not a scan: reference registration.h:2)."""
+    H, W = 128, 2048
+    src = capi.synth_scan_host(99, 0, 1, H, W, 0.01)
+    lidar = capi.LidarParams(H, W, 1.0, 120.0)
+    e, p = ctx().extract_features(src, lidar)
+    oe, op = oracle.extract_features(src, H, W, 1.0, 120.0)
+    assert np.array_equal(e, oe) and np.array_equal(p, op)
+    maps_e, maps_p = [], []
+    for k in range(3):
+        s = capi.synth_scan_host(1000 + k, 0, 0, H, W, 0.01)
+        me, mp_ = oracle.extract_features(s, H, W, 1.0, 120.0)
+        maps_e.append(s[me])
+        maps_p.append(s[mp_])
+    map_e, map_p = np.concatenate(maps_e), np.concatenate(maps_p)
+    assert len(map_p) > 100_000
+    pg, tg, ig = ctx().register_features(src[e], src[p], map_e, map_p)
+    po, to, io = oracle.register_features(src[oe], src[op], map_e, map_p)
+    assert (tg, ig) == (to, io)
+    rot, trans = pose_diff(oracle, po, pg)
+    assert rot < SE3_TOL and trans < SE3_TOL, (rot, trans)
+    rot, trans = pose_diff(oracle, capi.synth_pair_pose(99, 0), pg)
+    assert rot < 1e-2 and trans < 3e-2
