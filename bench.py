@@ -79,14 +79,23 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # LOAMX_BENCH_SHARE_GPU=1 + LOAMX_BENCH_BACKEND=gloo: rehearsal of the N>1 code path on a box with
+    # one GPU (all ranks on device 0, result records gathered through host memory). Never used by
+    # the real multi-GPU run, which is one rank per GPU over RCCL.
+    share_gpu = os.environ.get("LOAMX_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("LOAMX_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
     n_gpus = world if world > 1 else 1
 
     from loam_amd import capi
-    ctx = capi.Context(local_rank)
+    ctx = capi.Context(dev_index)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     lidar = capi.LidarParams(H, W, 1.0, 120.0)  # reference README.md:45
     fe, reg = capi.FeatureExtractionParams(), capi.RegistrationParams()
@@ -103,7 +112,7 @@ def main():
     def step():
         ctx.register_scan_pairs_dev(xyz.data_ptr(), P, lidar, fe, reg, results.data_ptr())
         if world > 1:  # the only collective: gather of 64-byte result records (RCCL over xGMI)
-            D.gather_results(results, world * P)
+            D.gather_results(results if backend == "nccl" else results.cpu(), world * P)
 
     def barrier():
         if world > 1:
@@ -124,7 +133,7 @@ def main():
     stats = ctx.kernel_stats()
     ctx.enable_kernel_timing(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
