@@ -21,10 +21,14 @@ namespace {
 #define LOAMX_CURV_TILE 512  // measured on 2048 scans of 64x1024: 1024 -> 1.75 ms (31 % of 8 TB/s), 512 -> 1.22 ms (46 %), 256 -> 1.38 ms
 #endif
 constexpr int kTile = LOAMX_CURV_TILE;
+#ifndef LOAMX_CURV_THREADS
+#define LOAMX_CURV_THREADS 256
+#endif
+constexpr int kCurvThreads = LOAMX_CURV_THREADS;
 constexpr int kHaloMax = kMaxNeighborPoints + 1;
 constexpr int kLocalMax = kTile + 2 * kHaloMax;
 
-__global__ __launch_bounds__(256) void curvature_valid_kernel(const double* __restrict__ xyz, ExtractParams P,
+__global__ __launch_bounds__(kCurvThreads) void curvature_valid_kernel(const double* __restrict__ xyz, ExtractParams P,
                                                               double* __restrict__ curv_out,
                                                               uint8_t* __restrict__ mask_out) {
   __shared__ double s_xyz[kLocalMax * 3];
@@ -42,9 +46,9 @@ __global__ __launch_bounds__(256) void curvature_valid_kernel(const double* __re
 
   // coalesced copy of the tile (+halo) of ring-ordered points into LDS
   const int nd = (hi - lo) * 3;
-  for (int k = tid; k < nd; k += 256) s_xyz[(lo - base) * 3 + k] = g[(size_t)lo * 3 + k];
+  for (int k = tid; k < nd; k += kCurvThreads) s_xyz[(lo - base) * 3 + k] = g[(size_t)lo * 3 + k];
   __syncthreads();
-  for (int c = lo + tid; c < hi; c += 256) {
+  for (int c = lo + tid; c < hi; c += kCurvThreads) {
     const int li = c - base;
     s_r[li] = point_range(s_xyz[3 * li], s_xyz[3 * li + 1], s_xyz[3 * li + 2]);
   }
@@ -52,14 +56,14 @@ __global__ __launch_bounds__(256) void curvature_valid_kernel(const double* __re
   {
     const int clo = t0 - np > 0 ? t0 - np : 0;
     const int chi = t0 + kTile + np < W ? t0 + kTile + np : W;
-    for (int c = clo + tid; c < chi; c += 256) {
+    for (int c = clo + tid; c < chi; c += kCurvThreads) {
       const int li = c - base;
       s_code[li] = is_line_end((uint32_t)c, P.W, P.np) ? (uint8_t)kCodeNone
                                                          : point_code(s_r[li - 1], s_r[li], s_r[li + 1], P);
     }
   }
   __syncthreads();
-  for (int k = tid; k < kTile; k += 256) {
+  for (int k = tid; k < kTile; k += kCurvThreads) {
     const int c = t0 + k;
     if (c >= W) break;
     const int li = c - base;
@@ -377,7 +381,7 @@ void launch_curvature_valid(const double* d_xyz, size_t n_scans, const ExtractPa
   const size_t n_lines = n_scans * P.H;
   if (n_lines == 0 || P.W == 0) return;
   const dim3 grid((unsigned)n_lines, (P.W + kTile - 1) / kTile);
-  hipLaunchKernelGGL(curvature_valid_kernel, grid, dim3(256), 0, s, d_xyz, P, d_curv, d_mask);
+  hipLaunchKernelGGL(curvature_valid_kernel, grid, dim3(kCurvThreads), 0, s, d_xyz, P, d_curv, d_mask);
 }
 
 
