@@ -103,4 +103,43 @@ Pose3d registerFeatures(const LoamFeatures<PointType, Alloc>& source, const Loam
   return Pose3d::fromArray(result.pose);
 }
 
+
+/** @brief Extension (not in the reference): the spatial index of a target feature set built once and
+ * kept on the device, for scan-to-map registration against a slowly changing local map. The
+ * reference rebuilds both KD-trees on every call (registration-inl.h:20-23). */
+class TargetIndex {
+ public:
+  template <template <typename> class Accessor = FieldAccessor, typename PointType, template <typename> class Alloc>
+  static TargetIndex build(const LoamFeatures<PointType, Alloc>& target, const RegistrationParams& params = RegistrationParams()) {
+    loamx_ctx* ctx = gpu::defaultContext();
+    const std::vector<double> te = gpu::pack<Accessor>(target.edge_points), tp = gpu::pack<Accessor>(target.planar_points);
+    const loamx_reg_params rp = gpu::toC(params);
+    loamx_target_index* h = nullptr;
+    gpu::check(ctx, loamx_target_index_create(ctx, te.data(), target.edge_points.size(), tp.data(),
+                                              target.planar_points.size(), &rp, &h));
+    return TargetIndex(h);
+  }
+  const loamx_target_index* handle() const { return handle_.get(); }
+
+ private:
+  explicit TargetIndex(loamx_target_index* h)
+      : handle_(h, [](loamx_target_index* p) { loamx_target_index_destroy(gpu::defaultContext(), p); }) {}
+  std::shared_ptr<loamx_target_index> handle_;
+};
+
+/// registerFeatures against a prebuilt TargetIndex (params must carry the neighbour radii the index was built with)
+template <template <typename> class Accessor = FieldAccessor, typename PointType, template <typename> class Alloc>
+Pose3d registerFeatures(const LoamFeatures<PointType, Alloc>& source, const TargetIndex& target,
+                        const Pose3d& target_T_source_init, const RegistrationParams& params = RegistrationParams()) {
+  loamx_ctx* ctx = gpu::defaultContext();
+  const std::vector<double> se = gpu::pack<Accessor>(source.edge_points), sp = gpu::pack<Accessor>(source.planar_points);
+  const loamx_reg_params rp = gpu::toC(params);
+  double init[7];
+  target_T_source_init.toArray(init);
+  loamx_reg_result result{};
+  gpu::check(ctx, loamx_register_features_indexed(ctx, target.handle(), se.data(), source.edge_points.size(), sp.data(),
+                                                  source.planar_points.size(), init, &rp, &result, nullptr));
+  return Pose3d::fromArray(result.pose);
+}
+
 }  // namespace loam

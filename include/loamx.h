@@ -141,6 +141,21 @@ int loamx_register_features(loamx_ctx* ctx, const double* src_edge, size_t n_src
                             const double* tgt_planar, size_t n_tgt_planar, const double init_pose[7],
                             const loamx_reg_params* reg, loamx_reg_result* result, loamx_reg_detail* detail);
 
+/* ---- persistent target index (scan-to-map; the reference rebuilds both KD-trees on every
+ * call, registration-inl.h:20-23). Build the spatial index of a target feature set (e.g. a local map)
+ * once, keep it resident on the device and register any number of source scans against it.
+ * The index depends on max_edge_neighbor_dist / max_plane_neighbor_dist of `reg` (cell size);
+ * loamx_register_features_indexed fails with LOAMX_ERR_BAD_PARAM if they differ. */
+typedef struct loamx_target_index loamx_target_index;
+int loamx_target_index_create(loamx_ctx* ctx, const double* tgt_edge, size_t n_tgt_edge, const double* tgt_planar,
+                              size_t n_tgt_planar, const loamx_reg_params* reg, loamx_target_index** out);
+void loamx_target_index_destroy(loamx_ctx* ctx, loamx_target_index* index);
+/* same contract as loamx_register_features, target taken from the index */
+int loamx_register_features_indexed(loamx_ctx* ctx, const loamx_target_index* index, const double* src_edge,
+                                    size_t n_src_edge, const double* src_planar, size_t n_src_planar,
+                                    const double init_pose[7], const loamx_reg_params* reg, loamx_reg_result* result,
+                                    loamx_reg_detail* detail);
+
 /* ---- device-resident batch entry points (asynchronous on the context stream) ------------------ */
 
 /* Feature buffers of scan s live at base + s * stride with

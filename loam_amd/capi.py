@@ -75,6 +75,7 @@ EXPORTS = [
     "loamx_default_fe_params", "loamx_default_reg_params", "loamx_status_string", "loamx_last_error",
     "loamx_ctx_create", "loamx_ctx_destroy", "loamx_ctx_set_stream", "loamx_ctx_synchronize",
     "loamx_compute_curvature", "loamx_compute_valid_points", "loamx_extract_features", "loamx_register_features",
+    "loamx_target_index_create", "loamx_target_index_destroy", "loamx_register_features_indexed",
     "loamx_edge_capacity", "loamx_planar_capacity", "loamx_extract_features_batch_dev",
     "loamx_register_features_batch_dev", "loamx_register_scan_pairs_dev", "loamx_ctx_enable_kernel_timing",
     "loamx_ctx_reset_kernel_stats", "loamx_ctx_get_kernel_stats", "loamx_kernel_name", "loamx_synth_pair_pose",
@@ -116,6 +117,11 @@ def load(build_if_missing=True):
     lib.loamx_register_features.argtypes = [vp, dp, C.c_size_t, dp, C.c_size_t, dp, C.c_size_t, dp, C.c_size_t, dp,
                                             C.POINTER(RegistrationParams), C.POINTER(RegResult),
                                             C.POINTER(RegDetail)]
+    lib.loamx_target_index_create.argtypes = [vp, dp, C.c_size_t, dp, C.c_size_t, C.POINTER(RegistrationParams), C.POINTER(vp)]
+    lib.loamx_target_index_destroy.argtypes = [vp, vp]
+    lib.loamx_target_index_destroy.restype = None
+    lib.loamx_register_features_indexed.argtypes = [vp, vp, dp, C.c_size_t, dp, C.c_size_t, dp, C.POINTER(RegistrationParams),
+                                                    C.POINTER(RegResult), C.POINTER(RegDetail)]
     lib.loamx_edge_capacity.restype = C.c_size_t
     lib.loamx_edge_capacity.argtypes = [C.POINTER(LidarParams), C.POINTER(FeatureExtractionParams)]
     lib.loamx_planar_capacity.restype = C.c_size_t
@@ -298,6 +304,26 @@ class Context:
                                  for i in range(detail.n_iter_info)])
             return pose, res.termination, res.iterations, d
         return pose, res.termination, res.iterations
+
+    # ---- persistent target index (scan-to-map) -----------------------------------------------------------
+    def target_index(self, tgt_edge, tgt_planar, reg=None):
+        reg = reg or RegistrationParams()
+        te, tp = _pts(tgt_edge), _pts(tgt_planar)
+        h = C.c_void_p()
+        self._check(self.lib.loamx_target_index_create(self.h, _dp(te), len(te), _dp(tp), len(tp), C.byref(reg), C.byref(h)))
+        return h
+
+    def target_index_destroy(self, index):
+        self.lib.loamx_target_index_destroy(self.h, index)
+
+    def register_features_indexed(self, index, src_edge, src_planar, init_pose=None, reg=None):
+        reg = reg or RegistrationParams()
+        se, sp = _pts(src_edge), _pts(src_planar)
+        init = np.ascontiguousarray([0, 0, 0, 1, 0, 0, 0] if init_pose is None else init_pose, dtype=np.float64)
+        res = RegResult()
+        self._check(self.lib.loamx_register_features_indexed(self.h, index, _dp(se), len(se), _dp(sp), len(sp), _dp(init),
+                                                             C.byref(reg), C.byref(res), None))
+        return np.array(list(res.pose)), res.termination, res.iterations
 
     # ---- device-resident batch entry points (raw device pointers as ints) -----------------------------
     def edge_capacity(self, lidar, fe):

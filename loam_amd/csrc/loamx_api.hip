@@ -53,6 +53,14 @@ struct loamx_ctx {
   std::mutex mu;
 };
 
+struct loamx_target_index {
+  GridDesc* desc[2] = {nullptr, nullptr};       // [edge, plane], one GridDesc each
+  uint32_t* cells[2] = {nullptr, nullptr};      // kGridCellsCap + 1 entries each
+  GridPoint* sorted[2] = {nullptr, nullptr};    // n + kGridPad entries each
+  size_t n[2] = {0, 0};
+  double radius[2] = {0, 0};
+};
+
 namespace {
 
 const char* kKernelNames[LOAMX_K_COUNT] = {"curvature_valid_kernel", "select_kernel", "compact_kernel",
@@ -246,7 +254,7 @@ struct RegInputs {
 typedef int (*AfterAssocHook)(loamx_ctx*, const RegBatch&, uint32_t it, void* user);
 
 int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_reg_result* d_results, bool want_iter_info,
-                 AfterAssocHook hook, void* hook_user) {
+                 AfterAssocHook hook, void* hook_user, const loamx_target_index* prebuilt = nullptr) {
   if (in.n_pairs == 0) return LOAMX_OK;
   if (in.n_pairs > 0x7FFFFFFFull / 128) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "too many pairs in one call");
   const size_t np = in.n_pairs, es = in.edge_stride ? in.edge_stride : 1, ps = in.planar_stride ? in.planar_stride : 1;
@@ -304,9 +312,14 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   B.use_lds_knn = getenv("LOAMX_KNN_LDS") ? 1u : 0u;  // off by default: measured slower than the global-memory kernel
   hipStream_t s = ctx->stream;
 
+  if (prebuilt) {  // persistent target index: only the source sets are (re)ordered
+    B.grid_edge = GridSet{prebuilt->desc[0], prebuilt->cells[0], prebuilt->sorted[0], prebuilt->n[0] + kGridPad};
+    B.grid_plane = GridSet{prebuilt->desc[1], prebuilt->cells[1], prebuilt->sorted[1], prebuilt->n[1] + kGridPad};
+  }
   {
     TimedScope t(ctx, LOAMX_K_GRID, 0.0);
-    launch_grid_build(B, C, s);
+    if (!prebuilt) launch_grid_build_targets(B, C, s);
+    launch_grid_build_sources(B, C, s);
   }
   CHECK_LAUNCH(ctx, "grid_build_kernel");
   launch_state_init(B, C, s);
@@ -570,10 +583,10 @@ int detail_hook(loamx_ctx* ctx, const RegBatch& B, uint32_t it, void* user) {
 }
 }  // namespace
 
-int loamx_register_features(loamx_ctx* ctx, const double* src_edge, size_t n_se, const double* src_planar, size_t n_sp,
-                            const double* tgt_edge, size_t n_te, const double* tgt_planar, size_t n_tp,
-                            const double init_pose[7], const loamx_reg_params* reg, loamx_reg_result* result,
-                            loamx_reg_detail* detail) {
+static int register_features_impl(loamx_ctx* ctx, const loamx_target_index* index, const double* src_edge, size_t n_se,
+                                  const double* src_planar, size_t n_sp, const double* tgt_edge, size_t n_te,
+                                  const double* tgt_planar, size_t n_tp, const double init_pose[7],
+                                  const loamx_reg_params* reg, loamx_reg_result* result, loamx_reg_detail* detail) {
   if (!ctx) return LOAMX_ERR_BAD_PARAM;
   std::lock_guard<std::mutex> lock(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -581,6 +594,11 @@ int loamx_register_features(loamx_ctx* ctx, const double* src_edge, size_t n_se,
   RegConfig C;
   int rc = make_reg_config(ctx, reg, C);
   if (rc != LOAMX_OK) return rc;
+  if (index) {
+    if (index->radius[0] != C.r_edge || index->radius[1] != C.r_plane)
+      return fail(ctx, LOAMX_ERR_BAD_PARAM, "registration params do not match the ones the target index was built with");
+    n_te = 0, n_tp = 0;  // the target lives in the index
+  }
   const size_t es = n_se > n_te ? n_se : n_te, ps = n_sp > n_tp ? n_sp : n_tp;
   if (es > 0x7FFFFFFFull || ps > 0x7FFFFFFFull) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "feature set too large");
   hipStream_t s = ctx->stream;
@@ -610,7 +628,7 @@ int loamx_register_features(loamx_ctx* ctx, const double* src_edge, size_t n_se,
   DetailHook hook{detail, n_se, n_sp};
   if (detail) detail->n_iter_info = 0;
   rc = register_dev(ctx, in, C, wsp<loamx_reg_result>(ctx, WS_RESULTS), detail && detail->iter_info,
-                    detail ? detail_hook : nullptr, &hook);
+                    detail ? detail_hook : nullptr, &hook, index);
   if (rc != LOAMX_OK) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(result, ctx->ws[WS_RESULTS].p, sizeof(loamx_reg_result), hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -619,6 +637,97 @@ int loamx_register_features(loamx_ctx* ctx, const double* src_edge, size_t n_se,
                            hipMemcpyDeviceToHost));
     detail->n_iter_info = result->iterations;
   }
+  return LOAMX_OK;
+}
+
+int loamx_register_features(loamx_ctx* ctx, const double* src_edge, size_t n_se, const double* src_planar, size_t n_sp,
+                            const double* tgt_edge, size_t n_te, const double* tgt_planar, size_t n_tp,
+                            const double init_pose[7], const loamx_reg_params* reg, loamx_reg_result* result,
+                            loamx_reg_detail* detail) {
+  return register_features_impl(ctx, nullptr, src_edge, n_se, src_planar, n_sp, tgt_edge, n_te, tgt_planar, n_tp, init_pose,
+                                reg, result, detail);
+}
+
+int loamx_register_features_indexed(loamx_ctx* ctx, const loamx_target_index* index, const double* src_edge, size_t n_se,
+                                    const double* src_planar, size_t n_sp, const double init_pose[7],
+                                    const loamx_reg_params* reg, loamx_reg_result* result, loamx_reg_detail* detail) {
+  if (!index) return LOAMX_ERR_BAD_PARAM;
+  return register_features_impl(ctx, index, src_edge, n_se, src_planar, n_sp, nullptr, 0, nullptr, 0, init_pose, reg, result,
+                                detail);
+}
+
+/* ---- persistent target index ---------------------------------------------------------------------------- */
+void loamx_target_index_destroy(loamx_ctx* ctx, loamx_target_index* index) {
+  if (!index) return;
+  if (ctx) {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  for (int k = 0; k < 2; k++) {
+    if (index->desc[k]) (void)hipFree(index->desc[k]);
+    if (index->cells[k]) (void)hipFree(index->cells[k]);
+    if (index->sorted[k]) (void)hipFree(index->sorted[k]);
+  }
+  delete index;
+}
+
+int loamx_target_index_create(loamx_ctx* ctx, const double* tgt_edge, size_t n_te, const double* tgt_planar, size_t n_tp,
+                              const loamx_reg_params* reg, loamx_target_index** out) {
+  if (!ctx || !out) return LOAMX_ERR_BAD_PARAM;
+  *out = nullptr;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  RegConfig C;
+  int rc = make_reg_config(ctx, reg, C);
+  if (rc != LOAMX_OK) return rc;
+  if (n_te > 0x0FFFFFFFull || n_tp > 0x0FFFFFFFull) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "feature set too large");
+  hipStream_t s = ctx->stream;
+  loamx_target_index* idx = new loamx_target_index;
+  idx->n[0] = n_te, idx->n[1] = n_tp;
+  idx->radius[0] = C.r_edge, idx->radius[1] = C.r_plane;
+  const double* host[2] = {tgt_edge, tgt_planar};
+  const int ws_pts[2] = {WS_TGT_E, WS_TGT_P};
+  rc = ensure(ctx, WS_FCOUNTS, 4 * sizeof(uint32_t));
+  const uint32_t counts[4] = {0, 0, (uint32_t)n_te, (uint32_t)n_tp};
+  if (rc == LOAMX_OK && hipMemcpyAsync(ctx->ws[WS_FCOUNTS].p, counts, sizeof(counts), hipMemcpyHostToDevice, s) != hipSuccess) rc = LOAMX_ERR_HIP;
+  for (int k = 0; k < 2 && rc == LOAMX_OK; k++) {
+    const size_t n = idx->n[k];
+    rc = ensure(ctx, ws_pts[k], (n ? n : 1) * 24);
+    if (rc != LOAMX_OK) break;
+    if (hipMalloc(reinterpret_cast<void**>(&idx->desc[k]), sizeof(GridDesc)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&idx->cells[k]), (size_t)(kGridCellsCap + 1) * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&idx->sorted[k]), (n + kGridPad) * sizeof(GridPoint)) != hipSuccess) {
+      rc = fail(ctx, LOAMX_ERR_HIP, "hipMalloc failed for the target index");
+      break;
+    }
+    if (n && hipMemcpyAsync(ctx->ws[ws_pts[k]].p, host[k], n * 24, hipMemcpyHostToDevice, s) != hipSuccess) rc = LOAMX_ERR_HIP;
+  }
+  if (rc == LOAMX_OK) {
+    RegBatch B{};
+    B.n_pairs = 1, B.in_pitch = 1;
+    B.edge_stride = n_te ? n_te : 1, B.planar_stride = n_tp ? n_tp : 1;
+    B.tgt_edge = wsp<double>(ctx, WS_TGT_E), B.tgt_planar = wsp<double>(ctx, WS_TGT_P);
+    B.n_tgt_edge = wsp<uint32_t>(ctx, WS_FCOUNTS) + 2, B.n_tgt_planar = wsp<uint32_t>(ctx, WS_FCOUNTS) + 3;
+    B.grid_edge = GridSet{idx->desc[0], idx->cells[0], idx->sorted[0], n_te + kGridPad};
+    B.grid_plane = GridSet{idx->desc[1], idx->cells[1], idx->sorted[1], n_tp + kGridPad};
+    {
+      TimedScope t(ctx, LOAMX_K_GRID, 0.0);
+      launch_grid_build_targets(B, C, s);
+    }
+    rc = check_launch(ctx, "grid_build_kernel");
+    if (rc == LOAMX_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(ctx, LOAMX_ERR_HIP, "target index build failed");
+  }
+  if (rc != LOAMX_OK) {
+    for (int k = 0; k < 2; k++) {
+      if (idx->desc[k]) (void)hipFree(idx->desc[k]);
+      if (idx->cells[k]) (void)hipFree(idx->cells[k]);
+      if (idx->sorted[k]) (void)hipFree(idx->sorted[k]);
+    }
+    delete idx;
+    return rc;
+  }
+  *out = idx;
   return LOAMX_OK;
 }
 

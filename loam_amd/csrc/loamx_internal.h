@@ -111,7 +111,8 @@ struct RegBatch {
   loamx_iter_info* iter_info;  // optional [n_pairs][max_iterations]
 };
 
-void launch_grid_build(const RegBatch& B, const RegConfig& C, hipStream_t s);
+void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_t s);
+void launch_grid_build_sources(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_state_init(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_lm_begin(const RegBatch& B, const RegConfig& C, uint32_t iteration, hipStream_t s);

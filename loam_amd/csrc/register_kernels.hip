@@ -652,13 +652,17 @@ inline unsigned per_pair_grid(size_t n_pairs) { return (unsigned)((n_pairs + 63)
 
 }  // namespace
 
-void launch_grid_build(const RegBatch& B, const RegConfig& C, hipStream_t s) {
+void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   if (B.n_pairs == 0) return;
   hipLaunchKernelGGL(grid_build_kernel<false>, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.tgt_edge, B.n_tgt_edge,
                      B.edge_stride, B.in_pitch, C.r_edge, B.grid_edge, (GridPoint*)nullptr);
   hipLaunchKernelGGL(grid_build_kernel<false>, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.tgt_planar,
                      B.n_tgt_planar, B.planar_stride, B.in_pitch, C.r_plane, B.grid_plane, (GridPoint*)nullptr);
-  // source sets: only the cell-sorted order is used
+}
+
+// source sets: only the cell-sorted (Morton) order is used
+void launch_grid_build_sources(const RegBatch& B, const RegConfig& C, hipStream_t s) {
+  if (B.n_pairs == 0) return;
   hipLaunchKernelGGL(grid_build_kernel<true>, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.src_edge, B.n_src_edge,
                      B.edge_stride, B.in_pitch, C.r_edge, B.src_grid_edge, B.sort_scratch);
   hipLaunchKernelGGL(grid_build_kernel<true>, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.src_planar,

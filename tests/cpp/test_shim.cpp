@@ -202,6 +202,16 @@ static void test_registration() {
   one.max_iterations = 1;
   checkRegistration(Pose3d(angleAxis(0.1, Vector3d(0, 0, 1)), Vector3d::Zero()),
                     Pose3d(angleAxis(-0.1, Vector3d(0, 0, 1)), Vector3d(0.1, 0, 0)), one, 1e-4, 1e-3);  // CompositionDirection
+  {  // extension: persistent target index gives the same pose as the plain call
+    LoamFeatures<Vector3d> target = constructSimpleScene();
+    const Pose3d sTt(q, Vector3d(-0.1, 0.1, 0.0));
+    LoamFeatures<Vector3d> source = transformFeatures(target, sTt);
+    const Pose3d plain = registerFeatures<ParenAccessor>(source, target, Pose3d());
+    TargetIndex index = TargetIndex::build<ParenAccessor>(target);
+    const Pose3d viaIndex = registerFeatures<ParenAccessor>(source, index, Pose3d());
+    for (int i = 0; i < 3; i++) CHECK(plain.translation(i) == viaIndex.translation(i));
+    CHECK(plain.rotation.w() == viaIndex.rotation.w());
+  }
   {  // NonStandardAllocator: planar only, self registration
     LoamFeatures<Vector3d> t;
     for (double y = 3; y < 6; y += 0.05)

@@ -131,3 +131,13 @@ def test_scan_to_map_registration(oracle):
     assert rot < SE3_TOL and trans < SE3_TOL, (rot, trans)
     rot, trans = pose_diff(oracle, capi.synth_pair_pose(99, 0), pg)
     assert rot < 1e-2 and trans < 3e-2
+    # persistent target index: build once, register repeatedly, bit-identical results
+    idx = ctx().target_index(map_e, map_p)
+    for _ in range(2):
+        pi, ti, ii = ctx().register_features_indexed(idx, src[e], src[p])
+        assert (ti, ii) == (tg, ig) and np.array_equal(pi.view(np.uint64), pg.view(np.uint64))
+    reg2 = capi.RegistrationParams()
+    reg2.max_plane_neighbor_dist = 1.5
+    with pytest.raises(capi.LoamxError):
+        ctx().register_features_indexed(idx, src[e], src[p], reg=reg2)
+    ctx().target_index_destroy(idx)
