@@ -37,7 +37,8 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc()] + FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    extra = os.environ.get("LOAMX_EXTRA_FLAGS", "").split()  # experiments only, e.g. -DLOAMX_ASSOC_WAVES=6
+    cmd = [_hipcc()] + FLAGS + extra + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -21,7 +21,7 @@ enum WsId {
   WS_XYZ = 0, WS_CURV, WS_MASK, WS_EDGE_STAGE, WS_PLANAR_STAGE, WS_EDGE_CNT, WS_PLANAR_CNT,
   WS_EDGE_IDX, WS_PLANAR_IDX, WS_N_EDGE, WS_N_PLANAR, WS_EDGE_XYZ, WS_PLANAR_XYZ,
   WS_GRID_DESC_E, WS_GRID_DESC_P, WS_CELLS_E, WS_CELLS_P, WS_SORTED_E, WS_SORTED_P,
-  WS_SGRID_DESC_E, WS_SGRID_DESC_P, WS_SCELLS_E, WS_SCELLS_P, WS_SSORTED_E, WS_SSORTED_P, WS_SORT_SCRATCH, WS_ASSOC_E, WS_ASSOC_P, WS_NN_E, WS_NN_P, WS_KNN_DONE, WS_NEAREST_E, WS_NEAREST_P, WS_NASSOC, WS_STATE, WS_PARTIALS,
+  WS_SGRID_DESC_E, WS_SGRID_DESC_P, WS_SCELLS_E, WS_SCELLS_P, WS_SSORTED_E, WS_SSORTED_P, WS_SORT_SCRATCH, WS_ASSOC_E, WS_ASSOC_P, WS_NN_E, WS_NN_P, WS_NEAREST_E, WS_NEAREST_P, WS_NASSOC, WS_STATE, WS_PARTIALS,
   WS_COUNTERS, WS_ITERINFO, WS_SRC_E, WS_SRC_P, WS_TGT_E, WS_TGT_P, WS_FCOUNTS, WS_RESULTS, WS_INIT,
   WS_COUNT
 };
@@ -281,7 +281,6 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   ENSURE(ctx, WS_ASSOC_P, 7 * np * ps * sizeof(double));
   ENSURE(ctx, WS_NN_E, (size_t)(1 + kMaxK) * np * es * sizeof(uint32_t));
   ENSURE(ctx, WS_NN_P, (size_t)(1 + kMaxK) * np * ps * sizeof(uint32_t));
-  ENSURE(ctx, WS_KNN_DONE, ((np + 7) / 8 * 8) * ((es > ps ? es : ps) / 256 + 1) * sizeof(uint32_t));
   ENSURE(ctx, WS_NEAREST_E, np * es * sizeof(uint32_t));
   ENSURE(ctx, WS_NEAREST_P, np * ps * sizeof(uint32_t));
   ENSURE(ctx, WS_NASSOC, np * 2 * sizeof(uint32_t));
@@ -300,7 +299,7 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   B.src_grid_plane = GridSet{wsp<GridDesc>(ctx, WS_SGRID_DESC_P), wsp<uint32_t>(ctx, WS_SCELLS_P), wsp<GridPoint>(ctx, WS_SSORTED_P), ps};
   B.sort_scratch = wsp<GridPoint>(ctx, WS_SORT_SCRATCH);
   B.assoc = AssocBuffers{wsp<double>(ctx, WS_ASSOC_E), wsp<double>(ctx, WS_ASSOC_P), wsp<uint32_t>(ctx, WS_NN_E),
-                         wsp<uint32_t>(ctx, WS_NN_P), wsp<uint32_t>(ctx, WS_KNN_DONE), wsp<uint32_t>(ctx, WS_NEAREST_E),
+                         wsp<uint32_t>(ctx, WS_NN_P), wsp<uint32_t>(ctx, WS_NEAREST_E),
                          wsp<uint32_t>(ctx, WS_NEAREST_P), wsp<uint32_t>(ctx, WS_NASSOC)};
   B.state = wsp<PairState>(ctx, WS_STATE);
   B.partials = wsp<double>(ctx, WS_PARTIALS);
@@ -309,7 +308,6 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   B.sweep_slots = reinterpret_cast<unsigned long long*>(wsp<unsigned char>(ctx, WS_COUNTERS) + 8);
   B.assoc_slots = B.sweep_slots + 2;
   B.iter_info = want_iter_info ? wsp<loamx_iter_info>(ctx, WS_ITERINFO) : nullptr;
-  B.use_lds_knn = getenv("LOAMX_KNN_LDS") ? 1u : 0u;  // off by default: measured slower than the global-memory kernel
   hipStream_t s = ctx->stream;
 
   if (prebuilt) {  // persistent target index: only the source sets are (re)ordered

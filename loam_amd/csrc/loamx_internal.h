@@ -60,7 +60,6 @@ struct AssocBuffers {
   double* plane;      // [7][n_pairs * planar_stride]
   uint32_t* nn_edge;        // [1 + kMaxK][n_pairs * edge_stride]   neighbour count, then positions in the sorted target
   uint32_t* nn_plane;       // [1 + kMaxK][n_pairs * planar_stride]
-  uint32_t* knn_done;       // [workgroups of one association launch] 1 = served by the LDS-staged kNN kernel
   uint32_t* nearest_edge;   // [n_pairs * edge_stride]   nearest target index (detail capture)
   uint32_t* nearest_plane;  // [n_pairs * planar_stride]
   uint32_t* n_assoc;  // [n_pairs][2] valid edge / plane associations of the current iteration
@@ -104,7 +103,6 @@ struct RegBatch {
   PairState* state;      // [n_pairs]
   double* partials;      // [n_pairs][blocks_per_pair][kAccSize]
   uint32_t blocks_per_pair;
-  uint32_t use_lds_knn;  // 1: try the LDS-staged kNN kernel first (experiment, slower as measured)
   uint32_t* n_active;    // device counter read back by the host after every outer iteration
   unsigned long long* sweep_slots;  // [2] edge / plane association slots streamed by sweep_kernel (roofline bytes)
   unsigned long long* assoc_slots;  // [2] edge / plane source features processed by associate_kernel

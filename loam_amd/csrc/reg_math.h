@@ -212,13 +212,141 @@ LOAMX_HD void knn_insert(KnnResult<KM>& r, int k, double d2, uint32_t pos, uint3
   r.worst = w;  // DBL_MAX until k points have been seen
 }
 
+// upper bound on the k-th smallest squared distance seen so far (DBL_MAX until k were seen)
+template <int KM>
+LOAMX_HD double knn_bound(const KnnResult<KM>& r, int k) {
+  (void)k;
+  return r.worst;
+}
+
+// four candidates (the first min(n, 4) are real). Measured: four straight-line insert sites beat one
+// rolled insert loop (7.3 vs 9.1 ms per launch).
+template <int KM>
+LOAMX_HD void knn_offer4(KnnResult<KM>& r, int k, double d0, double d1, double d2, double d3, uint32_t p, uint32_t n,
+                         uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3) {
+  if (d0 <= r.worst) knn_insert(r, k, d0, p, o0);
+  if (n > 1 && d1 <= r.worst) knn_insert(r, k, d1, p + 1, o1);
+  if (n > 2 && d2 <= r.worst) knn_insert(r, k, d2, p + 2, o2);
+  if (n > 3 && d3 <= r.worst) knn_insert(r, k, d3, p + 3, o3);
+}
+
+/* Keyed collector — the fast path of the search.
+ *
+ * A candidate is folded into ONE double: the bit pattern of its squared distance with the low
+ * `bits` mantissa bits replaced by its position in the cell-sorted array (bits = just enough for
+ * the set). For non-negative doubles the numeric order equals the order of the bit patterns, so
+ * keys order candidates by (truncated d2, position) and the KM+1 smallest keys are maintained with a
+ * chain of v_min_f64 / v_max_f64 pairs: 2 instructions per slot instead of the ~11 of the exact
+ * (d2, orig) compare-exchange above.
+ *
+ * Truncation is monotone, so trunc(a) < trunc(b) implies a < b. The result is therefore exact
+ * whenever the truncated distances of slots 0..k (k neighbours plus the best rejected candidate) are
+ * pairwise different: then slots 0..k-1 are the k nearest in exactly the (d2, orig) order. Otherwise
+ * (two candidates within ~2^-(52-bits) relative of each other: exact ties in structured data, or
+ * once in ~10^9 queries on noisy data), or when the radius filter cannot be decided from a truncated
+ * distance, knn_keys_finish reports "undecided" and the caller repeats the query with the exact
+ * collector. Results are thus always those of the exact search. */
+template <int KM>
+struct KnnKeys {
+  double key[KM + 1];  // ascending: KM-k sentinels (-1), then the k+1 smallest keys; +inf = empty
+  uint32_t mask;       // low-word mask of the position bits
+};
+
+LOAMX_HD double knn_key_empty() { return __builtin_huge_val(); }
+LOAMX_HD uint32_t knn_key_lo(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__double2loint(v);
+#else
+  uint64_t b;
+  __builtin_memcpy(&b, &v, 8);
+  return (uint32_t)b;
+#endif
+}
+LOAMX_HD uint32_t knn_key_hi(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__double2hiint(v);
+#else
+  uint64_t b;
+  __builtin_memcpy(&b, &v, 8);
+  return (uint32_t)(b >> 32);
+#endif
+}
+LOAMX_HD double knn_key_join(uint32_t hi, uint32_t lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __hiloint2double((int)hi, (int)lo);
+#else
+  const uint64_t b = ((uint64_t)hi << 32) | lo;
+  double v;
+  __builtin_memcpy(&v, &b, 8);
+  return v;
+#endif
+}
+// candidates whose distance is not a finite number (NaN / inf coordinates) never enter the list,
+// exactly as `d <= worst` keeps them out of the exact collector
+LOAMX_HD double knn_key_pack(double d2, uint32_t pos, uint32_t mask, bool real) {
+  const double key = knn_key_join(knn_key_hi(d2), (knn_key_lo(d2) & ~mask) | pos);
+  return (real && d2 <= kDblMax) ? key : knn_key_empty();
+}
+LOAMX_HD uint32_t knn_key_mask(uint32_t n_points) {
+  if (n_points <= 2u) return 1u;
+  return 0xFFFFFFFFu >> __builtin_clz(n_points - 1u);
+}
+// min / max of two keys. Keys are never NaN, so the plain machine instructions are exact; inline
+// asm keeps the compiler from wrapping every operand in a canonicalising v_max_f64 x, x (which the
+// IEEE-mode lowering of fmin / fmax requires for possible signalling NaNs).
+LOAMX_HD double knn_key_min(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  return a < b ? a : b;
+#endif
+}
+LOAMX_HD double knn_key_max(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  return a < b ? b : a;
+#endif
+}
+template <int KM>
+LOAMX_HD void knn_key_insert(KnnKeys<KM>& c, double key) {
+#pragma unroll
+  for (int j = 0; j < KM; j++) {
+    const double s = c.key[j];
+    c.key[j] = knn_key_min(s, key);
+    key = knn_key_max(s, key);
+  }
+  c.key[KM] = knn_key_min(c.key[KM], key);
+}
+// The k-th smallest real key sits in slot KM-1 and the best rejected one in slot KM, whatever k is:
+// the first KM-k slots hold the sentinel -1 (smaller than every key), see knn_init.
+template <int KM>
+LOAMX_HD double knn_bound(const KnnKeys<KM>& c, int k) {
+  (void)k;
+  const double kth = c.key[KM - 1];
+  // the true d2 of every one of the k smallest keys is <= its key with all position bits set
+  return kth < knn_key_empty() ? knn_key_join(knn_key_hi(kth), knn_key_lo(kth) | c.mask) : kDblMax;
+}
+template <int KM>
+LOAMX_HD void knn_offer4(KnnKeys<KM>& c, int k, double d0, double d1, double d2, double d3, uint32_t p, uint32_t n,
+                         uint32_t, uint32_t, uint32_t, uint32_t) {
+  (void)k;
+  knn_key_insert(c, knn_key_pack(d0, p, c.mask, true));
+  knn_key_insert(c, knn_key_pack(d1, p + 1, c.mask, n > 1));
+  knn_key_insert(c, knn_key_pack(d2, p + 2, c.mask, n > 2));
+  knn_key_insert(c, knn_key_pack(d3, p + 3, c.mask, n > 3));
+}
+
 // Candidates are fetched four at a time (four independent 32-byte loads in flight per lane).
 // The array is allocated with kGridPad spare entries, so the four loads never need clamping;
 // entries at or beyond the range end belong to the next cell (or are padding) and are masked by n
 // (= entries left in the range, may exceed 4).
-template <int KM>
-LOAMX_HD void knn_scan_batch(KnnResult<KM>& r, int k, Vec3 q, const GridPoint* __restrict__ sp, uint32_t p, uint32_t n,
-                             uint32_t pos_delta) {
+template <class Coll>
+LOAMX_HD void knn_scan_batch(Coll& r, int k, Vec3 q, const GridPoint* __restrict__ sp, uint32_t p, uint32_t n) {
   const GridPoint t0 = sp[p];
   const GridPoint t1 = sp[p + 1];
   const GridPoint t2 = sp[p + 2];
@@ -235,17 +363,12 @@ LOAMX_HD void knn_scan_batch(KnnResult<KM>& r, int k, Vec3 q, const GridPoint* _
   const double d2 = dx * dx + dy * dy + dz * dz;
   dx = q.x - t3.x, dy = q.y - t3.y, dz = q.z - t3.z;
   const double d3 = dx * dx + dy * dy + dz * dz;
-  // (measured: four straight-line insert sites beat one rolled insert loop, 7.3 vs 9.1 ms per launch)
-  if (d0 <= r.worst) knn_insert(r, k, d0, p + pos_delta, t0.orig);
-  if (n > 1 && d1 <= r.worst) knn_insert(r, k, d1, p + 1 + pos_delta, t1.orig);
-  if (n > 2 && d2 <= r.worst) knn_insert(r, k, d2, p + 2 + pos_delta, t2.orig);
-  if (n > 3 && d3 <= r.worst) knn_insert(r, k, d3, p + 3 + pos_delta, t3.orig);
+  knn_offer4(r, k, d0, d1, d2, d3, p, n, t0.orig, t1.orig, t2.orig, t3.orig);
 }
 
-template <int KM>
-LOAMX_HD void knn_scan_range(KnnResult<KM>& r, int k, Vec3 q, const GridPoint* __restrict__ sp, uint32_t begin, uint32_t end,
-                             uint32_t pos_delta) {
-  for (uint32_t p = begin; p < end; p += 4) knn_scan_batch(r, k, q, sp, p, end - p, pos_delta);
+template <class Coll>
+LOAMX_HD void knn_scan_range(Coll& r, int k, Vec3 q, const GridPoint* __restrict__ sp, uint32_t begin, uint32_t end) {
+  for (uint32_t p = begin; p < end; p += 4) knn_scan_batch(r, k, q, sp, p, end - p);
 }
 
 // distance from coordinate v to the slab of cell index c along one axis, shrunk by a safety margin
@@ -259,16 +382,17 @@ LOAMX_HD double slab_dist(double v, double origin, double h, int32_t c) {
 
 // Scans the cells [xlo, xhi] of row (iy, iz), skipping the row (or the part of it) whose slab is
 // farther than anything that could still enter the result: `bound` = min(k-th best d2, radius^2).
-template <int KM>
+template <class Coll>
 LOAMX_HD void knn_scan_row(const GridDesc& g, const uint32_t* __restrict__ cell_start, const GridPoint* __restrict__ sp,
-                           Vec3 q, int k, double r2, int32_t iy, int32_t iz, int32_t xlo, int32_t xhi, KnnResult<KM>& r) {
+                           Vec3 q, int k, double r2, int32_t iy, int32_t iz, int32_t xlo, int32_t xhi, Coll& r) {
   if (iy < 0 || iy > g.ny - 1 || iz < 0 || iz > g.nz - 1) return;
   if (xlo < 0) xlo = 0;
   if (xhi > g.nx - 1) xhi = g.nx - 1;
   if (xlo > xhi) return;
   const double sy = slab_dist(q.y, g.oy, g.h, iy), sz = slab_dist(q.z, g.oz, g.h, iz);
   const double rowmin2 = sy * sy + sz * sz;
-  const double bound = r.worst < r2 ? r.worst : r2;
+  const double worst = knn_bound(r, k);
+  const double bound = worst < r2 ? worst : r2;
   if (rowmin2 > bound) return;
   if (bound < kDblMax) {
     // cells whose x slab is farther than sqrt(bound - rowmin2) cannot contribute
@@ -282,7 +406,7 @@ LOAMX_HD void knn_scan_row(const GridDesc& g, const uint32_t* __restrict__ cell_
 #if defined(LOAMX_KNN_STATS)
   g_rows++;
 #endif
-  knn_scan_range(r, k, q, sp, cell_start[row + xlo], cell_start[row + xhi + 1], 0u);
+  knn_scan_range(r, k, q, sp, cell_start[row + xlo], cell_start[row + xhi + 1]);
 }
 
 template <int KM>
@@ -295,6 +419,12 @@ LOAMX_HD void knn_init(KnnResult<KM>& r) {
     r.pos[j] = 0;
     r.orig[j] = 0xFFFFFFFFu;
   }
+}
+template <int KM>
+LOAMX_HD void knn_init(KnnKeys<KM>& c, int k, uint32_t n_points) {
+  c.mask = knn_key_mask(n_points);
+#pragma unroll
+  for (int j = 0; j <= KM; j++) c.key[j] = j < KM - k ? -1.0 : knn_key_empty();
 }
 
 // Chebyshev distance (in cells) from the query cell to the grid box
@@ -311,16 +441,14 @@ LOAMX_HD double knn_radius_bound(double max_dist) { return max_dist > 0.0 ? max_
 
 // The rounds of the search. Cubes of cells of growing half-width w around the query cell are
 // visited; after round w every unvisited point is farther than w*h along some axis.
-// `scanned` = round w has already been visited by the caller (LDS-staged first round).
-template <int KM>
+template <class Coll>
 LOAMX_HD void knn_rounds(const GridDesc& g, const uint32_t* __restrict__ cell_start, const GridPoint* __restrict__ sp, Vec3 q,
-                         int k, double max_dist, int32_t cx, int32_t cy, int32_t cz, KnnResult<KM>& r, int32_t w, bool first,
-                         bool scanned, uint32_t* row_scratch, int row_stride) {
+                         int k, double max_dist, int32_t cx, int32_t cy, int32_t cz, Coll& r, int32_t w,
+                         uint32_t* row_scratch, int row_stride) {
   const double r2 = knn_radius_bound(max_dist);
+  bool first = true;
   for (;;) {
-    if (scanned) {
-      scanned = false;
-    } else if (first && w == 1) {
+    if (first && w == 1) {
       // Common case: the 3x3x3 block. The cell_start entries of its nine rows are fetched up front
       // (18 independent loads instead of nine dependent round trips). The non-empty rows are written
       // to a small per-thread list (LDS in the kernels) in the order centre, faces, corners, and the
@@ -361,7 +489,8 @@ LOAMX_HD void knn_rounds(const GridDesc& g, const uint32_t* __restrict__ cell_st
           ri++;
           const int j = (int)(bj >> 28), jy = j % 3, jz = j / 3;
           const double sy2 = jy == 0 ? sy2m : (jy == 1 ? 0.0 : sy2p), sz2 = jz == 0 ? sz2m : (jz == 1 ? 0.0 : sz2p);
-          const double bound = r.worst < r2 ? r.worst : r2;
+          const double worst = knn_bound(r, k);
+          const double bound = worst < r2 ? worst : r2;
           if (sy2 + sz2 <= bound) {
 #if defined(LOAMX_KNN_STATS)
             g_rows++;
@@ -370,7 +499,7 @@ LOAMX_HD void knn_rounds(const GridDesc& g, const uint32_t* __restrict__ cell_st
           }
         }
         if (p >= e) break;
-        knn_scan_batch(r, k, q, sp, p, e - p, 0u);
+        knn_scan_batch(r, k, q, sp, p, e - p);
         p += 4;
       }
     } else {
@@ -413,9 +542,9 @@ LOAMX_HD void knn_rounds(const GridDesc& g, const uint32_t* __restrict__ cell_st
       }
       if (guard < 0.0) guard = 0.0;
     }
-    if (guard == kDblMax) break;                 // the block covers the whole grid
-    if (r.worst < guard * guard) break;          // k found (worst is DBL_MAX otherwise), all closer than anything unvisited
-    if (max_dist > 0.0 && guard >= max_dist) break;  // anything unvisited fails the radius filter
+    if (guard == kDblMax) break;                       // the block covers the whole grid
+    if (knn_bound(r, k) < guard * guard) break;        // k found (bound is DBL_MAX otherwise), all closer than anything unvisited
+    if (max_dist > 0.0 && guard >= max_dist) break;    // anything unvisited fails the radius filter
     w++;
   }
 }
@@ -436,6 +565,35 @@ LOAMX_HD int knn_finish(KnnResult<KM>& r, int k, double max_dist) {
   return kept;
 }
 
+// Keyed collector: number of neighbours kept (a prefix of the real slots, ascending), or -1 =
+// undecided (see the KnnKeys comment): two of the k+1 real slots share a truncated distance, or a
+// truncated distance straddles the radius. pos[i] is the position held by slot i; neighbour j of the
+// result is slot (KM - k) + j.
+template <int KM>
+LOAMX_HD int knn_keys_finish(const KnnKeys<KM>& c, int k, double max_dist, uint32_t pos[KM]) {
+  int kept = 0;
+  bool undecided = false, open = true;
+#pragma unroll
+  for (int i = 0; i < KM; i++) {
+    const double a = c.key[i], b = c.key[i + 1];
+    const bool real = i >= KM - k && a < knn_key_empty();
+    pos[i] = knn_key_lo(a) & c.mask;
+    if (real && b < knn_key_empty() && knn_key_hi(a) == knn_key_hi(b) && ((knn_key_lo(a) ^ knn_key_lo(b)) & ~c.mask) == 0u)
+      undecided = true;
+    if (real && open) {
+      const double lo = knn_key_join(knn_key_hi(a), knn_key_lo(a) & ~c.mask);  // lo <= d2 <= hi
+      const double hi = knn_key_join(knn_key_hi(a), knn_key_lo(a) | c.mask);
+      if (max_dist <= 0.0 || sqrt(hi) < max_dist) {
+        kept++;
+      } else {
+        open = false;
+        if (sqrt(lo) < max_dist) undecided = true;
+      }
+    }
+  }
+  return undecided ? -1 : kept;
+}
+
 // Exact k-NN of q among the indexed points, then the strict radius filter of kdtree.cpp:25.
 // Returns the number of neighbours kept (prefix of r).
 template <int KM>
@@ -449,8 +607,47 @@ LOAMX_HD int knn_search(const GridDesc& g, const uint32_t* __restrict__ cell_sta
   const int32_t out = grid_outside_distance(g, cx, cy, cz);
   // every point is at least (out-1)*h away: nothing can pass the radius filter
   if (max_dist > 0.0 && out >= 1 && (double)(out - 1) * g.h >= max_dist) return 0;
-  knn_rounds(g, cell_start, sp, q, k, max_dist, cx, cy, cz, r, out > 1 ? out : 1, true, false, row_scratch, row_stride);
+  knn_rounds(g, cell_start, sp, q, k, max_dist, cx, cy, cz, r, out > 1 ? out : 1, row_scratch, row_stride);
   return knn_finish(r, k, max_dist);
+}
+
+// Same result as knn_search (positions only), through the keyed collector; the exact collector
+// re-runs the rare undecided query. Neighbour j (ascending) is pos[(KM - k) + j] — the keyed
+// collector keeps its k-th key in a fixed register, which shifts the list by KM - k.
+// `fallbacks`, when given, counts the re-runs.
+template <int KM>
+LOAMX_HD int knn_search_positions(const GridDesc& g, const uint32_t* __restrict__ cell_start,
+                                  const GridPoint* __restrict__ sp, Vec3 q, int k, double max_dist, uint32_t pos[KM],
+                                  uint32_t* row_scratch, int row_stride, uint32_t* fallbacks = nullptr) {
+#pragma unroll
+  for (int j = 0; j < KM; j++) pos[j] = 0;
+  if (g.n_points == 0 || k <= 0) return 0;
+  if (k > KM) k = KM;
+  const int32_t cx = grid_cell_coord(q.x, g.ox, g.inv_h);
+  const int32_t cy = grid_cell_coord(q.y, g.oy, g.inv_h);
+  const int32_t cz = grid_cell_coord(q.z, g.oz, g.inv_h);
+  const int32_t out = grid_outside_distance(g, cx, cy, cz);
+  if (max_dist > 0.0 && out >= 1 && (double)(out - 1) * g.h >= max_dist) return 0;
+  KnnKeys<KM> c;
+  knn_init(c, k, g.n_points);
+  knn_rounds(g, cell_start, sp, q, k, max_dist, cx, cy, cz, c, out > 1 ? out : 1, row_scratch, row_stride);
+  int kept = knn_keys_finish(c, k, max_dist, pos);
+  if (kept < 0) {
+    if (fallbacks) (*fallbacks)++;
+    KnnResult<KM> r;
+    knn_init(r);
+    knn_rounds(g, cell_start, sp, q, k, max_dist, cx, cy, cz, r, out > 1 ? out : 1, row_scratch, row_stride);
+    kept = knn_finish(r, k, max_dist);
+#pragma unroll
+    for (int i = 0; i < KM; i++) {
+      uint32_t v = 0;
+#pragma unroll
+      for (int j = 0; j < KM; j++)
+        if (j == i - (KM - k)) v = r.pos[j];
+      pos[i] = v;
+    }
+  }
+  return kept;
 }
 
 /* ------------------------------------------------------------------------------------------------

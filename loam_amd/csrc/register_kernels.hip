@@ -193,7 +193,7 @@ __device__ __forceinline__ bool xcd_pair_map(uint32_t block, uint32_t blocks_per
 //                          (in the cell-sorted target array) of the k nearest, ascending.
 //   associate_fit_kernel : pure FP64 arithmetic — gathers the neighbours, fitLine / fitPlane, guards,
 //                          writes the association record.
-template <bool PLANE, int KM, bool AFTER_LDS>
+template <bool PLANE, int KM>
 __global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_knn_kernel(RegBatch B, RegConfig C,
                                                                                          uint32_t blocks_per_pair) {
   size_t pair;
@@ -202,12 +202,11 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_kn
   const uint32_t i = chunk * kAssocThreads + threadIdx.x;
   const PairState& S = B.state[pair];
   if (!S.active) return;  // uniform per workgroup
-  if (AFTER_LDS && B.assoc.knn_done[blockIdx.x]) return;  // already served by associate_knn_lds_kernel
   const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
   const uint32_t n_src = PLANE ? B.n_src_planar[pair * B.in_pitch] : B.n_src_edge[pair * B.in_pitch];
   const GridSet& gs = PLANE ? B.grid_plane : B.grid_edge;
   const GridSet& src_gs = PLANE ? B.src_grid_plane : B.src_grid_edge;
-  if (!AFTER_LDS && chunk == 0 && threadIdx.x == 0 && B.assoc_slots)
+  if (chunk == 0 && threadIdx.x == 0 && B.assoc_slots)
     atomicAdd(&B.assoc_slots[PLANE ? 1 : 0], (unsigned long long)(n_src < stride ? n_src : stride));
   if (i >= n_src || i >= stride) return;
   // queries are taken in the source set's own cell order: neighbouring lanes look at neighbouring
@@ -218,201 +217,14 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_kn
   const uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
   const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
   __shared__ uint32_t s_rows[18 * kAssocThreads];  // per-thread list of non-empty rows, [word][thread] (conflict free)
-  KnnResult<KM> r;
-  const int kept = knn_search(g, cs, sp, p, PLANE ? C.k_plane : C.k_edge, PLANE ? C.r_plane : C.r_edge, r,
-                              s_rows + threadIdx.x, kAssocThreads);
+  uint32_t pos[KM];
+  const int kept = knn_search_positions<KM>(g, cs, sp, p, PLANE ? C.k_plane : C.k_edge, PLANE ? C.r_plane : C.r_edge, pos,
+                                            s_rows + threadIdx.x, kAssocThreads);
   const size_t field = B.n_pairs * stride, slot = pair * stride + i;
   uint32_t* __restrict__ nn = PLANE ? B.assoc.nn_plane : B.assoc.nn_edge;  // [1 + KM][n_pairs * stride]
   nn[slot] = (uint32_t)kept;
 #pragma unroll
-  for (int j = 0; j < KM; j++) nn[(1 + j) * field + slot] = r.pos[j];
-}
-
-/* LDS-staged variant of associate_knn_kernel ("LDS staging of correspondence candidates").
- * The 256 queries of a workgroup are neighbours in the source set's cell order, so their 3x3x3
- * candidate blocks overlap heavily. The workgroup computes the bounding box of its query cells
- * (+1 cell), copies the box's rows of the cell-sorted target array (coalesced 32-byte loads) and the
- * matching cell_start segments into LDS once, and every lane then runs the first search round out of
- * LDS. Lanes that need further rounds (sparse regions, queries outside the grid) continue on the
- * global path; boxes that do not fit the staging buffers fall back to the global path entirely.
- * Results are identical to associate_knn_kernel (same candidates, same total order). */
-constexpr int kStagePts = 2048;   // staged target points (64 KiB)
-constexpr int kStageCells = 3072; // staged cell_start entries (12 KiB)
-constexpr int kStageRows = 256;
-
-template <bool PLANE, int KM>
-__global__ __launch_bounds__(kAssocThreads) void associate_knn_lds_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
-  __shared__ GridPoint s_pts[kStagePts + kGridPad];
-  __shared__ uint32_t s_cs[kStageCells];
-  __shared__ uint32_t s_rowb[kStageRows];
-  __shared__ uint32_t s_rowoff[kStageRows + 1];
-  __shared__ int32_t s_red[6][kAssocThreads / 64];
-  __shared__ int32_t s_box[6];
-  __shared__ uint32_t s_scan[18 * kAssocThreads];  // block scan scratch, later the per-thread row list
-  __shared__ int32_t s_mode;  // 0 = global path, 1 = staged
-  size_t pair;
-  uint32_t chunk;
-  if (!xcd_pair_map(blockIdx.x, blocks_per_pair, B.n_pairs, pair, chunk)) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t i = chunk * kAssocThreads + tid;
-  const PairState& S = B.state[pair];
-  if (!S.active) return;  // uniform per workgroup
-  const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
-  const uint32_t n_src = PLANE ? B.n_src_planar[pair * B.in_pitch] : B.n_src_edge[pair * B.in_pitch];
-  const GridSet& gs = PLANE ? B.grid_plane : B.grid_edge;
-  const GridSet& src_gs = PLANE ? B.src_grid_plane : B.src_grid_edge;
-  if (chunk == 0 && tid == 0 && B.assoc_slots)
-    atomicAdd(&B.assoc_slots[PLANE ? 1 : 0], (unsigned long long)(n_src < stride ? n_src : stride));
-  const uint32_t n_lim = n_src < stride ? n_src : (uint32_t)stride;
-  if (chunk * kAssocThreads >= n_lim) {  // uniform: no query in this workgroup
-    if (tid == 0) B.assoc.knn_done[blockIdx.x] = 1u;
-    return;
-  }
-  const bool has = i < n_lim;
-  const int k = PLANE ? C.k_plane : C.k_edge;
-  const double max_dist = PLANE ? C.r_plane : C.r_edge;
-  const GridDesc g = gs.desc[pair];
-  const uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
-  const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
-
-  Vec3 p = v3(0, 0, 0);
-  int32_t cx = 0, cy = 0, cz = 0, out = 0;
-  bool searchable = false;  // has a query that must look at the grid at all
-  if (has) {
-    const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
-    p = pose_act(S.est, v3(sq.x, sq.y, sq.z));  // registration.cpp:34 / :75
-    cx = grid_cell_coord(p.x, g.ox, g.inv_h);
-    cy = grid_cell_coord(p.y, g.oy, g.inv_h);
-    cz = grid_cell_coord(p.z, g.oz, g.inv_h);
-    out = grid_outside_distance(g, cx, cy, cz);
-    searchable = g.n_points != 0 && k > 0 && !(max_dist > 0.0 && out >= 1 && (double)(out - 1) * g.h >= max_dist);
-  }
-  // ---- bounding box (in cells) of the queries that start with the 3x3x3 round
-  const bool first_round_here = searchable && out <= 1;
-  int32_t mn[3] = {first_round_here ? cx : 0x7fffffff, first_round_here ? cy : 0x7fffffff, first_round_here ? cz : 0x7fffffff};
-  int32_t mx[3] = {first_round_here ? cx : -0x7fffffff, first_round_here ? cy : -0x7fffffff, first_round_here ? cz : -0x7fffffff};
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const int32_t a0 = __shfl_xor(mn[a], off), a1 = __shfl_xor(mx[a], off);
-      mn[a] = a0 < mn[a] ? a0 : mn[a];
-      mx[a] = a1 > mx[a] ? a1 : mx[a];
-    }
-    if (lane == 0) s_red[a][wave] = mn[a], s_red[3 + a][wave] = mx[a];
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int32_t lo[3], hi[3];
-    for (int a = 0; a < 3; a++) {
-      lo[a] = s_red[a][0], hi[a] = s_red[3 + a][0];
-      for (int w = 1; w < kAssocThreads / 64; w++) {
-        lo[a] = s_red[a][w] < lo[a] ? s_red[a][w] : lo[a];
-        hi[a] = s_red[3 + a][w] > hi[a] ? s_red[3 + a][w] : hi[a];
-      }
-    }
-    const int32_t dim[3] = {g.nx, g.ny, g.nz};
-    bool ok = lo[0] <= hi[0];  // at least one first-round query
-    for (int a = 0; a < 3 && ok; a++) {
-      lo[a] = lo[a] - 1 < 0 ? 0 : lo[a] - 1;
-      hi[a] = hi[a] + 1 > dim[a] - 1 ? dim[a] - 1 : hi[a] + 1;
-      ok = lo[a] <= hi[a];
-    }
-    if (ok) {
-      const int64_t nxb = hi[0] - lo[0] + 1, nyb = hi[1] - lo[1] + 1, nzb = hi[2] - lo[2] + 1;
-      ok = nyb * nzb <= kStageRows && nyb * nzb * (nxb + 1) <= kStageCells;
-    }
-    for (int a = 0; a < 3; a++) s_box[2 * a] = lo[a], s_box[2 * a + 1] = hi[a];
-    s_mode = ok ? 1 : 0;
-  }
-  __syncthreads();
-  const int32_t X0 = s_box[0], X1 = s_box[1], Y0 = s_box[2], Y1 = s_box[3], Z0 = s_box[4];
-  const int32_t nxb1 = X1 - X0 + 2, nyb = Y1 - Y0 + 1;  // staged cell_start entries per row; rows per z
-  int32_t NR = 0;
-  if (s_mode == 1) {
-    NR = nyb * (s_box[5] - Z0 + 1);
-    // ---- row table: global begin, size, LDS offset (block exclusive scan)
-    uint32_t cnt = 0;
-    if (tid < NR) {
-      const uint32_t row = (uint32_t)(((Z0 + tid / nyb) * g.ny + (Y0 + tid % nyb)) * g.nx);
-      const uint32_t b = cs[row + X0], e = cs[row + X1 + 1];
-      s_rowb[tid] = b;
-      cnt = e - b;
-    }
-    s_scan[tid] = cnt;
-    __syncthreads();
-    for (int off = 1; off < kAssocThreads; off <<= 1) {
-      const uint32_t add = tid >= off ? s_scan[tid - off] : 0;
-      __syncthreads();
-      s_scan[tid] += add;
-      __syncthreads();
-    }
-    if (tid < NR) s_rowoff[tid] = s_scan[tid] - cnt;
-    if (tid == 0) {
-      s_rowoff[NR] = s_scan[kAssocThreads - 1];
-      if (s_scan[kAssocThreads - 1] > (uint32_t)kStagePts) s_mode = 0;  // too many candidates: global path
-    }
-    __syncthreads();
-  }
-  const bool staged = s_mode == 1;  // uniform
-  if (tid == 0) B.assoc.knn_done[blockIdx.x] = staged ? 1u : 0u;
-  if (!staged) return;  // this workgroup's queries are left to associate_knn_kernel (same grid, next launch)
-  {
-    // ---- stage the cell_start segments and the points of the box rows
-    const int32_t n_cells = NR * nxb1;
-    for (int32_t f = tid; f < n_cells; f += kAssocThreads) {
-      const int32_t rr = f / nxb1, x = f - rr * nxb1;
-      const uint32_t row = (uint32_t)(((Z0 + rr / nyb) * g.ny + (Y0 + rr % nyb)) * g.nx);
-      s_cs[f] = cs[row + X0 + x];
-    }
-    const uint32_t NP = s_rowoff[NR];
-    for (uint32_t f = tid; f < NP; f += kAssocThreads) {
-      int32_t lo = 0, hi = NR - 1;  // largest row with s_rowoff[row] <= f
-      while (lo < hi) {
-        const int32_t mid = (lo + hi + 1) >> 1;
-        if (s_rowoff[mid] <= f) lo = mid;
-        else hi = mid - 1;
-      }
-      s_pts[f] = sp[s_rowb[lo] + (f - s_rowoff[lo])];
-    }
-    __syncthreads();
-  }
-  if (!has) return;
-  KnnResult<KM> r;
-  knn_init(r);
-  int kept = 0;
-  if (searchable) {
-    bool scanned = false;
-    if (staged && out <= 1) {
-      // ---- first round (3x3x3 block) out of LDS: centre row, then faces, then corners
-      const double r2 = knn_radius_bound(max_dist);
-      const int32_t xa = cx - 1 < 0 ? 0 : cx - 1, xb = cx + 1 > g.nx - 1 ? g.nx - 1 : cx + 1;
-      if (xa <= xb) {
-#pragma unroll 1
-        for (int o = 0; o < 9; o++) {
-          const int j = (int)((0x862075314ull >> (4 * o)) & 0xFull);  // 4, 1, 3, 5, 7, 0, 2, 6, 8
-          const int32_t iy = cy + (j % 3) - 1, iz = cz + (j / 3) - 1;
-          if (iy < 0 || iy > g.ny - 1 || iz < 0 || iz > g.nz - 1) continue;
-          const int32_t rr = (iy - Y0) + (iz - Z0) * nyb;
-          const uint32_t gb = s_rowb[rr], lo_off = s_rowoff[rr];
-          const uint32_t b = s_cs[rr * nxb1 + (xa - X0)] - gb + lo_off, e = s_cs[rr * nxb1 + (xb + 1 - X0)] - gb + lo_off;
-          if (b >= e) continue;
-          const double sy = slab_dist(p.y, g.oy, g.h, iy), sz = slab_dist(p.z, g.oz, g.h, iz);
-          const double bound = r.worst < r2 ? r.worst : r2;
-          if (sy * sy + sz * sz > bound) continue;
-          knn_scan_range(r, k, p, s_pts, b, e, gb - lo_off);  // positions are reported in the global array
-        }
-      }
-      scanned = true;
-    }
-    knn_rounds(g, cs, sp, p, k, max_dist, cx, cy, cz, r, out > 1 ? out : 1, true, scanned, s_scan + tid, kAssocThreads);
-    kept = knn_finish(r, k, max_dist);
-  }
-  const size_t field = B.n_pairs * stride, slot = pair * stride + i;
-  uint32_t* __restrict__ nn = PLANE ? B.assoc.nn_plane : B.assoc.nn_edge;  // [1 + KM][n_pairs * stride]
-  nn[slot] = (uint32_t)kept;
-#pragma unroll
-  for (int j = 0; j < KM; j++) nn[(1 + j) * field + slot] = r.pos[j];
+  for (int j = 0; j < KM; j++) nn[(1 + j) * field + slot] = pos[j];
 }
 
 template <bool PLANE, int KM>
@@ -436,6 +248,8 @@ __global__ __launch_bounds__(kAssocThreads) void associate_fit_kernel(RegBatch B
     const size_t field = B.n_pairs * stride, slot = pair * stride + i;
     const uint32_t* __restrict__ nn = PLANE ? B.assoc.nn_plane : B.assoc.nn_edge;
     const int kept = (int)nn[slot];
+    const int kq = PLANE ? C.k_plane : C.k_edge;
+    const int shift = KM - (kq < KM ? kq : KM);  // neighbour j is slot shift + j (knn_search_positions)
     double prim[6] = {0, 0, 0, 0, 0, 0};
     uint32_t nearest = 0xFFFFFFFFu;
     if (kept >= (PLANE ? C.min_plane_pts : C.min_line_pts)) {  // registration.cpp:39 / :80
@@ -443,7 +257,7 @@ __global__ __launch_bounds__(kAssocThreads) void associate_fit_kernel(RegBatch B
 #pragma unroll
       for (int j = 0; j < KM; j++) {
         if (j < kept) {
-          const GridPoint t = sp[nn[(1 + j) * field + slot]];
+          const GridPoint t = sp[nn[(1 + shift + j) * field + slot]];
           nb[j] = v3(t.x, t.y, t.z);
           if (j == 0) nearest = t.orig;
         } else {
@@ -680,20 +494,12 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   const uint32_t bp = (uint32_t)((B.planar_stride + kAssocThreads - 1) / kAssocThreads);
   const size_t pair_groups = (B.n_pairs + 7) / 8;  // grid covers 8 XCD lanes x pair_groups x chunks
   // register-resident neighbour lists are instantiated for K <= 5 (the reference's default) and K <= 8
-  // kNN: LDS-staged kernel first; workgroups whose candidate box did not fit are served by the
-  // global-memory kernel (same grid); then the fit kernel.
-#define LOAMX_LAUNCH_ASSOC(PL, KMV, nblk)                                                                              \
-  do {                                                                                                                 \
-    const dim3 grid_((unsigned)(pair_groups * 8 * (nblk)));                                                            \
-    if (use_lds) {                                                                                                     \
-      hipLaunchKernelGGL((associate_knn_lds_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, s, B, C, (nblk));          \
-      hipLaunchKernelGGL((associate_knn_kernel<PL, KMV, true>), grid_, dim3(kAssocThreads), 0, s, B, C, (nblk));        \
-    } else {                                                                                                           \
-      hipLaunchKernelGGL((associate_knn_kernel<PL, KMV, false>), grid_, dim3(kAssocThreads), 0, s, B, C, (nblk));       \
-    }                                                                                                                  \
-    hipLaunchKernelGGL((associate_fit_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, s, B, C, (nblk));                \
+#define LOAMX_LAUNCH_ASSOC(PL, KMV, nblk)                                                                 \
+  do {                                                                                                    \
+    const dim3 grid_((unsigned)(pair_groups * 8 * (nblk)));                                               \
+    hipLaunchKernelGGL((associate_knn_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, s, B, C, (nblk));  \
+    hipLaunchKernelGGL((associate_fit_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, s, B, C, (nblk));  \
   } while (0)
-  const bool use_lds = B.use_lds_knn != 0 && B.assoc.knn_done != nullptr;
   if (be) {
     if (C.k_edge <= 5) LOAMX_LAUNCH_ASSOC(false, 5, be);
     else LOAMX_LAUNCH_ASSOC(false, 8, be);

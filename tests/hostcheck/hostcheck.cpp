@@ -239,20 +239,35 @@ static void build_grid(const double* pts, uint32_t n, double max_dist, HostGrid&
   }
 }
 
+extern "C++" {
+// Runs the keyed fast path (what the kernels run) and the exact collector on the same query and
+// requires identical answers; returns the answer. g_knn_fallbacks counts undecided keyed queries.
+static uint64_t g_knn_fallbacks = 0, g_knn_mismatch = 0;
+template <int KM>
+static int knn_both(const HostGrid& G, Vec3 q, int k, double max_dist, uint32_t pos[KM]) {
+  uint32_t rows[18], fb = 0;
+  const int kept = knn_search_positions<KM>(G.g, G.cell_start.data(), G.sp.data(), q, k, max_dist, pos, rows, 1, &fb);
+  g_knn_fallbacks += fb;
+  KnnResult<KM> r;
+  const int kept_exact = knn_search(G.g, G.cell_start.data(), G.sp.data(), q, k, max_dist, r, rows, 1);
+  bool same = kept == kept_exact;
+  for (int j = 0; same && j < kept; j++) same = pos[(KM - k) + j] == r.pos[j];
+  for (int j = 0; j < kept; j++) pos[j] = pos[(KM - k) + j];  // callers read the plain prefix
+  if (!same) g_knn_mismatch++;
+  return kept;
+}
+}
+uint64_t hostcheck_knn_fallbacks(void) { return g_knn_fallbacks; }
+uint64_t hostcheck_knn_mismatches(void) { return g_knn_mismatch; }
+
 uint64_t hostcheck_knn(const double* pts, uint64_t n, const double q[3], uint64_t k, double max_dist, uint64_t* idx_out) {
   HostGrid G;
   build_grid(pts, (uint32_t)n, max_dist, G);
-  if (k <= 5) {  // the kernels are instantiated for KM = 5 (default parameters) and KM = 8
-    uint32_t rows[18];
-    KnnResult<5> r;
-    const int kept = knn_search(G.g, G.cell_start.data(), G.sp.data(), v3(q[0], q[1], q[2]), (int)k, max_dist, r, rows, 1);
-    for (int j = 0; j < kept; j++) idx_out[j] = r.orig[j];
-    return (uint64_t)kept;
-  }
-  uint32_t rows[18];
-  KnnResult<8> r;
-  const int kept = knn_search(G.g, G.cell_start.data(), G.sp.data(), v3(q[0], q[1], q[2]), (int)k, max_dist, r, rows, 1);
-  for (int j = 0; j < kept; j++) idx_out[j] = r.orig[j];
+  uint32_t pos[8];
+  // the kernels are instantiated for KM = 5 (default parameters) and KM = 8
+  const int kept = k <= 5 ? knn_both<5>(G, v3(q[0], q[1], q[2]), (int)k, max_dist, pos)
+                          : knn_both<8>(G, v3(q[0], q[1], q[2]), (int)k, max_dist, pos);
+  for (int j = 0; j < kept; j++) idx_out[j] = G.sp[pos[j]].orig;
   return (uint64_t)kept;
 }
 
@@ -294,13 +309,12 @@ static uint32_t associate_t(const double* src, uint32_t n_src, const double* tgt
     Slot& s = slots[i];
     s.valid = false;
     s.p = pose_act(est, v3(src[3 * i], src[3 * i + 1], src[3 * i + 2]));
-    uint32_t rows[18];
-    KnnResult<KM> r;
-    const int kept = knn_search(G.g, G.cell_start.data(), G.sp.data(), s.p, k, maxd, r, rows, 1);
+    uint32_t pos[KM];
+    const int kept = knn_both<KM>(G, s.p, k, maxd, pos);
     if (kept < minfit) continue;
     Vec3 nb[KM];
     for (int j = 0; j < KM; j++)
-      if (j < kept) nb[j] = v3(G.sp[r.pos[j]].x, G.sp[r.pos[j]].y, G.sp[r.pos[j]].z);
+      if (j < kept) nb[j] = v3(G.sp[pos[j]].x, G.sp[pos[j]].y, G.sp[pos[j]].z);
     if (is_plane) {
       Vec3 n;
       double d;
@@ -315,7 +329,7 @@ static uint32_t associate_t(const double* src, uint32_t n_src, const double* tgt
       s.prim[0] = a.x, s.prim[1] = a.y, s.prim[2] = a.z, s.prim[3] = b.x, s.prim[4] = b.y, s.prim[5] = b.z;
     }
     s.valid = true;
-    s.nearest = r.orig[0];
+    s.nearest = G.sp[pos[0]].orig;
     count++;
   }
   return count;

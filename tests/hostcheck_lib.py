@@ -59,6 +59,8 @@ def lib():
         subprocess.check_call(["make", "-s", "-C", _DIR])
         _lib = C.CDLL(os.path.join(_DIR, "libhostcheck.so"))
         _lib.hostcheck_knn.restype = C.c_uint64
+        _lib.hostcheck_knn_fallbacks.restype = C.c_uint64
+        _lib.hostcheck_knn_mismatches.restype = C.c_uint64
         _lib.hostcheck_fit_plane.restype = C.c_double
     return _lib
 
@@ -170,3 +172,13 @@ def synth_pose(seed, pair):
     out = np.empty(7)
     lib().hostcheck_synth_pose(C.c_uint64(seed), C.c_uint64(pair), _dp(out))
     return out
+
+
+def knn_fallbacks():
+    """keyed-collector queries that were undecided and re-ran through the exact collector (cumulative)"""
+    return int(lib().hostcheck_knn_fallbacks())
+
+
+def knn_mismatches():
+    """queries on which the keyed path and the exact collector disagreed (must stay 0)"""
+    return int(lib().hostcheck_knn_mismatches())

@@ -123,6 +123,32 @@ def test_grid_knn_is_exact(oracle):
     # empty and tiny target sets
     assert len(Hc.knn(np.zeros((0, 3)), [0, 0, 0], 5, 1.0)) == 0
     assert np.array_equal(Hc.knn(np.array([[1.0, 0, 0], [0.5, 0, 0]]), [0, 0, 0], 5, -1.0), [1, 0])
+    assert Hc.knn_mismatches() == 0
+
+
+def test_keyed_knn_ties_and_radius_edges(oracle):
+    """The kernels' keyed collector (distance and position folded into one double) must hand every
+    query it cannot decide - exact distance ties, a distance within truncation of the radius - to the
+    exact collector, and agree with it everywhere else."""
+    # integer lattice: every query at a lattice point has 6 / 12 / 8 equidistant neighbours
+    g = np.arange(-3, 4, dtype=np.float64)
+    lattice = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    before = Hc.knn_fallbacks()  # (exact ties: the grid orders by (d2, index) like the brute-force oracle; nanoflann's
+    # tie order depends on its traversal - DESIGN.md "tie policy")
+    for q in ([0, 0, 0], [1, -1, 2], [0.5, 0.5, 0.5], [0.25, 0, 0], [3, 3, 3], [10, 0, 0]):
+        for k in (1, 5, 8):
+            for R in (-1.0, 1.0, 1.5, 2.0):  # R = 1.0: the 6 face neighbours sit exactly ON the (strict) radius
+                a = oracle.knn_bruteforce(lattice, np.array(q, dtype=np.float64), k, R)
+                assert np.array_equal(a, Hc.knn(lattice, np.array(q, dtype=np.float64), k, R)), (q, k, R)
+    assert Hc.knn_fallbacks() > before  # the tie cases really went through the fallback
+    # coincident points (d2 == 0 keys are denormal bit patterns) and duplicates
+    dup = np.array([[0.0, 0, 0]] * 7 + [[1.0, 0, 0]] * 3)
+    for k in (1, 5, 8):
+        assert np.array_equal(oracle.knn_bruteforce(dup, np.zeros(3), k, 2.0), Hc.knn(dup, np.zeros(3), k, 2.0))
+    # non-finite target coordinates never enter a result
+    bad = np.array([[0.0, 0, 0], [np.nan, 0, 0], [0.5, 0, 0], [np.inf, 0, 0], [0.25, 0, 0]])
+    assert np.array_equal(Hc.knn(bad, np.zeros(3), 5, -1.0)[:3], [0, 4, 2])
+    assert Hc.knn_mismatches() == 0
 
 
 @pytest.mark.parametrize("case", K.REGISTRATION_CASES, ids=lambda c: c["name"])
@@ -135,6 +161,7 @@ def test_registration_math_on_reference_scenes(oracle, case):
         prm.max_iterations = case["max_iter"]
     po, to, io = oracle.register_features(src_e, src_p, tgt_e, tgt_p, case["init"], prm)
     ph, th, ih = Hc.register(src_e, src_p, tgt_e, tgt_p, case["init"], Hc.conv_reg(prm))
+    assert Hc.knn_mismatches() == 0  # keyed fast path == exact collector on every query of the run
     assert (to, io) == (th, ih)
     rot, trans = _pdiff(oracle, po, ph)
     assert rot < 1e-5 and trans < 1e-5  # the north-star tolerance; observed ~1e-16
@@ -149,7 +176,10 @@ def test_registration_math_on_synthetic_pair(oracle):
     ea, pa = oracle.extract_features(A, H, W, 1.0, 120.0)
     eb, pb = oracle.extract_features(B, H, W, 1.0, 120.0)
     po, to, io = oracle.register_features(B[eb], B[pb], A[ea], A[pa])
+    fb0 = Hc.knn_fallbacks()
     ph, th, ih = Hc.register(B[eb], B[pb], A[ea], A[pa])
+    assert Hc.knn_mismatches() == 0
+    print('keyed kNN fallbacks on a noisy pair:', Hc.knn_fallbacks() - fb0)
     assert (to, io) == (th, ih)
     rot, trans = _pdiff(oracle, po, ph)
     assert rot < 1e-5 and trans < 1e-5

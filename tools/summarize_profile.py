@@ -105,6 +105,21 @@ def main():
         scopes = {k: v["launches"] for k, v in kern.items()}  # HIP-event scopes of that run (associate = kNN + fit, edge + plane)
         json.dump({"source": os.path.basename(src), "bench_config": cfg, "event_scopes": scopes, "kernels": out},
                   open(dst + "_pmc.json", "w"), indent=1)
+    # any further counter passes (pmc_x*): per-kernel average per dispatch
+    extra = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    for f in sorted(glob.glob(os.path.join(src, "pmc_x*", "*", "*_counter_collection.csv"))):
+        for r in csv.DictReader(open(f)):
+            a = extra[short(r["Kernel_Name"])][r["Counter_Name"]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    if extra:
+        ctrs = sorted({c for k in extra for c in extra[k]})
+        md += ["", "## Other counters (average per dispatch, one `--pmc` pass per set)", "",
+               "| kernel | " + " | ".join(ctrs) + " |", "|---|" + "---|" * len(ctrs)]
+        for k in sorted(extra):
+            if not re.search(r"knn|fit|select|compact|grid_build|curvature|sweep", k):
+                continue
+            md.append(f"| {k} | " + " | ".join(f"{extra[k][c][1] / extra[k][c][0]:.4g}" if c in extra[k] else "" for c in ctrs) + " |")
     open(dst + "_summary.md", "w").write("\n".join(md) + "\n")
     print("\n".join(md))
 
