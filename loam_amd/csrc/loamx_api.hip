@@ -189,6 +189,7 @@ int make_reg_config(loamx_ctx* ctx, const loamx_reg_params* r, RegConfig& C) {
   C.min_line_pts = (int)(r->min_line_fit_points > 64 ? 64 : r->min_line_fit_points);
   C.min_plane_pts = (int)(r->min_plane_fit_points > 64 ? 64 : r->min_plane_fit_points);
   C.r_edge = r->max_edge_neighbor_dist, C.r_plane = r->max_plane_neighbor_dist;
+  C.pass_edge = knn_radius_pass_max(C.r_edge), C.pass_plane = knn_radius_pass_max(C.r_plane);
   C.min_line_cond = r->min_line_condition_number, C.max_avg_plane_dist = r->max_avg_point_plane_dist;
   C.max_iterations = (uint32_t)r->max_iterations;
   C.rot_thresh = r->rotation_convergence_thresh, C.pos_thresh = r->position_convergence_thresh;
@@ -283,7 +284,7 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   ENSURE(ctx, WS_NN_P, (size_t)(1 + kMaxK) * np * ps * sizeof(uint32_t));
   ENSURE(ctx, WS_NEAREST_E, np * es * sizeof(uint32_t));
   ENSURE(ctx, WS_NEAREST_P, np * ps * sizeof(uint32_t));
-  ENSURE(ctx, WS_NASSOC, np * 2 * sizeof(uint32_t));
+  ENSURE(ctx, WS_NASSOC, np * 4 * sizeof(uint32_t));
   ENSURE(ctx, WS_STATE, np * sizeof(PairState));
   B.blocks_per_pair = (uint32_t)((es + ps + kSweepChunk - 1) / kSweepChunk);
   ENSURE(ctx, WS_PARTIALS, np * B.blocks_per_pair * kAccSize * sizeof(double));

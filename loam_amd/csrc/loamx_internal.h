@@ -36,6 +36,7 @@ struct RegConfig {
   int k_edge, k_plane;
   int min_line_pts, min_plane_pts;
   double r_edge, r_plane;
+  double pass_edge, pass_plane;  // knn_radius_pass_max(r_*): largest squared distance that passes the strict radius filter
   double min_line_cond, max_avg_plane_dist;
   uint32_t max_iterations;
   double rot_thresh, pos_thresh;
@@ -62,7 +63,8 @@ struct AssocBuffers {
   uint32_t* nn_plane;       // [1 + kMaxK][n_pairs * planar_stride]
   uint32_t* nearest_edge;   // [n_pairs * edge_stride]   nearest target index (detail capture)
   uint32_t* nearest_plane;  // [n_pairs * planar_stride]
-  uint32_t* n_assoc;  // [n_pairs][2] valid edge / plane associations of the current iteration
+  uint32_t* n_assoc;  // [n_pairs][4] valid edge / plane associations of the current iteration, then the
+                      // edge / plane queries its keyed k-NN left undecided
 };
 
 struct PairState {

@@ -19,6 +19,7 @@
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#include <math.h>
 #define LOAMX_HD __host__ __device__ __forceinline__
 #else
 #include <math.h>
@@ -93,6 +94,10 @@ LOAMX_HD int32_t grid_cell_coord(double v, double origin, double inv_h) {
   return (int32_t)c;
 }
 LOAMX_HD int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// cell_start[i] through a 32-bit byte offset from the (wave-uniform) table base
+LOAMX_HD uint32_t cell_start_at(const uint32_t* __restrict__ cell_start, uint32_t i) {
+  return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(cell_start) + (uint32_t)(i << 2));
+}
 // cell of a target point at build time (always inside the grid)
 LOAMX_HD uint32_t grid_cell_of_point(const GridDesc& g, Vec3 p) {
   const int32_t ix = clampi(grid_cell_coord(p.x, g.ox, g.inv_h), 0, g.nx - 1);
@@ -347,10 +352,13 @@ LOAMX_HD void knn_offer4(KnnKeys<KM>& c, int k, double d0, double d1, double d2,
 // (= entries left in the range, may exceed 4).
 template <class Coll>
 LOAMX_HD void knn_scan_batch(Coll& r, int k, Vec3 q, const GridPoint* __restrict__ sp, uint32_t p, uint32_t n) {
-  const GridPoint t0 = sp[p];
-  const GridPoint t1 = sp[p + 1];
-  const GridPoint t2 = sp[p + 2];
-  const GridPoint t3 = sp[p + 3];
+  // 32-bit byte offset from the (wave-uniform) set base: one VGPR of address per lane, the +32 / +64
+  // / +96 of the neighbours go into the instruction's immediate offset. Sets stay below 2^26 points.
+  const char* __restrict__ q0 = reinterpret_cast<const char*>(sp) + (uint32_t)(p << 5);
+  const GridPoint t0 = *reinterpret_cast<const GridPoint*>(q0);
+  const GridPoint t1 = *reinterpret_cast<const GridPoint*>(q0 + 32);
+  const GridPoint t2 = *reinterpret_cast<const GridPoint*>(q0 + 64);
+  const GridPoint t3 = *reinterpret_cast<const GridPoint*>(q0 + 96);
 #if defined(LOAMX_KNN_STATS)
   g_cand += n < 4u ? n : 4u;
 #endif
@@ -406,7 +414,7 @@ LOAMX_HD void knn_scan_row(const GridDesc& g, const uint32_t* __restrict__ cell_
 #if defined(LOAMX_KNN_STATS)
   g_rows++;
 #endif
-  knn_scan_range(r, k, q, sp, cell_start[row + xlo], cell_start[row + xhi + 1]);
+  knn_scan_range(r, k, q, sp, cell_start_at(cell_start, row + (uint32_t)xlo), cell_start_at(cell_start, row + (uint32_t)xhi + 1u));
 }
 
 template <int KM>
@@ -436,6 +444,21 @@ LOAMX_HD int32_t grid_outside_distance(const GridDesc& g, int32_t cx, int32_t cy
   return out > ez ? out : ez;
 }
 
+// The strict radius filter of kdtree.cpp:25 is sqrt(d2) < max_dist with a correctly rounded sqrt,
+// which is monotone: there is a largest double d2 that passes. The host computes it once per call
+// (RegConfig) so that the keyed collector decides the filter with two compares and no sqrt.
+#if defined(__HIPCC__)
+__host__
+#endif
+inline double knn_radius_pass_max(double max_dist) {
+  if (!(max_dist > 0.0)) return kDblMax;  // filter disabled
+  double x = max_dist * max_dist;
+  if (!(x <= kDblMax)) return kDblMax;
+  while (x > 0.0 && !(sqrt(x) < max_dist)) x = nextafter(x, 0.0);
+  while (x < kDblMax && sqrt(nextafter(x, kDblMax)) < max_dist) x = nextafter(x, kDblMax);
+  return sqrt(x) < max_dist ? x : -1.0;  // -1: nothing passes (max_dist below sqrt of the smallest double)
+}
+
 // radius^2 bound used for pruning: points at distance >= max_dist are dropped by the radius filter anyway
 LOAMX_HD double knn_radius_bound(double max_dist) { return max_dist > 0.0 ? max_dist * max_dist * (1.0 + 1e-12) : kDblMax; }
 
@@ -463,8 +486,8 @@ LOAMX_HD void knn_rounds(const GridDesc& g, const uint32_t* __restrict__ cell_st
         const int32_t iy = cy + (j % 3) - 1, iz = cz + (j / 3) - 1;
         const bool ok = xa <= xb && iy >= 0 && iy <= g.ny - 1 && iz >= 0 && iz <= g.nz - 1;
         const uint32_t row = ok ? (uint32_t)((iz * g.ny + iy) * g.nx) : 0u;
-        rb[j] = ok ? cell_start[row + xa] : 0u;
-        re[j] = ok ? cell_start[row + xb + 1] : 0u;
+        rb[j] = ok ? cell_start_at(cell_start, row + (uint32_t)xa) : 0u;
+        re[j] = ok ? cell_start_at(cell_start, row + (uint32_t)xb + 1u) : 0u;
       }
       int nrow = 0;
 #pragma unroll
@@ -570,7 +593,7 @@ LOAMX_HD int knn_finish(KnnResult<KM>& r, int k, double max_dist) {
 // truncated distance straddles the radius. pos[i] is the position held by slot i; neighbour j of the
 // result is slot (KM - k) + j.
 template <int KM>
-LOAMX_HD int knn_keys_finish(const KnnKeys<KM>& c, int k, double max_dist, uint32_t pos[KM]) {
+LOAMX_HD int knn_keys_finish(const KnnKeys<KM>& c, int k, double pass_max, uint32_t pos[KM]) {
   int kept = 0;
   bool undecided = false, open = true;
 #pragma unroll
@@ -583,11 +606,11 @@ LOAMX_HD int knn_keys_finish(const KnnKeys<KM>& c, int k, double max_dist, uint3
     if (real && open) {
       const double lo = knn_key_join(knn_key_hi(a), knn_key_lo(a) & ~c.mask);  // lo <= d2 <= hi
       const double hi = knn_key_join(knn_key_hi(a), knn_key_lo(a) | c.mask);
-      if (max_dist <= 0.0 || sqrt(hi) < max_dist) {
+      if (hi <= pass_max) {  // pass_max = knn_radius_pass_max(max_dist): d2 <= pass_max <=> sqrt(d2) < max_dist
         kept++;
       } else {
         open = false;
-        if (sqrt(lo) < max_dist) undecided = true;
+        if (lo <= pass_max) undecided = true;
       }
     }
   }
@@ -611,14 +634,14 @@ LOAMX_HD int knn_search(const GridDesc& g, const uint32_t* __restrict__ cell_sta
   return knn_finish(r, k, max_dist);
 }
 
-// Same result as knn_search (positions only), through the keyed collector; the exact collector
-// re-runs the rare undecided query. Neighbour j (ascending) is pos[(KM - k) + j] — the keyed
+// The keyed search on its own: number of neighbours kept, or -1 when the keys cannot decide the
+// query (the caller then runs knn_search). Neighbour j (ascending) is pos[(KM - k) + j] — the keyed
 // collector keeps its k-th key in a fixed register, which shifts the list by KM - k.
-// `fallbacks`, when given, counts the re-runs.
+// pass_max = knn_radius_pass_max(max_dist), computed once on the host.
 template <int KM>
-LOAMX_HD int knn_search_positions(const GridDesc& g, const uint32_t* __restrict__ cell_start,
-                                  const GridPoint* __restrict__ sp, Vec3 q, int k, double max_dist, uint32_t pos[KM],
-                                  uint32_t* row_scratch, int row_stride, uint32_t* fallbacks = nullptr) {
+LOAMX_HD int knn_search_keyed(const GridDesc& g, const uint32_t* __restrict__ cell_start, const GridPoint* __restrict__ sp,
+                              Vec3 q, int k, double max_dist, double pass_max, uint32_t pos[KM], uint32_t* row_scratch,
+                              int row_stride) {
 #pragma unroll
   for (int j = 0; j < KM; j++) pos[j] = 0;
   if (g.n_points == 0 || k <= 0) return 0;
@@ -631,21 +654,24 @@ LOAMX_HD int knn_search_positions(const GridDesc& g, const uint32_t* __restrict_
   KnnKeys<KM> c;
   knn_init(c, k, g.n_points);
   knn_rounds(g, cell_start, sp, q, k, max_dist, cx, cy, cz, c, out > 1 ? out : 1, row_scratch, row_stride);
-  int kept = knn_keys_finish(c, k, max_dist, pos);
+  return knn_keys_finish(c, k, pass_max, pos);
+}
+
+// Keyed search with the exact collector re-running the rare undecided query (the kernels do the
+// re-run in a second launch, associate_knn_exact_kernel). Same shifted layout of pos.
+// `fallbacks`, when given, counts the re-runs.
+template <int KM>
+LOAMX_HD int knn_search_positions(const GridDesc& g, const uint32_t* __restrict__ cell_start,
+                                  const GridPoint* __restrict__ sp, Vec3 q, int k, double max_dist, double pass_max,
+                                  uint32_t pos[KM], uint32_t* row_scratch, int row_stride, uint32_t* fallbacks = nullptr) {
+  int kept = knn_search_keyed<KM>(g, cell_start, sp, q, k, max_dist, pass_max, pos, row_scratch, row_stride);
   if (kept < 0) {
     if (fallbacks) (*fallbacks)++;
+    if (k > KM) k = KM;
     KnnResult<KM> r;
-    knn_init(r);
-    knn_rounds(g, cell_start, sp, q, k, max_dist, cx, cy, cz, r, out > 1 ? out : 1, row_scratch, row_stride);
-    kept = knn_finish(r, k, max_dist);
-#pragma unroll
-    for (int i = 0; i < KM; i++) {
-      uint32_t v = 0;
-#pragma unroll
-      for (int j = 0; j < KM; j++)
-        if (j == i - (KM - k)) v = r.pos[j];
-      pos[i] = v;
-    }
+    kept = knn_search(g, cell_start, sp, q, k, max_dist, r, row_scratch, row_stride);
+    for (int j = 0; j < KM; j++) pos[j] = 0;
+    for (int j = 0; j < k; j++) pos[(KM - k) + j] = r.pos[j];
   }
   return kept;
 }

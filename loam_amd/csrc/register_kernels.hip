@@ -163,8 +163,10 @@ __global__ void state_init_kernel(RegBatch B, RegConfig C) {
   S.iterations = 0;
   S.first_sweep = 0;
   S.lm.active = 0;
-  B.assoc.n_assoc[2 * pair] = 0;
-  B.assoc.n_assoc[2 * pair + 1] = 0;
+  B.assoc.n_assoc[4 * pair] = 0;
+  B.assoc.n_assoc[4 * pair + 1] = 0;
+  B.assoc.n_assoc[4 * pair + 2] = 0;
+  B.assoc.n_assoc[4 * pair + 3] = 0;
 }
 
 constexpr int kAssocThreads = 256;
@@ -218,13 +220,50 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_kn
   const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
   __shared__ uint32_t s_rows[18 * kAssocThreads];  // per-thread list of non-empty rows, [word][thread] (conflict free)
   uint32_t pos[KM];
-  const int kept = knn_search_positions<KM>(g, cs, sp, p, PLANE ? C.k_plane : C.k_edge, PLANE ? C.r_plane : C.r_edge, pos,
-                                            s_rows + threadIdx.x, kAssocThreads);
+  const int kept = knn_search_keyed<KM>(g, cs, sp, p, PLANE ? C.k_plane : C.k_edge, PLANE ? C.r_plane : C.r_edge,
+                                        PLANE ? C.pass_plane : C.pass_edge, pos, s_rows + threadIdx.x, kAssocThreads);
   const size_t field = B.n_pairs * stride, slot = pair * stride + i;
   uint32_t* __restrict__ nn = PLANE ? B.assoc.nn_plane : B.assoc.nn_edge;  // [1 + KM][n_pairs * stride]
+  nn[slot] = (uint32_t)kept;  // 0xFFFFFFFF: undecided by the keys, left to associate_knn_exact_kernel
+  if (kept < 0) atomicAdd(&B.assoc.n_assoc[4 * pair + (PLANE ? 3 : 2)], 1u);
+#pragma unroll
+  for (int j = 0; j < KM; j++) nn[(1 + j) * field + slot] = pos[j];  // neighbour j is slot (KM - k) + j
+}
+
+// Second pass of the k-NN: the queries the keyed collector could not decide (exact distance ties,
+// a truncated distance straddling the radius) are searched again with the exact (d2, index)
+// collector. Workgroups of pairs without such queries leave after one scalar load.
+template <bool PLANE, int KM>
+__global__ __launch_bounds__(kAssocThreads) void associate_knn_exact_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
+  size_t pair;
+  uint32_t chunk;
+  if (!xcd_pair_map(blockIdx.x, blocks_per_pair, B.n_pairs, pair, chunk)) return;
+  const PairState& S = B.state[pair];
+  if (!S.active) return;                                              // uniform per workgroup
+  if (B.assoc.n_assoc[4 * pair + (PLANE ? 3 : 2)] == 0u) return;      // uniform per workgroup
+  const uint32_t i = chunk * kAssocThreads + threadIdx.x;
+  const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
+  const uint32_t n_src = PLANE ? B.n_src_planar[pair * B.in_pitch] : B.n_src_edge[pair * B.in_pitch];
+  if (i >= n_src || i >= stride) return;
+  const size_t field = B.n_pairs * stride, slot = pair * stride + i;
+  uint32_t* __restrict__ nn = PLANE ? B.assoc.nn_plane : B.assoc.nn_edge;
+  if (nn[slot] != 0xFFFFFFFFu) return;
+  const GridSet& gs = PLANE ? B.grid_plane : B.grid_edge;
+  const GridSet& src_gs = PLANE ? B.src_grid_plane : B.src_grid_edge;
+  const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
+  const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));
+  const GridDesc g = gs.desc[pair];
+  const uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
+  const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
+  __shared__ uint32_t s_rows[18 * kAssocThreads];
+  int k = PLANE ? C.k_plane : C.k_edge;
+  k = k < KM ? k : KM;
+  KnnResult<KM> r;
+  const int kept = knn_search(g, cs, sp, p, k, PLANE ? C.r_plane : C.r_edge, r, s_rows + threadIdx.x, kAssocThreads);
   nn[slot] = (uint32_t)kept;
 #pragma unroll
-  for (int j = 0; j < KM; j++) nn[(1 + j) * field + slot] = pos[j];
+  for (int j = 0; j < KM; j++)
+    if (j < k) nn[(size_t)(1 + (KM - k) + j) * field + slot] = r.pos[j];
 }
 
 template <bool PLANE, int KM>
@@ -292,7 +331,7 @@ __global__ __launch_bounds__(kAssocThreads) void associate_fit_kernel(RegBatch B
   if (threadIdx.x == 0) {
     uint32_t c = 0;
     for (int w = 0; w < kAssocThreads / 64; w++) c += s_count[w];
-    if (c) atomicAdd(&B.assoc.n_assoc[2 * pair + (PLANE ? 1 : 0)], c);
+    if (c) atomicAdd(&B.assoc.n_assoc[4 * pair + (PLANE ? 1 : 0)], c);
   }
 }
 
@@ -301,9 +340,11 @@ __global__ void lm_begin_kernel(RegBatch B, RegConfig C, uint32_t iteration) {
   if (pair >= B.n_pairs) return;
   PairState& S = B.state[pair];
   if (!S.active) return;
-  const uint32_t ne = B.assoc.n_assoc[2 * pair], np = B.assoc.n_assoc[2 * pair + 1];
-  B.assoc.n_assoc[2 * pair] = 0;
-  B.assoc.n_assoc[2 * pair + 1] = 0;
+  const uint32_t ne = B.assoc.n_assoc[4 * pair], np = B.assoc.n_assoc[4 * pair + 1];
+  B.assoc.n_assoc[4 * pair] = 0;
+  B.assoc.n_assoc[4 * pair + 1] = 0;
+  B.assoc.n_assoc[4 * pair + 2] = 0;
+  B.assoc.n_assoc[4 * pair + 3] = 0;
   if ((uint64_t)ne + np < C.min_associations) {  // registration-inl.h:45-48
     S.termination = LOAMX_INSUFFICIENT_ASSOCIATIONS;
     S.active = 0;
@@ -498,6 +539,7 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   do {                                                                                                    \
     const dim3 grid_((unsigned)(pair_groups * 8 * (nblk)));                                               \
     hipLaunchKernelGGL((associate_knn_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, s, B, C, (nblk));  \
+    hipLaunchKernelGGL((associate_knn_exact_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, s, B, C, (nblk));  \
     hipLaunchKernelGGL((associate_fit_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, s, B, C, (nblk));  \
   } while (0)
   if (be) {

@@ -246,7 +246,8 @@ static uint64_t g_knn_fallbacks = 0, g_knn_mismatch = 0;
 template <int KM>
 static int knn_both(const HostGrid& G, Vec3 q, int k, double max_dist, uint32_t pos[KM]) {
   uint32_t rows[18], fb = 0;
-  const int kept = knn_search_positions<KM>(G.g, G.cell_start.data(), G.sp.data(), q, k, max_dist, pos, rows, 1, &fb);
+  const int kept = knn_search_positions<KM>(G.g, G.cell_start.data(), G.sp.data(), q, k, max_dist, knn_radius_pass_max(max_dist), pos,
+                                            rows, 1, &fb);
   g_knn_fallbacks += fb;
   KnnResult<KM> r;
   const int kept_exact = knn_search(G.g, G.cell_start.data(), G.sp.data(), q, k, max_dist, r, rows, 1);
