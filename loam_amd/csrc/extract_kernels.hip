@@ -134,6 +134,7 @@ __global__ __launch_bounds__(WAVES * 64) void select_kernel(const double* __rest
   }
   wave_lds_sync();
   const uint32_t line_base = (uint32_t)(line % P.H) * P.W;
+  const uint32_t idx_mask = W <= 2 ? 1u : (0xFFFFFFFFu >> __clz(W - 1));  // index-in-line bits of the sort keys
   for (uint32_t s = 0; s < P.S; s++) {
     const int start = (int)(s * P.pps);
     const int end = (s == P.S - 1) ? W : start + (int)P.pps;  // features-inl.h:31-35
@@ -177,7 +178,8 @@ __device__ __forceinline__ bool before_or_invalid(double ca, int32_t ia, double 
 template <int R, bool EDGE>
 __device__ __forceinline__ uint32_t mis_pass(int lane, int CH, int base, int start, int end, uint64_t& V, uint64_t T,
                                              const uint64_t gt[R], const double* s_c, double* m_c, int32_t* m_i,
-                                             uint32_t cap, uint32_t line_base, uint32_t* __restrict__ stage) {
+                                             uint32_t cap, uint32_t line_base, uint32_t* __restrict__ stage,
+                                             uint32_t idx_mask) {
   const uint64_t cm = low_mask(CH);
   int lo = start - base, hi = end - base;
   lo = lo < 0 ? 0 : lo;
@@ -215,17 +217,54 @@ __device__ __forceinline__ uint32_t mis_pass(int lane, int CH, int base, int sta
   double c = (uint32_t)lane < total ? m_c[lane] : 0.0;
   int32_t i = (uint32_t)lane < total ? m_i[lane] : -1;
   wave_lds_sync();
-  // 64-lane bitonic sort into the walk order of the reference (edge: descending, planar: ascending)
+  // Sort the picks into the walk order of the reference (edge: descending, planar: ascending by
+  // (curvature, index)) with a bitonic network over the next power of two >= total lanes.
+  // Fast path: curvature and index folded into one double (low index bits replace low mantissa
+  // bits; edge keys negated, padding = +inf), so a compare-exchange is v_min_f64 / v_max_f64 on one
+  // shuffled value. Exact unless two picks share a truncated curvature (or a curvature is not
+  // finite): then the network is re-run on the exact (curvature, index) pairs.
+  if (total > 1) {
+    const uint32_t n2 = total <= 2 ? 2u : (1u << (32 - __clz((int)total - 1)));
+    const bool finite = i < 0 || c <= 1.7976931348623157e308;
+    double key = __hiloint2double(__double2hiint(c), (int)(((uint32_t)__double2loint(c) & ~idx_mask) | (uint32_t)i));
+    key = EDGE ? -key : key;
+    key = i < 0 ? __builtin_huge_val() : key;
+    if (__ballot(!finite) == 0) {
 #pragma unroll
-  for (int k = 2; k <= 64; k <<= 1) {
+      for (int k = 2; k <= 64; k <<= 1) {
+        if ((uint32_t)k > n2) break;  // wave-uniform
 #pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const double oc = __shfl_xor(c, j);
-      const int32_t oi = __shfl_xor(i, j);
-      const bool keep_first = ((lane & j) == 0) == ((lane & k) == 0);
-      const bool other_first = before_or_invalid<EDGE>(oc, oi, c, i);
-      const bool me_first = before_or_invalid<EDGE>(c, i, oc, oi);
-      if (keep_first ? other_first : me_first) c = oc, i = oi;
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          const double other = __shfl_xor(key, j);
+          const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+          double mn, mx;
+          asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(key), "v"(other));
+          asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(key), "v"(other));
+          key = keep_min ? mn : mx;
+        }
+      }
+    }
+    // neighbours in the sorted order with the same truncated curvature: undecided by the keys
+    const double nxt = __shfl_down(key, 1);
+    const bool both = (uint32_t)lane + 1 < total;
+    const bool same = both && __double2hiint(key) == __double2hiint(nxt) &&
+                      (((uint32_t)__double2loint(key) ^ (uint32_t)__double2loint(nxt)) & ~idx_mask) == 0u;
+    if (__ballot(!finite) != 0 || __ballot(same) != 0) {
+#pragma unroll 1
+      for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll 1
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          const double oc = __shfl_xor(c, j);
+          const int32_t oi = __shfl_xor(i, j);
+          const bool keep_first = ((lane & j) == 0) == ((lane & k) == 0);
+          const bool other_first = before_or_invalid<EDGE>(oc, oi, c, i);
+          const bool me_first = before_or_invalid<EDGE>(c, i, oc, oi);
+          if (keep_first ? other_first : me_first) c = oc, i = oi;
+        }
+      }
+    } else {
+      i = (uint32_t)lane < total ? (int32_t)((uint32_t)__double2loint(key) & idx_mask) : -1;
+      c = (uint32_t)lane < total ? s_c[i < 0 ? 0 : i] : 0.0;
     }
   }
   const uint32_t kept = total < cap ? total : cap;  // features-inl.h:155/:177: at most max+1 picks
@@ -287,14 +326,15 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
     gt[d - 1] = g;
   }
   const uint32_t line_base = (uint32_t)(line % P.H) * P.W;
+  const uint32_t idx_mask = W <= 2 ? 1u : (0xFFFFFFFFu >> __clz(W - 1));  // index-in-line bits of the sort keys
   for (uint32_t s = 0; s < P.S; s++) {
     const int start = (int)(s * P.pps);
     const int end = (s == P.S - 1) ? W : start + (int)P.pps;  // features-inl.h:31-35
     const size_t group = line * P.S + s;
     const uint32_t ne = mis_pass<R, true>(lane, CH, base, start, end, V, ET, gt, s_c, m_c, m_i, P.cap_edge, line_base,
-                                          st.edge_stage + group * P.cap_edge);
+                                          st.edge_stage + group * P.cap_edge, idx_mask);
     const uint32_t npl = mis_pass<R, false>(lane, CH, base, start, end, V, PT, gt, s_c, m_c, m_i, P.cap_planar,
-                                            line_base, st.planar_stage + group * P.cap_planar);
+                                            line_base, st.planar_stage + group * P.cap_planar, idx_mask);
     if (lane == 0) {
       st.edge_cnt[group] = ne;
       st.planar_cnt[group] = npl;

@@ -10,6 +10,10 @@
 #include <algorithm>
 #include <vector>
 
+// search statistics (candidates / rows visited) for tools/knn_stats.py
+#define LOAMX_KNN_STATS 1
+static uint64_t g_cand = 0, g_rows = 0;
+
 #include "../../include/loamx.h"
 #include "../../loam_amd/csrc/extract_math.h"
 #include "../../loam_amd/csrc/reg_math.h"
@@ -270,6 +274,24 @@ uint64_t hostcheck_knn(const double* pts, uint64_t n, const double q[3], uint64_
                           : knn_both<8>(G, v3(q[0], q[1], q[2]), (int)k, max_dist, pos);
   for (int j = 0; j < kept; j++) idx_out[j] = G.sp[pos[j]].orig;
   return (uint64_t)kept;
+}
+
+// per-query search statistics of the keyed path (analysis only): candidates and rows visited;
+// grid_out = {nx, ny, nz, h}
+void hostcheck_knn_stats(const double* pts, uint64_t n, const double* queries, uint64_t nq, uint64_t k, double max_dist,
+                         uint32_t* cand_out, uint32_t* rows_out, double grid_out[4]) {
+  HostGrid G;
+  build_grid(pts, (uint32_t)n, max_dist, G);
+  grid_out[0] = G.g.nx, grid_out[1] = G.g.ny, grid_out[2] = G.g.nz, grid_out[3] = G.g.h;
+  const double pass = knn_radius_pass_max(max_dist);
+  for (uint64_t i = 0; i < nq; i++) {
+    uint32_t rows[18], pos[8];
+    g_cand = g_rows = 0;
+    const Vec3 q = v3(queries[3 * i], queries[3 * i + 1], queries[3 * i + 2]);
+    if (k <= 5) knn_search_keyed<5>(G.g, G.cell_start.data(), G.sp.data(), q, (int)k, max_dist, pass, pos, rows, 1);
+    else knn_search_keyed<8>(G.g, G.cell_start.data(), G.sp.data(), q, (int)k, max_dist, pass, pos, rows, 1);
+    cand_out[i] = (uint32_t)g_cand, rows_out[i] = (uint32_t)g_rows;
+  }
 }
 
 double hostcheck_fit_plane(const double* pts, uint64_t k, double out[4]) {
