@@ -54,6 +54,7 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
   const double* __restrict__ pts = pts_base + pair * in_pitch * stride * 3;
 
   double lx = kDblMax, ly = kDblMax, lz = kDblMax, hx = -kDblMax, hy = -kDblMax, hz = -kDblMax;
+#pragma unroll 4
   for (uint32_t i = tid; i < n; i += kBuildThreads) {
     const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
     lx = fmin(lx, x), ly = fmin(ly, y), lz = fmin(lz, z);
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
     const uint32_t nc = ncell - c_lo < kGridLdsCells ? ncell - c_lo : kGridLdsCells;
     for (uint32_t c = tid; c < nc; c += kBuildThreads) s_cells[c] = 0;
     __syncthreads();
+#pragma unroll 4
     for (uint32_t i = tid; i < n; i += kBuildThreads) {
       const Vec3 pt = v3(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]);
       const uint32_t cell = (ORDERED ? grid_morton_of_point(g, pt) : grid_cell_of_point(g, pt)) - c_lo;
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
       run += cnt;
     }
     __syncthreads();
+#pragma unroll 4
     for (uint32_t i = tid; i < n; i += kBuildThreads) {
       const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
       const uint32_t cell = (ORDERED ? grid_morton_of_point(g, v3(x, y, z)) : grid_cell_of_point(g, v3(x, y, z))) - c_lo;
@@ -146,6 +149,7 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
       const uint32_t cell = grid_morton_of_point(g, v3(e.x, e.y, e.z));
       const uint32_t b = cell ? s_cells[cell - 1] : 0u, en = s_cells[cell];
       uint32_t rank = 0;
+#pragma unroll 4
       for (uint32_t j = b; j < en; j++) rank += dst[j].orig < e.orig ? 1u : 0u;
       sp[b + rank] = e;
     }
@@ -234,36 +238,41 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_kn
 // a truncated distance straddling the radius) are searched again with the exact (d2, index)
 // collector. Workgroups of pairs without such queries leave after one scalar load.
 template <bool PLANE, int KM>
-__global__ __launch_bounds__(kAssocThreads) void associate_knn_exact_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
+__global__ __launch_bounds__(kAssocThreads) void associate_knn_exact_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair,
+                                                                           uint32_t chunks_per_pair) {
   size_t pair;
-  uint32_t chunk;
-  if (!xcd_pair_map(blockIdx.x, blocks_per_pair, B.n_pairs, pair, chunk)) return;
+  uint32_t chunk0;
+  if (!xcd_pair_map(blockIdx.x, blocks_per_pair, B.n_pairs, pair, chunk0)) return;
   const PairState& S = B.state[pair];
   if (!S.active) return;                                              // uniform per workgroup
   if (B.assoc.n_assoc[4 * pair + (PLANE ? 3 : 2)] == 0u) return;      // uniform per workgroup
-  const uint32_t i = chunk * kAssocThreads + threadIdx.x;
+  __shared__ uint32_t s_rows[18 * kAssocThreads];
   const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
   const uint32_t n_src = PLANE ? B.n_src_planar[pair * B.in_pitch] : B.n_src_edge[pair * B.in_pitch];
-  if (i >= n_src || i >= stride) return;
-  const size_t field = B.n_pairs * stride, slot = pair * stride + i;
+  const size_t field = B.n_pairs * stride;
   uint32_t* __restrict__ nn = PLANE ? B.assoc.nn_plane : B.assoc.nn_edge;
-  if (nn[slot] != 0xFFFFFFFFu) return;
   const GridSet& gs = PLANE ? B.grid_plane : B.grid_edge;
   const GridSet& src_gs = PLANE ? B.src_grid_plane : B.src_grid_edge;
-  const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
-  const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));
   const GridDesc g = gs.desc[pair];
   const uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
   const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
-  __shared__ uint32_t s_rows[18 * kAssocThreads];
   int k = PLANE ? C.k_plane : C.k_edge;
   k = k < KM ? k : KM;
-  KnnResult<KM> r;
-  const int kept = knn_search(g, cs, sp, p, k, PLANE ? C.r_plane : C.r_edge, r, s_rows + threadIdx.x, kAssocThreads);
-  nn[slot] = (uint32_t)kept;
+  // a few workgroups per pair walk all of its query chunks (undecided queries are rare)
+  for (uint32_t chunk = chunk0; chunk < chunks_per_pair; chunk += blocks_per_pair) {
+    const uint32_t i = chunk * kAssocThreads + threadIdx.x;
+    if (i >= n_src || i >= stride) continue;
+    const size_t slot = pair * stride + i;
+    if (nn[slot] != 0xFFFFFFFFu) continue;
+    const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
+    const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));
+    KnnResult<KM> r;
+    const int kept = knn_search(g, cs, sp, p, k, PLANE ? C.r_plane : C.r_edge, r, s_rows + threadIdx.x, kAssocThreads);
+    nn[slot] = (uint32_t)kept;
 #pragma unroll
-  for (int j = 0; j < KM; j++)
-    if (j < k) nn[(size_t)(1 + (KM - k) + j) * field + slot] = r.pos[j];
+    for (int j = 0; j < KM; j++)
+      if (j < k) nn[(size_t)(1 + (KM - k) + j) * field + slot] = r.pos[j];
+  }
 }
 
 template <bool PLANE, int KM>
@@ -539,7 +548,9 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   do {                                                                                                    \
     const dim3 grid_((unsigned)(pair_groups * 8 * (nblk)));                                               \
     hipLaunchKernelGGL((associate_knn_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, s, B, C, (nblk));  \
-    hipLaunchKernelGGL((associate_knn_exact_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, s, B, C, (nblk));  \
+    const uint32_t xblk_ = (nblk) < 2u ? (nblk) : 2u;                                                      \
+    hipLaunchKernelGGL((associate_knn_exact_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * xblk_)),  \
+                       dim3(kAssocThreads), 0, s, B, C, xblk_, (nblk));                                   \
     hipLaunchKernelGGL((associate_fit_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, s, B, C, (nblk));  \
   } while (0)
   if (be) {

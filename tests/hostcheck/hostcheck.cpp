@@ -12,7 +12,7 @@
 
 // search statistics (candidates / rows visited) for tools/knn_stats.py
 #define LOAMX_KNN_STATS 1
-static uint64_t g_cand = 0, g_rows = 0;
+static uint64_t g_cand = 0, g_rows = 0, g_general = 0;
 
 #include "../../include/loamx.h"
 #include "../../loam_amd/csrc/extract_math.h"
@@ -279,18 +279,31 @@ uint64_t hostcheck_knn(const double* pts, uint64_t n, const double q[3], uint64_
 // per-query search statistics of the keyed path (analysis only): candidates and rows visited;
 // grid_out = {nx, ny, nz, h}
 void hostcheck_knn_stats(const double* pts, uint64_t n, const double* queries, uint64_t nq, uint64_t k, double max_dist,
-                         uint32_t* cand_out, uint32_t* rows_out, double grid_out[4]) {
+                         uint32_t* cand_out, uint32_t* rows_out, double grid_out[4], uint32_t* block_out) {
   HostGrid G;
   build_grid(pts, (uint32_t)n, max_dist, G);
   grid_out[0] = G.g.nx, grid_out[1] = G.g.ny, grid_out[2] = G.g.nz, grid_out[3] = G.g.h;
   const double pass = knn_radius_pass_max(max_dist);
   for (uint64_t i = 0; i < nq; i++) {
     uint32_t rows[18], pos[8];
-    g_cand = g_rows = 0;
+    g_cand = g_rows = g_general = 0;
     const Vec3 q = v3(queries[3 * i], queries[3 * i + 1], queries[3 * i + 2]);
     if (k <= 5) knn_search_keyed<5>(G.g, G.cell_start.data(), G.sp.data(), q, (int)k, max_dist, pass, pos, rows, 1);
     else knn_search_keyed<8>(G.g, G.cell_start.data(), G.sp.data(), q, (int)k, max_dist, pass, pos, rows, 1);
-    cand_out[i] = (uint32_t)g_cand, rows_out[i] = (uint32_t)g_rows;
+    cand_out[i] = (uint32_t)g_cand, rows_out[i] = (uint32_t)g_rows | ((uint32_t)g_general << 16);
+    // points in the 3x3x3 block of cells around the query (known before the candidate loop starts)
+    const int32_t cx = grid_cell_coord(q.x, G.g.ox, G.g.inv_h), cy = grid_cell_coord(q.y, G.g.oy, G.g.inv_h);
+    const int32_t cz = grid_cell_coord(q.z, G.g.oz, G.g.inv_h);
+    uint32_t blockpts = 0;
+    for (int dz = -1; dz <= 1; dz++)
+      for (int dy = -1; dy <= 1; dy++) {
+        const int32_t iy = cy + dy, iz = cz + dz;
+        const int32_t xa = std::max(cx - 1, 0), xb = std::min(cx + 1, G.g.nx - 1);
+        if (iy < 0 || iy >= G.g.ny || iz < 0 || iz >= G.g.nz || xa > xb) continue;
+        const uint32_t row = (uint32_t)((iz * G.g.ny + iy) * G.g.nx);
+        blockpts += (G.cell_start[row + xb + 1] - G.cell_start[row + xa]);
+      }
+    block_out[i] = blockpts;
   }
 }
 

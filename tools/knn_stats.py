@@ -32,10 +32,12 @@ def main():
         cand = np.zeros(len(src), np.uint32)
         rows = np.zeros(len(src), np.uint32)
         grid = np.zeros(4)
+        blockpts = np.zeros(len(src), np.uint32)
         lib.hostcheck_knn_stats(tgt.ctypes.data_as(C.POINTER(C.c_double)), C.c_uint64(len(tgt)),
                                 src.ctypes.data_as(C.POINTER(C.c_double)), C.c_uint64(len(src)), C.c_uint64(k),
                                 C.c_double(R), cand.ctypes.data_as(C.POINTER(C.c_uint32)),
-                                rows.ctypes.data_as(C.POINTER(C.c_uint32)), grid.ctypes.data_as(C.POINTER(C.c_double)))
+                                rows.ctypes.data_as(C.POINTER(C.c_uint32)), grid.ctypes.data_as(C.POINTER(C.c_double)),
+                                blockpts.ctypes.data_as(C.POINTER(C.c_uint32)))
         print(f"{name}: {len(tgt)} targets, {len(src)} queries, grid {grid[:3].astype(int)} h={grid[3]:.3f} R={R}")
         print("  candidates/query: mean %.1f median %d p90 %d p99 %d max %d" % (
             cand.mean(), np.median(cand), np.percentile(cand, 90), np.percentile(cand, 99), cand.max()))
@@ -60,6 +62,13 @@ def main():
             nb = len(b) // blk
             bb = np.sort(b[: nb * blk].reshape(nb, blk), axis=1).reshape(-1, 64)
             print("  sorted inside blocks of %d: utilisation %.2f (wave max mean %.1f)" % (blk, bb.mean() / bb.max(1).mean(), bb.max(1).mean()))
+        for blk in (256, 1024):  # same, ordered by a proxy known before the loop: points in the 3x3x3 block
+            nb = len(b) // blk
+            pr = blockpts[order][: nb * blk].reshape(nb, blk)
+            idx = np.argsort(pr, axis=1, kind="stable")
+            bb = np.take_along_axis(b[: nb * blk].reshape(nb, blk), idx, axis=1).reshape(-1, 64)
+            print("  ordered by block population inside blocks of %d: utilisation %.2f (wave max mean %.1f)" % (
+                blk, bb.mean() / bb.max(1).mean(), bb.max(1).mean()))
         bs = np.sort(b)[: nw * 64].reshape(nw, 64)
         print("  (if queries were sorted by work: utilisation %.2f)" % (bs.mean() / bs.max(1).mean()))
 
