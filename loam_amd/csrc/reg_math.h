@@ -133,6 +133,12 @@ LOAMX_HD void grid_choose(GridDesc& g, Vec3 lo, Vec3 hi, uint32_t n, double max_
   if (h_dense > 0.0 && (h <= 0.0 || h_dense < h)) h = h_dense;
   if (!(h > 0.0)) h = 1.0;
   if (max_dist > 0.0 && h < 1e-3 * max_dist) h = 1e-3 * max_dist;
+  // sparse sets: no more than ~16 cells per point (a table far larger than the set costs build time and
+  // sends most queries through several rounds of empty cells)
+  {
+    const double sparse_cap = 16.0 * (double)n > 4096.0 ? 16.0 * (double)n : 4096.0;
+    if (sparse_cap < (double)cells_cap) cells_cap = (uint32_t)sparse_cap;
+  }
   int32_t nx = 1, ny = 1, nz = 1;
   for (int it = 0; it < 400; it++) {
     const double fx = floor(ex / h), fy = floor(ey / h), fz = floor(ez / h);
@@ -147,19 +153,22 @@ LOAMX_HD void grid_choose(GridDesc& g, Vec3 lo, Vec3 hi, uint32_t n, double max_
   g.nx = nx, g.ny = ny, g.nz = nz;
 }
 
-// Source feature sets are only *ordered* by a grid (never searched): a 32x32x32 grid over the
+// Source feature sets are only *ordered* by a grid (never searched): a 2^L x 2^L x 2^L grid over the
 // bounding box, cells numbered along the Morton (Z-order) curve, so that any run of consecutive
-// points is spatially compact at every scale. 15-bit codes fill the 32 768-entry LDS table exactly.
+// points is spatially compact at every scale. L = 5 (15-bit codes fill the 32 768-entry LDS table
+// exactly) except for small sets, where fewer cells keep the table work proportional to the set.
 LOAMX_HD void grid_choose_morton(GridDesc& g, Vec3 lo, Vec3 hi, uint32_t n) {
   g.n_points = n;
+  const int level = n <= 128u ? 2 : (n <= 1024u ? 3 : (n <= 4096u ? 4 : 5));
+  const int32_t dim = 1 << level;
   double ext = hi.x - lo.x;
   if (hi.y - lo.y > ext) ext = hi.y - lo.y;
   if (hi.z - lo.z > ext) ext = hi.z - lo.z;
-  double h = ext / 32.0 * (1.0 + 1e-9);
+  double h = ext / (double)dim * (1.0 + 1e-9);
   if (!(h > 0.0) || n == 0) h = 1.0;
   g.ox = n ? lo.x : 0.0, g.oy = n ? lo.y : 0.0, g.oz = n ? lo.z : 0.0;
   g.h = h, g.inv_h = 1.0 / h;
-  g.nx = g.ny = g.nz = 32;
+  g.nx = g.ny = g.nz = dim;
 }
 LOAMX_HD uint32_t morton_spread5(uint32_t v) {  // abcde -> a00b00c00d00e
   v &= 31u;
@@ -169,9 +178,9 @@ LOAMX_HD uint32_t morton_spread5(uint32_t v) {  // abcde -> a00b00c00d00e
   return v;
 }
 LOAMX_HD uint32_t grid_morton_of_point(const GridDesc& g, Vec3 p) {
-  const uint32_t ix = (uint32_t)clampi(grid_cell_coord(p.x, g.ox, g.inv_h), 0, 31);
-  const uint32_t iy = (uint32_t)clampi(grid_cell_coord(p.y, g.oy, g.inv_h), 0, 31);
-  const uint32_t iz = (uint32_t)clampi(grid_cell_coord(p.z, g.oz, g.inv_h), 0, 31);
+  const uint32_t ix = (uint32_t)clampi(grid_cell_coord(p.x, g.ox, g.inv_h), 0, g.nx - 1);
+  const uint32_t iy = (uint32_t)clampi(grid_cell_coord(p.y, g.oy, g.inv_h), 0, g.nx - 1);
+  const uint32_t iz = (uint32_t)clampi(grid_cell_coord(p.z, g.oz, g.inv_h), 0, g.nx - 1);
   return morton_spread5(ix) | (morton_spread5(iy) << 1) | (morton_spread5(iz) << 2);
 }
 

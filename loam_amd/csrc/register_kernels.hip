@@ -140,20 +140,32 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
     __syncthreads();
   }
   if (tid == 0) cs[ncell] = n;
-  if (ORDERED) {
-    // single pass here (Morton grid = kGridLdsCells cells): after the scatter s_cells[c] holds the
-    // END of cell c; its begin is the end of cell c-1
-    __threadfence_block();
-    for (uint32_t p = tid; p < n; p += kBuildThreads) {
-      const GridPoint e = dst[p];
-      const uint32_t cell = grid_morton_of_point(g, v3(e.x, e.y, e.z));
-      const uint32_t b = cell ? s_cells[cell - 1] : 0u, en = s_cells[cell];
-      uint32_t rank = 0;
+}
+
+// Second half of the ORDERED build (source sets): every point of the scratch copy is placed at
+// (cell begin + number of cell mates with a smaller original index). A kernel of its own because the
+// pair-wise comparison inside a cell is a latency-bound gather that wants far more waves in flight
+// than the one 128 KiB-LDS workgroup per CU of grid_build_kernel can offer.
+constexpr int kRankThreads = 256;
+__global__ __launch_bounds__(kRankThreads) void grid_rank_kernel(const uint32_t* __restrict__ n_pts, size_t stride,
+                                                                 uint32_t in_pitch, GridSet gs,
+                                                                 const GridPoint* __restrict__ scratch) {
+  const size_t pair = blockIdx.y;
+  const uint32_t n_raw = n_pts[pair * in_pitch];
+  const uint32_t n = n_raw < stride ? n_raw : (uint32_t)stride;
+  const uint32_t p = blockIdx.x * kRankThreads + threadIdx.x;
+  if (p >= n) return;
+  const GridDesc g = gs.desc[pair];
+  const uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
+  const GridPoint* __restrict__ src = scratch + pair * gs.stride;
+  GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
+  const GridPoint e = src[p];
+  const uint32_t cell = grid_morton_of_point(g, v3(e.x, e.y, e.z));
+  const uint32_t b = cs[cell], en = cs[cell + 1];
+  uint32_t rank = 0;
 #pragma unroll 4
-      for (uint32_t j = b; j < en; j++) rank += dst[j].orig < e.orig ? 1u : 0u;
-      sp[b + rank] = e;
-    }
-  }
+  for (uint32_t j = b; j < en; j++) rank += src[j].orig < e.orig ? 1u : 0u;
+  sp[b + rank] = e;
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -527,10 +539,18 @@ void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_
 // source sets: only the cell-sorted (Morton) order is used
 void launch_grid_build_sources(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   if (B.n_pairs == 0) return;
+  // (the scratch copy is shared: build + rank of one set complete before the next set's build starts)
   hipLaunchKernelGGL(grid_build_kernel<true>, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.src_edge, B.n_src_edge,
                      B.edge_stride, B.in_pitch, C.r_edge, B.src_grid_edge, B.sort_scratch);
+  if (B.edge_stride)
+    hipLaunchKernelGGL(grid_rank_kernel, dim3((unsigned)((B.edge_stride + kRankThreads - 1) / kRankThreads), (unsigned)B.n_pairs),
+                       dim3(kRankThreads), 0, s, B.n_src_edge, B.edge_stride, B.in_pitch, B.src_grid_edge, B.sort_scratch);
   hipLaunchKernelGGL(grid_build_kernel<true>, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.src_planar,
                      B.n_src_planar, B.planar_stride, B.in_pitch, C.r_plane, B.src_grid_plane, B.sort_scratch);
+  if (B.planar_stride)
+    hipLaunchKernelGGL(grid_rank_kernel, dim3((unsigned)((B.planar_stride + kRankThreads - 1) / kRankThreads), (unsigned)B.n_pairs),
+                       dim3(kRankThreads), 0, s, B.n_src_planar, B.planar_stride, B.in_pitch, B.src_grid_plane,
+                       B.sort_scratch);
 }
 
 void launch_state_init(const RegBatch& B, const RegConfig& C, hipStream_t s) {
