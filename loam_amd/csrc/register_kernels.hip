@@ -102,9 +102,11 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
       if (cell < nc) atomicAdd(&s_cells[cell], 1u);
     }
     __syncthreads();
-    // exclusive scan of s_cells[0..nc): contiguous chunk per thread + block scan of chunk sums
-    const uint32_t per = (nc + kBuildThreads - 1) / kBuildThreads;
-    const uint32_t c0 = tid * per, c1 = c0 + per < nc ? c0 + per : nc;
+    // exclusive scan of s_cells[0..nc): contiguous chunk per thread + block scan of chunk sums.
+    // The chunk length is odd, so the 64 lanes of a wavefront walk 64 different LDS banks (an even
+    // length such as 32 would put every lane on the same bank).
+    const uint32_t per = ((nc + kBuildThreads - 1) / kBuildThreads) | 1u;
+    const uint32_t c0 = tid * per < nc ? tid * per : nc, c1 = c0 + per < nc ? c0 + per : nc;
     uint32_t local = 0;
     for (uint32_t c = c0; c < c1; c++) local += s_cells[c];
     uint32_t incl = local;
@@ -123,9 +125,10 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
     for (uint32_t c = c0; c < c1; c++) {
       const uint32_t cnt = s_cells[c];
       s_cells[c] = run;
-      cs[c_lo + c] = run;
       run += cnt;
     }
+    __syncthreads();
+    for (uint32_t c = tid; c < nc; c += kBuildThreads) cs[c_lo + c] = s_cells[c];  // coalesced copy of the scan
     __syncthreads();
 #pragma unroll 4
     for (uint32_t i = tid; i < n; i += kBuildThreads) {
