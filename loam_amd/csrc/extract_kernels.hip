@@ -159,6 +159,10 @@ __global__ __launch_bounds__(WAVES * 64) void select_kernel(const double* __rest
  * shuffle pair for the suppression. Used when np-1 = R in 1..4, R <= CH, CH + 2R <= 64 and a sector
  * can hold at most 64 picks; select_kernel remains the general fallback (identical results).
  * ---------------------------------------------------------------------------------------------- */
+// LDS bytes per wavefront: padded curvature (W + 64 doubles), 64 pick slots (double + int), padded mask
+__host__ __device__ inline size_t select_mis_lds_bytes(int W) {
+  return ((size_t)W + 64) * 8 + 64 * 8 + 64 * 4 + (((size_t)W + 256 + 7) & ~(size_t)7);
+}
 __device__ __forceinline__ uint64_t shfl_prev(uint64_t v, int lane) {
   const uint64_t t = (uint64_t)__shfl_up((unsigned long long)v, 1);
   return lane == 0 ? 0ull : t;
@@ -179,8 +183,9 @@ template <int R, bool EDGE>
 __device__ __forceinline__ uint32_t mis_pass(int lane, int CH, int base, int start, int end, uint64_t& V, uint64_t T,
                                              const uint64_t gt[R], const double* s_c, double* m_c, int32_t* m_i,
                                              uint32_t cap, uint32_t line_base, uint32_t* __restrict__ stage,
-                                             uint32_t idx_mask) {
+                                             uint32_t idx_mask, uint32_t ch_magic) {
   const uint64_t cm = low_mask(CH);
+  const int pbase = lane * (CH + 1);  // s_c is stored with one spare slot per lane chunk (see select_mis_kernel)
   int lo = start - base, hi = end - base;
   lo = lo < 0 ? 0 : lo;
   hi = hi > CH ? CH : hi;
@@ -208,7 +213,7 @@ __device__ __forceinline__ uint32_t mis_pass(int lane, int CH, int base, int sta
   for (uint64_t bits = Pk; bits; bits &= bits - 1) {
     const int j = __ffsll((unsigned long long)bits) - 1;
     if (slot < 64) {
-      m_c[slot] = s_c[base + j];
+      m_c[slot] = s_c[pbase + j];
       m_i[slot] = base + j;
     }
     slot++;
@@ -264,7 +269,7 @@ __device__ __forceinline__ uint32_t mis_pass(int lane, int CH, int base, int sta
       }
     } else {
       i = (uint32_t)lane < total ? (int32_t)((uint32_t)__double2loint(key) & idx_mask) : -1;
-      c = (uint32_t)lane < total ? s_c[i < 0 ? 0 : i] : 0.0;
+      c = (uint32_t)lane < total ? s_c[i < 0 ? 0 : i + (ch_magic ? (int32_t)__umulhi((uint32_t)i, ch_magic) : i)] : 0.0;
     }
   }
   const uint32_t kept = total < cap ? total : cap;  // features-inl.h:155/:177: at most max+1 picks
@@ -277,7 +282,7 @@ __device__ __forceinline__ uint32_t mis_pass(int lane, int CH, int base, int sta
     K = 0;
     for (uint64_t bits = Pk; bits; bits &= bits - 1) {
       const int j = __ffsll((unsigned long long)bits) - 1;
-      const double cj = s_c[base + j];
+      const double cj = s_c[pbase + j];
       if (!(EDGE ? edge_before(tc, ti, cj, base + j) : planar_before(tc, ti, cj, base + j))) K |= 1ull << j;
     }
   }
@@ -296,34 +301,59 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
   const size_t line = (size_t)blockIdx.x * WAVES + wave;
   if (line >= n_lines) return;  // whole wavefront leaves; no workgroup barrier below
   const int W = (int)P.W, CH = (W + 63) / 64, base = lane * CH;
-  const size_t per_wave = (size_t)W * 8 + 64 * 8 + 64 * 4 + (((size_t)W + 7) & ~(size_t)7);
+  // LDS layout: every lane's chunk of CH points is followed by one spare double (4 spare bytes in
+  // the mask): with the chunk stride CH (16 for W = 1024) the lanes of a wavefront would all read the
+  // same LDS bank when each walks its own chunk; CH + 1 spreads them over all banks.
+  const size_t per_wave = select_mis_lds_bytes(W);
   double* s_c = reinterpret_cast<double*>(smem + wave * per_wave);
-  double* m_c = s_c + W;
+  double* m_c = s_c + W + 64;
   int32_t* m_i = reinterpret_cast<int32_t*>(m_c + 64);
   uint8_t* s_v = reinterpret_cast<uint8_t*>(m_i + 64);
+  // i / CH == umulhi(i, ch_magic) for i < 2^16 when CH >= 2; ch_magic == 0 stands for CH == 1 (i / CH == i)
+  const uint32_t ch_magic = CH > 1 ? 0xFFFFFFFFu / (uint32_t)CH + 1u : 0u;
   for (int i = lane; i < W; i += 64) {
-    s_c[i] = curv[line * (size_t)W + i];
-    s_v[i] = mask[line * (size_t)W + i];
+    const int owner = ch_magic ? (int)__umulhi((uint32_t)i, ch_magic) : i;
+    s_c[i + owner] = curv[line * (size_t)W + i];
+    s_v[i + 4 * owner] = mask[line * (size_t)W + i];
   }
   wave_lds_sync();
+  const int pbase = lane * (CH + 1), vbase = lane * (CH + 4);
   uint64_t V = 0, ET = 0, PT = 0, gt[R];
   for (int j = 0; j < CH; j++) {
     const int i = base + j;
     if (i < W) {
-      const double c = s_c[i];
-      V |= (uint64_t)(s_v[i] != 0) << j;
+      const double c = s_c[pbase + j];
+      V |= (uint64_t)(s_v[vbase + j] != 0) << j;
       ET |= (uint64_t)(c > P.edge_thr) << j;
       PT |= (uint64_t)(c < P.planar_thr) << j;
     }
   }
+  // window values base-R .. base+CH+R-1 (+R more for the comparisons), read once: the halo on either
+  // side belongs to the neighbouring lanes' chunks (R <= CH)
 #pragma unroll
-  for (int d = 1; d <= R; d++) {
-    uint64_t g = 0;
+  for (int d = 1; d <= R; d++) gt[d - 1] = 0;
+  {
+    double win[2 * R + 1];  // sliding window of R + 1 consecutive values
+    // value at line index i (any lane's chunk within one chunk of mine)
+    auto at = [&](int i) -> double {
+      const int owner = i < base ? lane - 1 : (i >= base + CH ? (i >= base + 2 * CH ? lane + 2 : lane + 1) : lane);
+      return s_c[i + owner];
+    };
+#pragma unroll
+    for (int u = 0; u < R; u++) {
+      const int i = base - R + u;
+      win[u] = (i >= 0 && i < W) ? at(i) : 0.0;
+    }
     for (int t = 0; t < CH + 2 * R; t++) {
       const int i = base - R + t;
-      if (i >= 0 && i + d < W) g |= (uint64_t)(s_c[i] > s_c[i + d]) << t;
+      const int in = i + R;  // newest value entering the window
+      win[R] = (in >= 0 && in < W) ? at(in) : 0.0;
+#pragma unroll
+      for (int d = 1; d <= R; d++)
+        if (i >= 0 && i + d < W) gt[d - 1] |= (uint64_t)(win[0] > win[d]) << t;
+#pragma unroll
+      for (int u = 0; u < R; u++) win[u] = win[u + 1];
     }
-    gt[d - 1] = g;
   }
   const uint32_t line_base = (uint32_t)(line % P.H) * P.W;
   const uint32_t idx_mask = W <= 2 ? 1u : (0xFFFFFFFFu >> __clz(W - 1));  // index-in-line bits of the sort keys
@@ -332,9 +362,9 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
     const int end = (s == P.S - 1) ? W : start + (int)P.pps;  // features-inl.h:31-35
     const size_t group = line * P.S + s;
     const uint32_t ne = mis_pass<R, true>(lane, CH, base, start, end, V, ET, gt, s_c, m_c, m_i, P.cap_edge, line_base,
-                                          st.edge_stage + group * P.cap_edge, idx_mask);
+                                          st.edge_stage + group * P.cap_edge, idx_mask, ch_magic);
     const uint32_t npl = mis_pass<R, false>(lane, CH, base, start, end, V, PT, gt, s_c, m_c, m_i, P.cap_planar,
-                                            line_base, st.planar_stage + group * P.cap_planar, idx_mask);
+                                            line_base, st.planar_stage + group * P.cap_planar, idx_mask, ch_magic);
     if (lane == 0) {
       st.edge_cnt[group] = ne;
       st.planar_cnt[group] = npl;
@@ -428,7 +458,7 @@ void launch_curvature_valid(const double* d_xyz, size_t n_scans, const ExtractPa
 template <int R>
 static void launch_select_mis(const double* d_curv, const uint8_t* d_mask, size_t n_lines, const ExtractParams& P,
                               const ExtractStage& st, hipStream_t s) {
-  const size_t per_wave = (size_t)P.W * 8 + 64 * 8 + 64 * 4 + (((size_t)P.W + 7) & ~(size_t)7);
+  const size_t per_wave = select_mis_lds_bytes((int)P.W);
   if (per_wave * 4 <= 48 * 1024) {
     hipLaunchKernelGGL((select_mis_kernel<R, 4>), dim3((unsigned)((n_lines + 3) / 4)), dim3(256), per_wave * 4, s, d_curv,
                        d_mask, n_lines, P, st);
