@@ -163,13 +163,19 @@ __global__ __launch_bounds__(WAVES * 64) void select_kernel(const double* __rest
 __host__ __device__ inline size_t select_mis_lds_bytes(int W) {
   return ((size_t)W + 64) * 8 + 64 * 8 + 64 * 4 + (((size_t)W + 256 + 7) & ~(size_t)7);
 }
+// value of the previous / next lane (0 at the wave's ends): one DPP move per dword
+// (wave_shr:1 / wave_shl:1 with bound_ctrl zero fill) instead of an LDS-crossbar ds_bpermute
 __device__ __forceinline__ uint64_t shfl_prev(uint64_t v, int lane) {
-  const uint64_t t = (uint64_t)__shfl_up((unsigned long long)v, 1);
-  return lane == 0 ? 0ull : t;
+  (void)lane;
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x138, 0xF, 0xF, true);          // wave_shr:1
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x138, 0xF, 0xF, true);
+  return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
 }
 __device__ __forceinline__ uint64_t shfl_next(uint64_t v, int lane) {
-  const uint64_t t = (uint64_t)__shfl_down((unsigned long long)v, 1);
-  return lane == 63 ? 0ull : t;
+  (void)lane;
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x130, 0xF, 0xF, true);          // wave_shl:1
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x130, 0xF, 0xF, true);
+  return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
 }
 
 template <bool EDGE>
