@@ -42,6 +42,8 @@ struct PendingEvent {
 struct loamx_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
+  hipStream_t aux_stream = nullptr;  // edge association chain, forked from / joined into `stream` with the two events
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::string last_error;
   Buf ws[WS_COUNT];
   uint32_t* h_pinned = nullptr;  // small pinned readback area
@@ -326,7 +328,7 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   for (uint32_t it = 0; it < C.max_iterations; it++) {
     {
       TimedScope t(ctx, LOAMX_K_ASSOC, 0.0);
-      launch_associate(B, C, s);
+      launch_associate(B, C, s, ctx->aux_stream, ctx->ev_fork, ctx->ev_join);
     }
     CHECK_LAUNCH(ctx, "associate_kernel");
     if (hook) {
@@ -423,6 +425,14 @@ int loamx_ctx_create(int device, loamx_ctx** out) {
     return LOAMX_ERR_HIP;
   }
   ctx->stream = ctx->own_stream;
+  // optional: without the auxiliary stream the edge and plane association chains simply run in sequence
+  if (!getenv("LOAMX_NO_AUX_STREAM") && hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) == hipSuccess) {
+    if (hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipStreamDestroy(ctx->aux_stream);
+      ctx->aux_stream = nullptr;
+    }
+  }
   *out = ctx;
   return LOAMX_OK;
 }
@@ -439,6 +449,12 @@ void loamx_ctx_destroy(loamx_ctx* ctx) {
   for (Buf& b : ctx->ws)
     if (b.p) (void)hipFree(b.p);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  if (ctx->aux_stream) {
+    (void)hipStreamSynchronize(ctx->aux_stream);
+    (void)hipStreamDestroy(ctx->aux_stream);
+  }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }

@@ -114,7 +114,8 @@ struct RegBatch {
 void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_grid_build_sources(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_state_init(const RegBatch& B, const RegConfig& C, hipStream_t s);
-void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s);
+void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipStream_t aux, hipEvent_t ev_fork,
+                      hipEvent_t ev_join);  // aux == nullptr: everything on s
 void launch_lm_begin(const RegBatch& B, const RegConfig& C, uint32_t iteration, hipStream_t s);
 void launch_sweep(const RegBatch& B, hipStream_t s);
 void launch_lm_step(const RegBatch& B, hipStream_t s);

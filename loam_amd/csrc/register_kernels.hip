@@ -561,29 +561,37 @@ void launch_state_init(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   hipLaunchKernelGGL(state_init_kernel, dim3(per_pair_grid(B.n_pairs)), dim3(64), 0, s, B, C);
 }
 
-void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s) {
+void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipStream_t aux, hipEvent_t ev_fork,
+                      hipEvent_t ev_join) {
   if (B.n_pairs == 0) return;
   const uint32_t be = (uint32_t)((B.edge_stride + kAssocThreads - 1) / kAssocThreads);
   const uint32_t bp = (uint32_t)((B.planar_stride + kAssocThreads - 1) / kAssocThreads);
   const size_t pair_groups = (B.n_pairs + 7) / 8;  // grid covers 8 XCD lanes x pair_groups x chunks
   // register-resident neighbour lists are instantiated for K <= 5 (the reference's default) and K <= 8
-#define LOAMX_LAUNCH_ASSOC(PL, KMV, nblk)                                                                 \
-  do {                                                                                                    \
-    const dim3 grid_((unsigned)(pair_groups * 8 * (nblk)));                                               \
-    hipLaunchKernelGGL((associate_knn_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, s, B, C, (nblk));  \
-    const uint32_t xblk_ = (nblk) < 2u ? (nblk) : 2u;                                                      \
-    hipLaunchKernelGGL((associate_knn_exact_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * xblk_)),  \
-                       dim3(kAssocThreads), 0, s, B, C, xblk_, (nblk));                                   \
-    hipLaunchKernelGGL((associate_fit_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, s, B, C, (nblk));  \
+#define LOAMX_LAUNCH_ASSOC(PL, KMV, nblk, st)                                                                \
+  do {                                                                                                       \
+    const dim3 grid_((unsigned)(pair_groups * 8 * (nblk)));                                                  \
+    hipLaunchKernelGGL((associate_knn_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, (st), B, C, (nblk));  \
+    const uint32_t xblk_ = (nblk) < 2u ? (nblk) : 2u;                                                         \
+    hipLaunchKernelGGL((associate_knn_exact_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * xblk_)),     \
+                       dim3(kAssocThreads), 0, (st), B, C, xblk_, (nblk));                                   \
+    hipLaunchKernelGGL((associate_fit_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, (st), B, C, (nblk));  \
   } while (0)
+  // The edge chain (small sets: a few latency-bound workgroups per pair) runs on the auxiliary stream
+  // next to the plane chain, which it shares no buffers with, instead of in front of it.
+  const bool fork = aux != nullptr && be != 0 && bp != 0 && hipEventRecord(ev_fork, s) == hipSuccess &&
+                    hipStreamWaitEvent(aux, ev_fork, 0) == hipSuccess;
+  hipStream_t se = fork ? aux : s;
   if (be) {
-    if (C.k_edge <= 5) LOAMX_LAUNCH_ASSOC(false, 5, be);
-    else LOAMX_LAUNCH_ASSOC(false, 8, be);
+    if (C.k_edge <= 5) LOAMX_LAUNCH_ASSOC(false, 5, be, se);
+    else LOAMX_LAUNCH_ASSOC(false, 8, be, se);
   }
+  if (fork) (void)hipEventRecord(ev_join, aux);
   if (bp) {
-    if (C.k_plane <= 5) LOAMX_LAUNCH_ASSOC(true, 5, bp);
-    else LOAMX_LAUNCH_ASSOC(true, 8, bp);
+    if (C.k_plane <= 5) LOAMX_LAUNCH_ASSOC(true, 5, bp, s);
+    else LOAMX_LAUNCH_ASSOC(true, 8, bp, s);
   }
+  if (fork) (void)hipStreamWaitEvent(s, ev_join, 0);
 #undef LOAMX_LAUNCH_ASSOC
 }
 
