@@ -1084,33 +1084,44 @@ LOAMX_HD double sym_at(const double H[21], int i, int j) {
 // Solve (S H S + D^2) y = S g by Cholesky; returns false if not positive definite / non-finite.
 LOAMX_HD bool lm_solve6(const double H[21], const double g[6], const double scaling[6], const double d2[6], double y[6]) {
   double A[6][6], b[6];
+  #pragma unroll
   for (int i = 0; i < 6; i++) {
+    #pragma unroll
     for (int j = 0; j < 6; j++) A[i][j] = scaling[i] * sym_at(H, i, j) * scaling[j];
     A[i][i] += d2[i];
     b[i] = scaling[i] * g[i];
   }
+  #pragma unroll
   for (int j = 0; j < 6; j++) {
     double s = A[j][j];
+    #pragma unroll
     for (int k = 0; k < j; k++) s -= A[j][k] * A[j][k];
     if (!(s > 0.0)) return false;
     const double l = sqrt(s);
     A[j][j] = l;
+    #pragma unroll
     for (int i = j + 1; i < 6; i++) {
       double t = A[i][j];
+      #pragma unroll
       for (int k = 0; k < j; k++) t -= A[i][k] * A[j][k];
       A[i][j] = t / l;
     }
   }
+  #pragma unroll
   for (int i = 0; i < 6; i++) {
     double t = b[i];
+    #pragma unroll
     for (int k = 0; k < i; k++) t -= A[i][k] * y[k];
     y[i] = t / A[i][i];
   }
+  #pragma unroll
   for (int i = 5; i >= 0; i--) {
     double t = y[i];
+    #pragma unroll
     for (int k = i + 1; k < 6; k++) t -= A[k][i] * y[k];
     y[i] = t / A[i][i];
   }
+  #pragma unroll
   for (int i = 0; i < 6; i++)
     if (!(y[i] - y[i] == 0.0)) return false;
   return true;
@@ -1128,6 +1139,7 @@ LOAMX_HD bool lm_propose(LmState& st) {
     st.iteration++;
     // LevenbergMarquardtStrategy::ComputeStep on the column-scaled Jacobian
     if (!st.reuse_diagonal) {
+      #pragma unroll
       for (int j = 0; j < 6; j++) {
         double d = st.scaling[j] * sym_at(st.H, j, j) * st.scaling[j];
         d = d < 1e-6 ? 1e-6 : d;
@@ -1136,18 +1148,22 @@ LOAMX_HD bool lm_propose(LmState& st) {
       }
     }
     double d2[6], y[6];
+    #pragma unroll
     for (int j = 0; j < 6; j++) d2[j] = st.diagonal[j] / st.radius;  // lm_diagonal^2
     const bool solved = lm_solve6(st.H, st.g, st.scaling, d2, y);
     st.reuse_diagonal = 1;
     bool valid = false;
     double step[6];
     if (solved) {
+      #pragma unroll
       for (int j = 0; j < 6; j++) step[j] = -y[j];
       // model_cost_change = -(J step)^T (f + J step / 2) = -step^T S g - step^T S H S step / 2
       double lin = 0, quad = 0;
+      #pragma unroll
       for (int i = 0; i < 6; i++) {
         lin += step[i] * st.scaling[i] * st.g[i];
         double row = 0;
+        #pragma unroll
         for (int j = 0; j < 6; j++) row += st.scaling[i] * sym_at(st.H, i, j) * st.scaling[j] * step[j];
         quad += step[i] * row;
       }
@@ -1162,6 +1178,7 @@ LOAMX_HD bool lm_propose(LmState& st) {
     }
     st.num_invalid = 0;
     double delta[6];
+    #pragma unroll
     for (int j = 0; j < 6; j++) delta[j] = step[j] * st.scaling[j];
     manifold_plus(st.x, delta, st.xeval);
     return true;
@@ -1169,19 +1186,24 @@ LOAMX_HD bool lm_propose(LmState& st) {
 }
 
 LOAMX_HD void lm_init(LmState& st) {
+  #pragma unroll
   for (int i = 0; i < 7; i++) st.x[i] = st.x_user[i] = st.xeval[i] = (i == 3) ? 1.0 : 0.0;  // Pose3d() identity
   st.radius = 1e4, st.decrease_factor = 2.0;
   st.iteration = 0, st.num_invalid = 0, st.reuse_diagonal = 0, st.active = 1;
   st.x_cost = 0, st.minimum_cost = 0, st.x_norm = 1.0, st.model_cost_change = 0;
+  #pragma unroll
   for (int j = 0; j < 6; j++) st.scaling[j] = 1.0, st.diagonal[j] = 0.0, st.g[j] = 0.0;
+  #pragma unroll
   for (int j = 0; j < 21; j++) st.H[j] = 0.0;
 }
 
 LOAMX_HD double gradient_max_norm(const LmState& st) {
   double neg[6], xp[7];
+  #pragma unroll
   for (int j = 0; j < 6; j++) neg[j] = -st.g[j];
   manifold_plus(st.x, neg, xp);
   double m = 0;
+  #pragma unroll
   for (int i = 0; i < 7; i++) {
     const double a = fabs(st.x[i] - xp[i]);
     m = a > m ? a : m;
@@ -1198,10 +1220,13 @@ LOAMX_HD void lm_consume(LmState& st, const double acc[kAccSize], bool first) {
       st.active = 0;
       return;
     }
+    #pragma unroll
     for (int j = 0; j < 21; j++) st.H[j] = acc[j];
+    #pragma unroll
     for (int j = 0; j < 6; j++) st.g[j] = acc[21 + j];
     st.x_cost = acc[27];
     st.minimum_cost = st.x_cost;
+    #pragma unroll
     for (int j = 0; j < 6; j++) st.scaling[j] = 1.0 / (1.0 + sqrt(sym_at(st.H, j, j)));  // jacobi scaling, once
     st.active = lm_propose(st) ? 1 : 0;
     return;
@@ -1209,6 +1234,7 @@ LOAMX_HD void lm_consume(LmState& st, const double acc[kAccSize], bool first) {
   const double cand_cost = eval_ok ? acc[27] : kDblMax;
   // ParameterToleranceReached: candidate discarded
   double step_norm = 0;
+  #pragma unroll
   for (int i = 0; i < 7; i++) step_norm += (st.x[i] - st.xeval[i]) * (st.x[i] - st.xeval[i]);
   step_norm = sqrt(step_norm);
   if (step_norm <= 1e-8 * (st.x_norm + 1e-8)) {
@@ -1223,12 +1249,16 @@ LOAMX_HD void lm_consume(LmState& st, const double acc[kAccSize], bool first) {
   const double relative_decrease = (st.x_cost - cand_cost) / st.model_cost_change;
   if (relative_decrease > 1e-3) {
     // HandleSuccessfulStep: the sweep already holds J^T J, J^T f at the candidate
+    #pragma unroll
     for (int i = 0; i < 7; i++) st.x[i] = st.xeval[i];
     double n2 = 0;
+    #pragma unroll
     for (int i = 0; i < 7; i++) n2 += st.x[i] * st.x[i];
     st.x_norm = sqrt(n2);
     // (a non-finite Jacobian at an accepted candidate would have made cand_cost = DBL_MAX above)
+    #pragma unroll
     for (int j = 0; j < 21; j++) st.H[j] = acc[j];
+    #pragma unroll
     for (int j = 0; j < 6; j++) st.g[j] = acc[21 + j];
     st.x_cost = acc[27];
     double q = 2.0 * relative_decrease - 1.0;
@@ -1240,6 +1270,7 @@ LOAMX_HD void lm_consume(LmState& st, const double acc[kAccSize], bool first) {
     // Finalize: publish to the user's parameter blocks
     if (st.x_cost < st.minimum_cost) {
       st.minimum_cost = st.x_cost;
+      #pragma unroll
       for (int i = 0; i < 7; i++) st.x_user[i] = st.x[i];
     }
     if (st.iteration < 4 && gradient_max_norm(st) <= 1e-10) {

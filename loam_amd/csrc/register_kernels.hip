@@ -359,7 +359,7 @@ __global__ __launch_bounds__(kAssocThreads) void associate_fit_kernel(RegBatch B
   }
 }
 
-__global__ void lm_begin_kernel(RegBatch B, RegConfig C, uint32_t iteration) {
+__global__ __launch_bounds__(64) void lm_begin_kernel(RegBatch B, RegConfig C, uint32_t iteration) {
   const size_t pair = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pair >= B.n_pairs) return;
   PairState& S = B.state[pair];
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(kSweepThreads, LOAMX_SWEEP_WAVES) void sweep_kernel
   }
 }
 
-__global__ void lm_step_kernel(RegBatch B) {
+__global__ __launch_bounds__(64) void lm_step_kernel(RegBatch B) {  // one wavefront: the 6x6 solve may use the whole register file
   const size_t pair = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pair >= B.n_pairs) return;
   PairState& S = B.state[pair];
