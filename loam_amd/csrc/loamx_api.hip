@@ -21,7 +21,7 @@ enum WsId {
   WS_XYZ = 0, WS_CURV, WS_MASK, WS_EDGE_STAGE, WS_PLANAR_STAGE, WS_EDGE_CNT, WS_PLANAR_CNT,
   WS_EDGE_IDX, WS_PLANAR_IDX, WS_N_EDGE, WS_N_PLANAR, WS_EDGE_XYZ, WS_PLANAR_XYZ,
   WS_GRID_DESC_E, WS_GRID_DESC_P, WS_CELLS_E, WS_CELLS_P, WS_SORTED_E, WS_SORTED_P,
-  WS_SGRID_DESC_E, WS_SGRID_DESC_P, WS_SCELLS_E, WS_SCELLS_P, WS_SSORTED_E, WS_SSORTED_P, WS_SORT_SCRATCH, WS_ASSOC_E, WS_ASSOC_P, WS_NN_E, WS_NN_P, WS_NEAREST_E, WS_NEAREST_P, WS_NASSOC, WS_STATE, WS_PARTIALS,
+  WS_SGRID_DESC_E, WS_SGRID_DESC_P, WS_SCELLS_E, WS_SCELLS_P, WS_SSORTED_E, WS_SSORTED_P, WS_SORT_SCRATCH, WS_ASSOC_E, WS_ASSOC_P, WS_NN_E, WS_NN_P, WS_RNN_E, WS_RNN_P, WS_NEAREST_E, WS_NEAREST_P, WS_REST_E, WS_REST_P, WS_EXACT_E, WS_EXACT_P, WS_NASSOC, WS_STATE, WS_PARTIALS,
   WS_COUNTERS, WS_ITERINFO, WS_SRC_E, WS_SRC_P, WS_TGT_E, WS_TGT_P, WS_FCOUNTS, WS_RESULTS, WS_INIT,
   WS_COUNT
 };
@@ -43,7 +43,7 @@ struct loamx_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
   hipStream_t aux_stream = nullptr;  // edge association chain, forked from / joined into `stream` with the two events
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_mid = nullptr, ev_join = nullptr;
   std::string last_error;
   Buf ws[WS_COUNT];
   uint32_t* h_pinned = nullptr;  // small pinned readback area
@@ -284,9 +284,15 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   ENSURE(ctx, WS_ASSOC_P, 7 * np * ps * sizeof(double));
   ENSURE(ctx, WS_NN_E, (size_t)(1 + kMaxK) * np * es * sizeof(uint32_t));
   ENSURE(ctx, WS_NN_P, (size_t)(1 + kMaxK) * np * ps * sizeof(uint32_t));
+  ENSURE(ctx, WS_RNN_E, (size_t)(1 + kMaxK) * np * es * sizeof(uint32_t));
+  ENSURE(ctx, WS_RNN_P, (size_t)(1 + kMaxK) * np * ps * sizeof(uint32_t));
   ENSURE(ctx, WS_NEAREST_E, np * es * sizeof(uint32_t));
   ENSURE(ctx, WS_NEAREST_P, np * ps * sizeof(uint32_t));
-  ENSURE(ctx, WS_NASSOC, np * 4 * sizeof(uint32_t));
+  ENSURE(ctx, WS_REST_E, np * es * sizeof(uint32_t));
+  ENSURE(ctx, WS_REST_P, np * ps * sizeof(uint32_t));
+  ENSURE(ctx, WS_EXACT_E, np * es * sizeof(uint32_t));
+  ENSURE(ctx, WS_EXACT_P, np * ps * sizeof(uint32_t));
+  ENSURE(ctx, WS_NASSOC, np * 8 * sizeof(uint32_t));
   ENSURE(ctx, WS_STATE, np * sizeof(PairState));
   B.blocks_per_pair = (uint32_t)((es + ps + kSweepChunk - 1) / kSweepChunk);
   ENSURE(ctx, WS_PARTIALS, np * B.blocks_per_pair * kAccSize * sizeof(double));
@@ -302,8 +308,11 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   B.src_grid_plane = GridSet{wsp<GridDesc>(ctx, WS_SGRID_DESC_P), wsp<uint32_t>(ctx, WS_SCELLS_P), wsp<GridPoint>(ctx, WS_SSORTED_P), ps};
   B.sort_scratch = wsp<GridPoint>(ctx, WS_SORT_SCRATCH);
   B.assoc = AssocBuffers{wsp<double>(ctx, WS_ASSOC_E), wsp<double>(ctx, WS_ASSOC_P), wsp<uint32_t>(ctx, WS_NN_E),
-                         wsp<uint32_t>(ctx, WS_NN_P), wsp<uint32_t>(ctx, WS_NEAREST_E),
-                         wsp<uint32_t>(ctx, WS_NEAREST_P), wsp<uint32_t>(ctx, WS_NASSOC)};
+                         wsp<uint32_t>(ctx, WS_NN_P), wsp<uint32_t>(ctx, WS_RNN_E), wsp<uint32_t>(ctx, WS_RNN_P),
+                         wsp<uint32_t>(ctx, WS_NEAREST_E),
+                         wsp<uint32_t>(ctx, WS_NEAREST_P), wsp<uint32_t>(ctx, WS_REST_E), wsp<uint32_t>(ctx, WS_REST_P),
+                         wsp<uint32_t>(ctx, WS_EXACT_E), wsp<uint32_t>(ctx, WS_EXACT_P),
+                         wsp<uint32_t>(ctx, WS_NASSOC)};
   B.state = wsp<PairState>(ctx, WS_STATE);
   B.partials = wsp<double>(ctx, WS_PARTIALS);
   // counters: [0] n_active (u32), [8..24) sweep slot counters (2 x u64)
@@ -328,7 +337,7 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   for (uint32_t it = 0; it < C.max_iterations; it++) {
     {
       TimedScope t(ctx, LOAMX_K_ASSOC, 0.0);
-      launch_associate(B, C, s, ctx->aux_stream, ctx->ev_fork, ctx->ev_join);
+      launch_associate(B, C, s, ctx->aux_stream, ctx->ev_fork, ctx->ev_mid, ctx->ev_join);
     }
     CHECK_LAUNCH(ctx, "associate_kernel");
     if (hook) {
@@ -428,6 +437,7 @@ int loamx_ctx_create(int device, loamx_ctx** out) {
   // optional: without the auxiliary stream the edge and plane association chains simply run in sequence
   if (!getenv("LOAMX_NO_AUX_STREAM") && hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) == hipSuccess) {
     if (hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_mid, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
       (void)hipStreamDestroy(ctx->aux_stream);
       ctx->aux_stream = nullptr;
@@ -455,6 +465,7 @@ void loamx_ctx_destroy(loamx_ctx* ctx) {
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }

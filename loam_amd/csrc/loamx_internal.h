@@ -61,10 +61,16 @@ struct AssocBuffers {
   double* plane;      // [7][n_pairs * planar_stride]
   uint32_t* nn_edge;        // [1 + kMaxK][n_pairs * edge_stride]   neighbour count, then positions in the sorted target
   uint32_t* nn_plane;       // [1 + kMaxK][n_pairs * planar_stride]
+  uint32_t* rnn_edge;       // as nn_*, for the queued queries, indexed by queue position
+  uint32_t* rnn_plane;
   uint32_t* nearest_edge;   // [n_pairs * edge_stride]   nearest target index (detail capture)
   uint32_t* nearest_plane;  // [n_pairs * planar_stride]
-  uint32_t* n_assoc;  // [n_pairs][4] valid edge / plane associations of the current iteration, then the
-                      // edge / plane queries its keyed k-NN left undecided
+  uint32_t* rest_edge;      // [n_pairs * edge_stride]   queue of the queries round 1 of the k-NN did not finish
+  uint32_t* rest_plane;     // [n_pairs * planar_stride]
+  uint32_t* exact_edge;     // queues of the queries the keyed collector could not decide (exact collector re-runs them)
+  uint32_t* exact_plane;
+  uint32_t* n_assoc;  // [n_pairs][8]: valid edge / plane associations of the current iteration [0,1], lengths of the
+                      // queues rest_* [2,3] and exact_* [4,5]
 };
 
 struct PairState {
@@ -115,7 +121,7 @@ void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_
 void launch_grid_build_sources(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_state_init(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipStream_t aux, hipEvent_t ev_fork,
-                      hipEvent_t ev_join);  // aux == nullptr: everything on s
+                      hipEvent_t ev_mid, hipEvent_t ev_join);  // aux == nullptr: everything on s
 void launch_lm_begin(const RegBatch& B, const RegConfig& C, uint32_t iteration, hipStream_t s);
 void launch_sweep(const RegBatch& B, hipStream_t s);
 void launch_lm_step(const RegBatch& B, hipStream_t s);

@@ -397,35 +397,6 @@ LOAMX_HD double slab_dist(double v, double origin, double h, int32_t c) {
   return d > 0.0 ? d : 0.0;
 }
 
-// Scans the cells [xlo, xhi] of row (iy, iz), skipping the row (or the part of it) whose slab is
-// farther than anything that could still enter the result: `bound` = min(k-th best d2, radius^2).
-template <class Coll>
-LOAMX_HD void knn_scan_row(const GridDesc& g, const uint32_t* __restrict__ cell_start, const GridPoint* __restrict__ sp,
-                           Vec3 q, int k, double r2, int32_t iy, int32_t iz, int32_t xlo, int32_t xhi, Coll& r) {
-  if (iy < 0 || iy > g.ny - 1 || iz < 0 || iz > g.nz - 1) return;
-  if (xlo < 0) xlo = 0;
-  if (xhi > g.nx - 1) xhi = g.nx - 1;
-  if (xlo > xhi) return;
-  const double sy = slab_dist(q.y, g.oy, g.h, iy), sz = slab_dist(q.z, g.oz, g.h, iz);
-  const double rowmin2 = sy * sy + sz * sz;
-  const double worst = knn_bound(r, k);
-  const double bound = worst < r2 ? worst : r2;
-  if (rowmin2 > bound) return;
-  if (bound < kDblMax) {
-    // cells whose x slab is farther than sqrt(bound - rowmin2) cannot contribute
-    const double reach = sqrt(bound - rowmin2) + 1e-9 * g.h;
-    const int32_t xl = grid_cell_coord(q.x - reach, g.ox, g.inv_h), xh = grid_cell_coord(q.x + reach, g.ox, g.inv_h);
-    if (xl > xlo) xlo = xl;
-    if (xh < xhi) xhi = xh;
-    if (xlo > xhi) return;
-  }
-  const uint32_t row = (uint32_t)((iz * g.ny + iy) * g.nx);
-#if defined(LOAMX_KNN_STATS)
-  g_rows++;
-#endif
-  knn_scan_range(r, k, q, sp, cell_start_at(cell_start, row + (uint32_t)xlo), cell_start_at(cell_start, row + (uint32_t)xhi + 1u));
-}
-
 template <int KM>
 LOAMX_HD void knn_init(KnnResult<KM>& r) {
   r.count = 0;
@@ -473,6 +444,210 @@ LOAMX_HD double knn_radius_bound(double max_dist) { return max_dist > 0.0 ? max_
 
 // The rounds of the search. Cubes of cells of growing half-width w around the query cell are
 // visited; after round w every unvisited point is farther than w*h along some axis.
+
+// Round 1 when it starts at the query's own cell: the 3x3x3 block, as one flattened candidate stream.
+template <class Coll>
+LOAMX_HD void knn_round1(const GridDesc& g, const uint32_t* __restrict__ cell_start, const GridPoint* __restrict__ sp, Vec3 q,
+                         int k, double r2, int32_t cx, int32_t cy, int32_t cz, Coll& r, uint32_t* row_scratch,
+                         int row_stride) {
+  // Common case: the 3x3x3 block. The cell_start entries of its nine rows are fetched up front
+  // (18 independent loads instead of nine dependent round trips). The non-empty rows are written
+  // to a small per-thread list (LDS in the kernels) in the order centre, faces, corners, and the
+  // lane then walks ONE flattened stream of 4-wide candidate batches over that list, skipping a
+  // row when its slab is already farther than the current bound. Flattening matters on the GPU:
+  // a wavefront then runs for max_lanes(sum of batches) instead of sum_rows(max_lanes(batches))
+  // (measured on the 64x1024 workload: 20.4 vs 37.0 batch steps per wavefront).
+  uint32_t rb[9], re[9];
+  const int32_t xa = cx - 1 < 0 ? 0 : cx - 1, xb = cx + 1 > g.nx - 1 ? g.nx - 1 : cx + 1;
+#pragma unroll
+  for (int j = 0; j < 9; j++) {
+    const int32_t iy = cy + (j % 3) - 1, iz = cz + (j / 3) - 1;
+    const bool ok = xa <= xb && iy >= 0 && iy <= g.ny - 1 && iz >= 0 && iz <= g.nz - 1;
+    const uint32_t row = ok ? (uint32_t)((iz * g.ny + iy) * g.nx) : 0u;
+    rb[j] = ok ? cell_start_at(cell_start, row + (uint32_t)xa) : 0u;
+    re[j] = ok ? cell_start_at(cell_start, row + (uint32_t)xb + 1u) : 0u;
+  }
+  int nrow = 0;
+#pragma unroll
+  for (int o = 0; o < 9; o++) {
+    constexpr int kOrder[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
+    const int j = kOrder[o];
+    if (rb[j] < re[j]) {
+      row_scratch[(2 * nrow) * row_stride] = rb[j] | ((uint32_t)j << 28);  // set sizes stay below 2^28
+      row_scratch[(2 * nrow + 1) * row_stride] = re[j];
+      nrow++;
+    }
+  }
+  // squared slab distances to the neighbouring rows (the query's own row is at distance 0)
+  double sy2m = slab_dist(q.y, g.oy, g.h, cy - 1), sy2p = slab_dist(q.y, g.oy, g.h, cy + 1);
+  double sz2m = slab_dist(q.z, g.oz, g.h, cz - 1), sz2p = slab_dist(q.z, g.oz, g.h, cz + 1);
+  sy2m *= sy2m, sy2p *= sy2p, sz2m *= sz2m, sz2p *= sz2p;
+  uint32_t p = 0, e = 0;
+  int ri = 0;
+  for (;;) {
+    while (p >= e && ri < nrow) {  // next admissible row
+      const uint32_t bj = row_scratch[(2 * ri) * row_stride], e2 = row_scratch[(2 * ri + 1) * row_stride];
+      ri++;
+      const int j = (int)(bj >> 28), jy = j % 3, jz = j / 3;
+      const double sy2 = jy == 0 ? sy2m : (jy == 1 ? 0.0 : sy2p), sz2 = jz == 0 ? sz2m : (jz == 1 ? 0.0 : sz2p);
+      const double worst = knn_bound(r, k);
+      const double bound = worst < r2 ? worst : r2;
+      if (sy2 + sz2 <= bound) {
+#if defined(LOAMX_KNN_STATS)
+        g_rows++;
+#endif
+        p = bj & 0x0FFFFFFFu, e = e2;
+      }
+    }
+    if (p >= e) break;
+    knn_scan_batch(r, k, q, sp, p, e - p);
+    p += 4;
+  }
+}
+
+// Round w > 1 (or a first round that starts away from the query's cell): cells at Chebyshev distance
+// <= w (first) or == w (later rounds). The row pieces are taken nine at a time: their extents are
+// computed from the current bound, the eighteen cell_start entries are fetched together, and the
+// candidates of all nine run through one flattened stream — three memory round trips per nine pieces
+// instead of two per piece.
+#ifndef LOAMX_ROUND_CHUNK
+#define LOAMX_ROUND_CHUNK 9
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LOAMX_WAVE_ANY(x) (__any((int)(x)) != 0)
+#else
+#define LOAMX_WAVE_ANY(x) (x)
+#endif
+constexpr int kRoundChunk = LOAMX_ROUND_CHUNK;  // <= 9 (row_scratch holds 18 words per thread)
+template <class Coll>
+LOAMX_HD void knn_general_round(const GridDesc& g, const uint32_t* __restrict__ cell_start,
+                                const GridPoint* __restrict__ sp, Vec3 q, int k, double r2, int32_t cx, int32_t cy,
+                                int32_t cz, Coll& r, int32_t w, bool first, uint32_t* row_scratch, int row_stride) {
+#if defined(LOAMX_KNN_STATS)
+  g_general++;
+#endif
+  int32_t dz = -w, dy = -w;
+  int sg = 0;
+  bool more = true;
+  // squared slab distances of the current row (dy, dz) and of the two end cells cx -+ w: recomputed only
+  // when the cursor moves to another row, so that a row out of reach costs a handful of instructions
+  double sz2 = slab_dist(q.z, g.oz, g.h, cz + dz), sy2 = slab_dist(q.y, g.oy, g.h, cy + dy);
+  sz2 *= sz2, sy2 *= sy2;
+  double sx2m = slab_dist(q.x, g.ox, g.h, cx - w), sx2p = slab_dist(q.x, g.ox, g.h, cx + w);
+  sx2m *= sx2m, sx2p *= sx2p;
+  while (more) {
+    // ---- collect up to kRoundChunk admissible pieces
+    int n = 0;
+    const double worst = knn_bound(r, k);
+    const double bound = worst < r2 ? worst : r2;
+    // (the cursor advances in lock-step for the whole wavefront: the chunk ends as soon as any lane's
+    // list is full, so dy / dz / sg stay wave-uniform and no lane waits for another's gaps)
+    while (more && !LOAMX_WAVE_ANY(n >= kRoundChunk)) {
+      const int32_t ady = dy < 0 ? -dy : dy, adz = dz < 0 ? -dz : dz;
+      const int nseg = (first || ady == w || adz == w) ? 1 : 2;  // full row, or just its two end cells
+      const int32_t iy = cy + dy, iz = cz + dz;
+      const double rowmin2 = sy2 + sz2;
+      if (iy >= 0 && iy <= g.ny - 1 && iz >= 0 && iz <= g.nz - 1 && rowmin2 <= bound) {
+        int32_t xlo = (nseg == 2 && sg == 1) ? cx + w : cx - w;
+        int32_t xhi = (nseg == 2 && sg == 0) ? cx - w : cx + w;
+        bool ok = true;
+        if (nseg == 2) {
+          ok = rowmin2 + (sg == 0 ? sx2m : sx2p) <= bound && xlo >= 0 && xlo <= g.nx - 1;
+        } else {
+          if (xlo < 0) xlo = 0;
+          if (xhi > g.nx - 1) xhi = g.nx - 1;
+          if (bound < kDblMax) {
+            // cells whose x slab is farther than sqrt(bound - rowmin2) cannot contribute
+            const double reach = sqrt(bound - rowmin2) + 1e-9 * g.h;
+            const int32_t xl = grid_cell_coord(q.x - reach, g.ox, g.inv_h), xh = grid_cell_coord(q.x + reach, g.ox, g.inv_h);
+            if (xl > xlo) xlo = xl;
+            if (xh < xhi) xhi = xh;
+          }
+          ok = xlo <= xhi;
+        }
+        if (ok) {
+          const uint32_t row = (uint32_t)((iz * g.ny + iy) * g.nx);
+          row_scratch[(2 * n) * row_stride] = row + (uint32_t)xlo;
+          row_scratch[(2 * n + 1) * row_stride] = row + (uint32_t)xhi + 1u;
+          n++;
+        }
+      }
+      if (++sg >= nseg) {
+        sg = 0;
+        if (++dy > w) {
+          dy = -w;
+          if (++dz > w) more = false;
+          sz2 = slab_dist(q.z, g.oz, g.h, cz + dz);
+          sz2 *= sz2;
+        }
+        sy2 = slab_dist(q.y, g.oy, g.h, cy + dy);
+        sy2 *= sy2;
+      }
+    }
+    // ---- their cell_start entries, all in flight together
+    uint32_t pb[kRoundChunk], pe[kRoundChunk];
+#pragma unroll
+    for (int j = 0; j < kRoundChunk; j++) {
+      const bool use = j < n;
+      const uint32_t a = use ? row_scratch[(2 * j) * row_stride] : 0u, b = use ? row_scratch[(2 * j + 1) * row_stride] : 0u;
+      pb[j] = use ? cell_start_at(cell_start, a) : 0u;
+      pe[j] = use ? cell_start_at(cell_start, b) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < kRoundChunk; j++) {
+      row_scratch[(2 * j) * row_stride] = pb[j];
+      row_scratch[(2 * j + 1) * row_stride] = pe[j];
+    }
+    // ---- one flattened candidate stream over the pieces
+    uint32_t p = 0, e = 0;
+    int ri = 0;
+    for (;;) {
+      while (p >= e && ri < n) {
+        p = row_scratch[(2 * ri) * row_stride], e = row_scratch[(2 * ri + 1) * row_stride];
+        ri++;
+#if defined(LOAMX_KNN_STATS)
+        if (p < e) g_rows++;
+#endif
+      }
+      if (p >= e) break;
+      knn_scan_batch(r, k, q, sp, p, e - p);
+      p += 4;
+    }
+  }
+}
+
+// Is the search over after the cube of half-width w?
+template <class Coll>
+LOAMX_HD bool knn_done(const GridDesc& g, Vec3 q, int k, double max_dist, int32_t cx, int32_t cy, int32_t cz, const Coll& r,
+                       int32_t w) {
+  // Every unvisited point lies beyond one of the six faces of the visited block of cells
+  // [c-w, c+w]^3, so it is at least as far as the nearest face that still has grid cells behind it
+  // (>= w*h; on average ~1.25*h for w = 1, which ends the search after the first round more often
+  // than the plain w*h bound). A face on the grid boundary has nothing behind it.
+  double guard = kDblMax;
+  {
+    const double m = 1e-9 * g.h;
+    const int32_t c3[3] = {cx, cy, cz}, n3[3] = {g.nx, g.ny, g.nz};
+    const double q3[3] = {q.x, q.y, q.z}, o3[3] = {g.ox, g.oy, g.oz};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      if (c3[a] - w > 0) {
+        const double d = (q3[a] - (o3[a] + (double)(c3[a] - w) * g.h)) * (1.0 - 1e-9) - m;
+        guard = d < guard ? d : guard;
+      }
+      if (c3[a] + w < n3[a] - 1) {
+        const double d = ((o3[a] + (double)(c3[a] + w + 1) * g.h) - q3[a]) * (1.0 - 1e-9) - m;
+        guard = d < guard ? d : guard;
+      }
+    }
+    if (guard < 0.0) guard = 0.0;
+  }
+  if (guard == kDblMax) return true;                       // the block covers the whole grid
+  if (knn_bound(r, k) < guard * guard) return true;        // k found (bound is DBL_MAX otherwise), all closer than anything unvisited
+  if (max_dist > 0.0 && guard >= max_dist) return true;    // anything unvisited fails the radius filter
+  return false;
+}
+
 template <class Coll>
 LOAMX_HD void knn_rounds(const GridDesc& g, const uint32_t* __restrict__ cell_start, const GridPoint* __restrict__ sp, Vec3 q,
                          int k, double max_dist, int32_t cx, int32_t cy, int32_t cz, Coll& r, int32_t w,
@@ -480,103 +655,10 @@ LOAMX_HD void knn_rounds(const GridDesc& g, const uint32_t* __restrict__ cell_st
   const double r2 = knn_radius_bound(max_dist);
   bool first = true;
   for (;;) {
-    if (first && w == 1) {
-      // Common case: the 3x3x3 block. The cell_start entries of its nine rows are fetched up front
-      // (18 independent loads instead of nine dependent round trips). The non-empty rows are written
-      // to a small per-thread list (LDS in the kernels) in the order centre, faces, corners, and the
-      // lane then walks ONE flattened stream of 4-wide candidate batches over that list, skipping a
-      // row when its slab is already farther than the current bound. Flattening matters on the GPU:
-      // a wavefront then runs for max_lanes(sum of batches) instead of sum_rows(max_lanes(batches))
-      // (measured on the 64x1024 workload: 20.4 vs 37.0 batch steps per wavefront).
-      uint32_t rb[9], re[9];
-      const int32_t xa = cx - 1 < 0 ? 0 : cx - 1, xb = cx + 1 > g.nx - 1 ? g.nx - 1 : cx + 1;
-#pragma unroll
-      for (int j = 0; j < 9; j++) {
-        const int32_t iy = cy + (j % 3) - 1, iz = cz + (j / 3) - 1;
-        const bool ok = xa <= xb && iy >= 0 && iy <= g.ny - 1 && iz >= 0 && iz <= g.nz - 1;
-        const uint32_t row = ok ? (uint32_t)((iz * g.ny + iy) * g.nx) : 0u;
-        rb[j] = ok ? cell_start_at(cell_start, row + (uint32_t)xa) : 0u;
-        re[j] = ok ? cell_start_at(cell_start, row + (uint32_t)xb + 1u) : 0u;
-      }
-      int nrow = 0;
-#pragma unroll
-      for (int o = 0; o < 9; o++) {
-        constexpr int kOrder[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
-        const int j = kOrder[o];
-        if (rb[j] < re[j]) {
-          row_scratch[(2 * nrow) * row_stride] = rb[j] | ((uint32_t)j << 28);  // set sizes stay below 2^28
-          row_scratch[(2 * nrow + 1) * row_stride] = re[j];
-          nrow++;
-        }
-      }
-      // squared slab distances to the neighbouring rows (the query's own row is at distance 0)
-      double sy2m = slab_dist(q.y, g.oy, g.h, cy - 1), sy2p = slab_dist(q.y, g.oy, g.h, cy + 1);
-      double sz2m = slab_dist(q.z, g.oz, g.h, cz - 1), sz2p = slab_dist(q.z, g.oz, g.h, cz + 1);
-      sy2m *= sy2m, sy2p *= sy2p, sz2m *= sz2m, sz2p *= sz2p;
-      uint32_t p = 0, e = 0;
-      int ri = 0;
-      for (;;) {
-        while (p >= e && ri < nrow) {  // next admissible row
-          const uint32_t bj = row_scratch[(2 * ri) * row_stride], e2 = row_scratch[(2 * ri + 1) * row_stride];
-          ri++;
-          const int j = (int)(bj >> 28), jy = j % 3, jz = j / 3;
-          const double sy2 = jy == 0 ? sy2m : (jy == 1 ? 0.0 : sy2p), sz2 = jz == 0 ? sz2m : (jz == 1 ? 0.0 : sz2p);
-          const double worst = knn_bound(r, k);
-          const double bound = worst < r2 ? worst : r2;
-          if (sy2 + sz2 <= bound) {
-#if defined(LOAMX_KNN_STATS)
-            g_rows++;
-#endif
-            p = bj & 0x0FFFFFFFu, e = e2;
-          }
-        }
-        if (p >= e) break;
-        knn_scan_batch(r, k, q, sp, p, e - p);
-        p += 4;
-      }
-    } else {
-      // general round: cells at Chebyshev distance <= w (first round) or == w (later rounds)
-#pragma unroll 1
-      for (int32_t dz = -w; dz <= w; dz++) {
-#pragma unroll 1
-        for (int32_t dy = -w; dy <= w; dy++) {
-          const int32_t ady = dy < 0 ? -dy : dy, adz = dz < 0 ? -dz : dz;
-          const int nseg = (first || ady == w || adz == w) ? 1 : 2;  // full row, or just its two end cells
-#pragma unroll 1
-          for (int sg = 0; sg < nseg; sg++) {
-            const int32_t xlo = (nseg == 2 && sg == 1) ? cx + w : cx - w;
-            const int32_t xhi = (nseg == 2 && sg == 0) ? cx - w : cx + w;
-            knn_scan_row(g, cell_start, sp, q, k, r2, cy + dy, cz + dz, xlo, xhi, r);
-          }
-        }
-      }
-    }
+    if (first && w == 1) knn_round1(g, cell_start, sp, q, k, r2, cx, cy, cz, r, row_scratch, row_stride);
+    else knn_general_round(g, cell_start, sp, q, k, r2, cx, cy, cz, r, w, first, row_scratch, row_stride);
     first = false;
-    // Every unvisited point lies beyond one of the six faces of the visited block of cells
-    // [c-w, c+w]^3, so it is at least as far as the nearest face that still has grid cells behind it
-    // (>= w*h; on average ~1.25*h for w = 1, which ends the search after the first round more often
-    // than the plain w*h bound). A face on the grid boundary has nothing behind it.
-    double guard = kDblMax;
-    {
-      const double m = 1e-9 * g.h;
-      const int32_t c3[3] = {cx, cy, cz}, n3[3] = {g.nx, g.ny, g.nz};
-      const double q3[3] = {q.x, q.y, q.z}, o3[3] = {g.ox, g.oy, g.oz};
-#pragma unroll
-      for (int a = 0; a < 3; a++) {
-        if (c3[a] - w > 0) {
-          const double d = (q3[a] - (o3[a] + (double)(c3[a] - w) * g.h)) * (1.0 - 1e-9) - m;
-          guard = d < guard ? d : guard;
-        }
-        if (c3[a] + w < n3[a] - 1) {
-          const double d = ((o3[a] + (double)(c3[a] + w + 1) * g.h) - q3[a]) * (1.0 - 1e-9) - m;
-          guard = d < guard ? d : guard;
-        }
-      }
-      if (guard < 0.0) guard = 0.0;
-    }
-    if (guard == kDblMax) break;                       // the block covers the whole grid
-    if (knn_bound(r, k) < guard * guard) break;        // k found (bound is DBL_MAX otherwise), all closer than anything unvisited
-    if (max_dist > 0.0 && guard >= max_dist) break;    // anything unvisited fails the radius filter
+    if (knn_done(g, q, k, max_dist, cx, cy, cz, r, w)) break;
     w++;
   }
 }
@@ -666,8 +748,35 @@ LOAMX_HD int knn_search_keyed(const GridDesc& g, const uint32_t* __restrict__ ce
   return knn_keys_finish(c, k, pass_max, pos);
 }
 
-// Keyed search with the exact collector re-running the rare undecided query (the kernels do the
-// re-run in a second launch, associate_knn_exact_kernel). Same shifted layout of pos.
+// The fast kernel's search: keyed collector, round 1 only. Returns the number of neighbours kept, or
+// -1 when the query needs more than that — it starts outside the grid's first shell, the search is
+// not over after the 3x3x3 block, or the keys are undecided. Such queries (a few per cent, in sparse
+// regions) are queued and searched completely by a second kernel on dense wavefronts, instead of
+// dragging every wavefront of this one through the row-by-row outer rounds.
+template <int KM>
+LOAMX_HD int knn_search_keyed_round1(const GridDesc& g, const uint32_t* __restrict__ cell_start,
+                                     const GridPoint* __restrict__ sp, Vec3 q, int k, double max_dist, double pass_max,
+                                     uint32_t pos[KM], uint32_t* row_scratch, int row_stride) {
+#pragma unroll
+  for (int j = 0; j < KM; j++) pos[j] = 0;
+  if (g.n_points == 0 || k <= 0) return 0;
+  if (k > KM) k = KM;
+  const int32_t cx = grid_cell_coord(q.x, g.ox, g.inv_h);
+  const int32_t cy = grid_cell_coord(q.y, g.oy, g.inv_h);
+  const int32_t cz = grid_cell_coord(q.z, g.oz, g.inv_h);
+  const int32_t out = grid_outside_distance(g, cx, cy, cz);
+  if (max_dist > 0.0 && out >= 1 && (double)(out - 1) * g.h >= max_dist) return 0;
+  if (out > 1) return -1;
+  KnnKeys<KM> c;
+  knn_init(c, k, g.n_points);
+  knn_round1(g, cell_start, sp, q, k, knn_radius_bound(max_dist), cx, cy, cz, c, row_scratch, row_stride);
+  if (!knn_done(g, q, k, max_dist, cx, cy, cz, c, 1)) return -1;
+  return knn_keys_finish(c, k, pass_max, pos);
+}
+
+// The complete search: keyed collector over all rounds, then the exact collector for a query whose
+// keys are undecided (associate_knn_rest_kernel; queries queued by the round-1 kernel). Same shifted
+// layout of pos.
 // `fallbacks`, when given, counts the re-runs.
 template <int KM>
 LOAMX_HD int knn_search_positions(const GridDesc& g, const uint32_t* __restrict__ cell_start,

@@ -182,10 +182,7 @@ __global__ void state_init_kernel(RegBatch B, RegConfig C) {
   S.iterations = 0;
   S.first_sweep = 0;
   S.lm.active = 0;
-  B.assoc.n_assoc[4 * pair] = 0;
-  B.assoc.n_assoc[4 * pair + 1] = 0;
-  B.assoc.n_assoc[4 * pair + 2] = 0;
-  B.assoc.n_assoc[4 * pair + 3] = 0;
+  for (int c = 0; c < 6; c++) B.assoc.n_assoc[8 * pair + c] = 0;
 }
 
 constexpr int kAssocThreads = 256;
@@ -209,6 +206,98 @@ __device__ __forceinline__ bool xcd_pair_map(uint32_t block, uint32_t blocks_per
   return pair < n_pairs;
 }
 
+// Small target sets (a few hundred edge features per scan) are searched exhaustively: the whole set
+// streams through LDS in tiles and every lane scans all of it — no divergence, no dependent loads,
+// and none of the empty-cell rounds a grid search spends on sparse sets. Same collectors, same result.
+constexpr uint32_t kBruteMax = 512;
+constexpr int kBruteTile = 256;
+
+template <class Coll>
+__device__ __forceinline__ void brute_scan_tile(Coll& c, int k, Vec3 q, const GridPoint* s_tile, uint32_t tile, uint32_t tn) {
+  for (uint32_t u = 0; u < tn; u += 4) {
+    const GridPoint t0 = s_tile[u], t1 = s_tile[u + 1], t2 = s_tile[u + 2], t3 = s_tile[u + 3];
+    // nanoflann L2_Simple: ((dx^2 + dy^2) + dz^2), as knn_scan_batch
+    double dx = q.x - t0.x, dy = q.y - t0.y, dz = q.z - t0.z;
+    const double d0 = dx * dx + dy * dy + dz * dz;
+    dx = q.x - t1.x, dy = q.y - t1.y, dz = q.z - t1.z;
+    const double d1 = dx * dx + dy * dy + dz * dz;
+    dx = q.x - t2.x, dy = q.y - t2.y, dz = q.z - t2.z;
+    const double d2 = dx * dx + dy * dy + dz * dz;
+    dx = q.x - t3.x, dy = q.y - t3.y, dz = q.z - t3.z;
+    const double d3 = dx * dx + dy * dy + dz * dz;
+    knn_offer4(c, k, d0, d1, d2, d3, tile + u, tn - u, t0.orig, t1.orig, t2.orig, t3.orig);
+  }
+}
+
+template <bool PLANE, int KM>
+__global__ __launch_bounds__(kAssocThreads) void associate_knn_brute_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
+  size_t pair;
+  uint32_t chunk;
+  if (!xcd_pair_map(blockIdx.x, blocks_per_pair, B.n_pairs, pair, chunk)) return;
+  const PairState& S = B.state[pair];
+  if (!S.active) return;  // uniform per workgroup
+  const GridSet& gs = PLANE ? B.grid_plane : B.grid_edge;
+  const uint32_t n_tgt = gs.desc[pair].n_points;
+  if (n_tgt > kBruteMax) return;  // uniform: the grid kernels take this pair
+  const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
+  const uint32_t n_src = PLANE ? B.n_src_planar[pair * B.in_pitch] : B.n_src_edge[pair * B.in_pitch];
+  if (chunk * kAssocThreads >= n_src || chunk * kAssocThreads >= stride) return;  // uniform: no query here
+  const uint32_t i = chunk * kAssocThreads + threadIdx.x;
+  const bool has = i < n_src && i < stride;
+  const GridSet& src_gs = PLANE ? B.src_grid_plane : B.src_grid_edge;
+  const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
+  __shared__ GridPoint s_tile[kBruteTile + kGridPad];
+  Vec3 p = v3(0, 0, 0);
+  if (has) {
+    const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
+    p = pose_act(S.est, v3(sq.x, sq.y, sq.z));  // registration.cpp:34 / :75
+  }
+  int k = PLANE ? C.k_plane : C.k_edge;
+  k = k < KM ? k : KM;
+  const double max_dist = PLANE ? C.r_plane : C.r_edge;
+  uint32_t pos[KM];
+#pragma unroll
+  for (int j = 0; j < KM; j++) pos[j] = 0;
+  int kept = 0;
+  if (k > 0 && n_tgt > 0) {
+    KnnKeys<KM> c;
+    knn_init(c, k, n_tgt);
+    for (uint32_t tile = 0; tile < n_tgt; tile += kBruteTile) {
+      const uint32_t tn = n_tgt - tile < (uint32_t)kBruteTile ? n_tgt - tile : (uint32_t)kBruteTile;
+      __syncthreads();
+      for (uint32_t t = threadIdx.x; t < tn + kGridPad; t += kAssocThreads) s_tile[t] = sp[tile + t];  // (the set has kGridPad spare entries)
+      __syncthreads();
+      if (has) brute_scan_tile(c, k, p, s_tile, tile, tn);
+    }
+    kept = has ? knn_keys_finish(c, k, PLANE ? C.pass_plane : C.pass_edge, pos) : 0;
+    if (__syncthreads_or(kept < 0)) {  // undecided keys somewhere in the workgroup: exact collector for those lanes
+      KnnResult<KM> r;
+      knn_init(r);
+      for (uint32_t tile = 0; tile < n_tgt; tile += kBruteTile) {
+        const uint32_t tn = n_tgt - tile < (uint32_t)kBruteTile ? n_tgt - tile : (uint32_t)kBruteTile;
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < tn + kGridPad; t += kAssocThreads) s_tile[t] = sp[tile + t];
+        __syncthreads();
+        if (kept < 0) brute_scan_tile(r, k, p, s_tile, tile, tn);
+      }
+      if (kept < 0) {
+        kept = knn_finish(r, k, max_dist);
+#pragma unroll
+        for (int j = 0; j < KM; j++) pos[j] = 0;
+#pragma unroll
+        for (int jj = 0; jj < KM; jj++)
+          if (jj < k) pos[(KM - k) + jj] = r.pos[jj];
+      }
+    }
+  }
+  if (!has) return;
+  const size_t field = B.n_pairs * stride, slot = pair * stride + i;
+  uint32_t* __restrict__ nn = PLANE ? B.assoc.nn_plane : B.assoc.nn_edge;
+  nn[slot] = (uint32_t)kept;
+#pragma unroll
+  for (int j = 0; j < KM; j++) nn[(1 + j) * field + slot] = pos[j];
+}
+
 // Association is split in two kernels so that each runs at its own register budget:
 //   associate_knn_kernel : the latency-bound grid walk; writes the neighbour count and the positions
 //                          (in the cell-sorted target array) of the k nearest, ascending.
@@ -229,43 +318,92 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_kn
   const GridSet& src_gs = PLANE ? B.src_grid_plane : B.src_grid_edge;
   if (chunk == 0 && threadIdx.x == 0 && B.assoc_slots)
     atomicAdd(&B.assoc_slots[PLANE ? 1 : 0], (unsigned long long)(n_src < stride ? n_src : stride));
+  const GridDesc g = gs.desc[pair];
+  if (g.n_points <= kBruteMax) return;  // uniform: small target sets belong to associate_knn_brute_kernel
   if (i >= n_src || i >= stride) return;
   // queries are taken in the source set's own cell order: neighbouring lanes look at neighbouring
   // target cells (shared cache lines, similar trip counts)
   const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
   const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));  // registration.cpp:34 / :75
-  const GridDesc g = gs.desc[pair];
   const uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
   const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
   __shared__ uint32_t s_rows[18 * kAssocThreads];  // per-thread list of non-empty rows, [word][thread] (conflict free)
   uint32_t pos[KM];
-  const int kept = knn_search_keyed<KM>(g, cs, sp, p, PLANE ? C.k_plane : C.k_edge, PLANE ? C.r_plane : C.r_edge,
-                                        PLANE ? C.pass_plane : C.pass_edge, pos, s_rows + threadIdx.x, kAssocThreads);
+  const int kept = knn_search_keyed_round1<KM>(g, cs, sp, p, PLANE ? C.k_plane : C.k_edge, PLANE ? C.r_plane : C.r_edge,
+                                               PLANE ? C.pass_plane : C.pass_edge, pos, s_rows + threadIdx.x, kAssocThreads);
   const size_t field = B.n_pairs * stride, slot = pair * stride + i;
   uint32_t* __restrict__ nn = PLANE ? B.assoc.nn_plane : B.assoc.nn_edge;  // [1 + KM][n_pairs * stride]
-  nn[slot] = (uint32_t)kept;  // 0xFFFFFFFF: undecided by the keys, left to associate_knn_exact_kernel
-  if (kept < 0) atomicAdd(&B.assoc.n_assoc[4 * pair + (PLANE ? 3 : 2)], 1u);
+  nn[slot] = (uint32_t)kept;
+  if (kept < 0) {  // not finished by round 1: queued for associate_knn_rest_kernel
+    const uint32_t at = atomicAdd(&B.assoc.n_assoc[8 * pair + (PLANE ? 3 : 2)], 1u);
+    (PLANE ? B.assoc.rest_plane : B.assoc.rest_edge)[pair * stride + at] = i;
+  }
 #pragma unroll
   for (int j = 0; j < KM; j++) nn[(1 + j) * field + slot] = pos[j];  // neighbour j is slot (KM - k) + j
 }
 
-// Second pass of the k-NN: the queries the keyed collector could not decide (exact distance ties,
-// a truncated distance straddling the radius) are searched again with the exact (d2, index)
-// collector. Workgroups of pairs without such queries leave after one scalar load.
+// Second pass of the k-NN: the queries round 1 could not finish (sparse regions where the 3x3x3 block
+// does not hold k points close enough, queries outside the grid, undecided keys) were queued per
+// pair; here the keyed collector searches them over all rounds, on wavefronts that are dense again.
+// What the keys still cannot decide is queued once more, for associate_knn_exact_kernel.
+// Workgroups of pairs with an empty queue leave after one scalar load.
+#ifndef LOAMX_REST_THREADS
+#define LOAMX_REST_THREADS 64
+#endif
+constexpr int kRestThreads = LOAMX_REST_THREADS;  // small workgroups: the queues are short and uneven
 template <bool PLANE, int KM>
-__global__ __launch_bounds__(kAssocThreads) void associate_knn_exact_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair,
-                                                                           uint32_t chunks_per_pair) {
+__global__ __launch_bounds__(kRestThreads) void associate_knn_rest_kernel(RegBatch B, RegConfig C,
+                                                                                              uint32_t blocks_per_pair) {
   size_t pair;
   uint32_t chunk0;
   if (!xcd_pair_map(blockIdx.x, blocks_per_pair, B.n_pairs, pair, chunk0)) return;
   const PairState& S = B.state[pair];
   if (!S.active) return;                                              // uniform per workgroup
-  if (B.assoc.n_assoc[4 * pair + (PLANE ? 3 : 2)] == 0u) return;      // uniform per workgroup
+  const uint32_t queued = B.assoc.n_assoc[8 * pair + (PLANE ? 3 : 2)];
+  if (queued == 0u) return;                                           // uniform per workgroup
+  __shared__ uint32_t s_rows[18 * kRestThreads];
+  const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
+  const size_t field = B.n_pairs * stride;
+  uint32_t* __restrict__ rnn = PLANE ? B.assoc.rnn_plane : B.assoc.rnn_edge;  // results by queue position
+  const uint32_t* __restrict__ rest = (PLANE ? B.assoc.rest_plane : B.assoc.rest_edge) + pair * stride;
+  uint32_t* __restrict__ exact = (PLANE ? B.assoc.exact_plane : B.assoc.exact_edge) + pair * stride;
+  const GridSet& gs = PLANE ? B.grid_plane : B.grid_edge;
+  const GridSet& src_gs = PLANE ? B.src_grid_plane : B.src_grid_edge;
+  const GridDesc g = gs.desc[pair];
+  const uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
+  const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
+  for (uint32_t t = chunk0 * kRestThreads + threadIdx.x; t < queued; t += blocks_per_pair * kRestThreads) {
+    const uint32_t i = rest[t];
+    const size_t slot = pair * stride + t;  // (queue position, not query index)
+    const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
+    const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));
+    uint32_t pos[KM];
+    const int kept = knn_search_keyed<KM>(g, cs, sp, p, PLANE ? C.k_plane : C.k_edge, PLANE ? C.r_plane : C.r_edge,
+                                          PLANE ? C.pass_plane : C.pass_edge, pos, s_rows + threadIdx.x, kRestThreads);
+    rnn[slot] = (uint32_t)kept;
+    if (kept < 0) exact[atomicAdd(&B.assoc.n_assoc[8 * pair + (PLANE ? 5 : 4)], 1u)] = t;
+#pragma unroll
+    for (int j = 0; j < KM; j++) rnn[(1 + j) * field + slot] = pos[j];
+  }
+}
+
+// Third pass: the queries whose keys stayed undecided (exact distance ties, a truncated distance
+// straddling the radius) are searched with the exact (d2, index) collector.
+template <bool PLANE, int KM>
+__global__ __launch_bounds__(kAssocThreads) void associate_knn_exact_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
+  size_t pair;
+  uint32_t chunk0;
+  if (!xcd_pair_map(blockIdx.x, blocks_per_pair, B.n_pairs, pair, chunk0)) return;
+  const PairState& S = B.state[pair];
+  if (!S.active) return;                                              // uniform per workgroup
+  const uint32_t queued = B.assoc.n_assoc[8 * pair + (PLANE ? 5 : 4)];
+  if (queued == 0u) return;                                           // uniform per workgroup
   __shared__ uint32_t s_rows[18 * kAssocThreads];
   const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
-  const uint32_t n_src = PLANE ? B.n_src_planar[pair * B.in_pitch] : B.n_src_edge[pair * B.in_pitch];
   const size_t field = B.n_pairs * stride;
-  uint32_t* __restrict__ nn = PLANE ? B.assoc.nn_plane : B.assoc.nn_edge;
+  uint32_t* __restrict__ rnn = PLANE ? B.assoc.rnn_plane : B.assoc.rnn_edge;
+  const uint32_t* __restrict__ rest = (PLANE ? B.assoc.rest_plane : B.assoc.rest_edge) + pair * stride;
+  const uint32_t* __restrict__ exact = (PLANE ? B.assoc.exact_plane : B.assoc.exact_edge) + pair * stride;
   const GridSet& gs = PLANE ? B.grid_plane : B.grid_edge;
   const GridSet& src_gs = PLANE ? B.src_grid_plane : B.src_grid_edge;
   const GridDesc g = gs.desc[pair];
@@ -273,23 +411,75 @@ __global__ __launch_bounds__(kAssocThreads) void associate_knn_exact_kernel(RegB
   const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
   int k = PLANE ? C.k_plane : C.k_edge;
   k = k < KM ? k : KM;
-  // a few workgroups per pair walk all of its query chunks (undecided queries are rare)
-  for (uint32_t chunk = chunk0; chunk < chunks_per_pair; chunk += blocks_per_pair) {
-    const uint32_t i = chunk * kAssocThreads + threadIdx.x;
-    if (i >= n_src || i >= stride) continue;
-    const size_t slot = pair * stride + i;
-    if (nn[slot] != 0xFFFFFFFFu) continue;
+  for (uint32_t t = chunk0 * kAssocThreads + threadIdx.x; t < queued; t += blocks_per_pair * kAssocThreads) {
+    const uint32_t qpos = exact[t], i = rest[qpos];
+    const size_t slot = pair * stride + qpos;
     const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
     const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));
     KnnResult<KM> r;
     const int kept = knn_search(g, cs, sp, p, k, PLANE ? C.r_plane : C.r_edge, r, s_rows + threadIdx.x, kAssocThreads);
-    nn[slot] = (uint32_t)kept;
+    rnn[slot] = (uint32_t)kept;
 #pragma unroll
     for (int j = 0; j < KM; j++)
-      if (j < k) nn[(size_t)(1 + (KM - k) + j) * field + slot] = r.pos[j];
+      if (j < k) rnn[(size_t)(1 + (KM - k) + j) * field + slot] = r.pos[j];
   }
 }
 
+// fitLine / fitPlane on the neighbours of query i of `pair` and its association record; the neighbour
+// count and positions are read at index nidx of the (1 + KM)-field array nnsrc. Returns "valid".
+template <bool PLANE, int KM>
+__device__ __forceinline__ bool fit_one(const RegBatch& B, const RegConfig& C, const PairState& S, size_t pair, uint32_t i,
+                                        const uint32_t* __restrict__ nnsrc, size_t nidx) {
+  const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
+  const GridSet& gs = PLANE ? B.grid_plane : B.grid_edge;
+  const GridSet& src_gs = PLANE ? B.src_grid_plane : B.src_grid_edge;
+  const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
+  const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));
+  const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
+  const size_t field = B.n_pairs * stride, slot = pair * stride + i;
+  const int kept = (int)nnsrc[nidx];
+  const int kq = PLANE ? C.k_plane : C.k_edge;
+  const int shift = KM - (kq < KM ? kq : KM);  // neighbour j is slot shift + j (knn_search_positions)
+  double prim[6] = {0, 0, 0, 0, 0, 0};
+  uint32_t nearest = 0xFFFFFFFFu;
+  bool valid = false;
+  if (kept >= (PLANE ? C.min_plane_pts : C.min_line_pts)) {  // registration.cpp:39 / :80
+    Vec3 nb[KM];
+#pragma unroll
+    for (int j = 0; j < KM; j++) {
+      if (j < kept) {
+        const GridPoint t = sp[nnsrc[(1 + shift + j) * field + nidx]];
+        nb[j] = v3(t.x, t.y, t.z);
+        if (j == 0) nearest = t.orig;
+      } else {
+        nb[j] = v3(0, 0, 0);
+      }
+    }
+    if (PLANE) {
+      Vec3 nrm;
+      double d;
+      const double avg = fit_plane<KM>(nb, kept, nrm, d);
+      valid = !(avg > C.max_avg_plane_dist);  // registration.cpp:90
+      prim[0] = nrm.x, prim[1] = nrm.y, prim[2] = nrm.z, prim[3] = d;
+    } else {
+      Vec3 a, b;
+      fit_line<KM>(nb, kept, a, b);
+      valid = !(kDblMax < C.min_line_cond);  // registration.cpp:49 (condition number is always DBL_MAX)
+      prim[0] = a.x, prim[1] = a.y, prim[2] = a.z, prim[3] = b.x, prim[4] = b.y, prim[5] = b.z;
+    }
+  }
+  double* __restrict__ rec = PLANE ? B.assoc.plane : B.assoc.edge;
+  rec[slot] = valid ? p.x : __longlong_as_double(0x7FF8000000000000ll);
+  rec[field + slot] = p.y;
+  rec[2 * field + slot] = p.z;
+#pragma unroll
+  for (int f = 0; f < (PLANE ? 4 : 6); f++) rec[(3 + f) * field + slot] = prim[f];
+  // detail capture is indexed by the caller's source index
+  (PLANE ? B.assoc.nearest_plane : B.assoc.nearest_edge)[pair * stride + sq.orig] = valid ? nearest : 0xFFFFFFFFu;
+  return valid;
+}
+
+// The queries round 1 of the k-NN finished (everything but the queued ones, whose count stays 0xFFFFFFFF in nn).
 template <bool PLANE, int KM>
 __global__ __launch_bounds__(kAssocThreads) void associate_fit_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
   __shared__ uint32_t s_count[kAssocThreads / 64];
@@ -301,62 +491,39 @@ __global__ __launch_bounds__(kAssocThreads) void associate_fit_kernel(RegBatch B
   if (!S.active) return;  // uniform per workgroup
   const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
   const uint32_t n_src = PLANE ? B.n_src_planar[pair * B.in_pitch] : B.n_src_edge[pair * B.in_pitch];
-  const GridSet& gs = PLANE ? B.grid_plane : B.grid_edge;
-  const GridSet& src_gs = PLANE ? B.src_grid_plane : B.src_grid_edge;
+  const uint32_t* __restrict__ nn = PLANE ? B.assoc.nn_plane : B.assoc.nn_edge;
   bool valid = false;
-  if (i < n_src && i < stride) {
-    const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
-    const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));
-    const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
-    const size_t field = B.n_pairs * stride, slot = pair * stride + i;
-    const uint32_t* __restrict__ nn = PLANE ? B.assoc.nn_plane : B.assoc.nn_edge;
-    const int kept = (int)nn[slot];
-    const int kq = PLANE ? C.k_plane : C.k_edge;
-    const int shift = KM - (kq < KM ? kq : KM);  // neighbour j is slot shift + j (knn_search_positions)
-    double prim[6] = {0, 0, 0, 0, 0, 0};
-    uint32_t nearest = 0xFFFFFFFFu;
-    if (kept >= (PLANE ? C.min_plane_pts : C.min_line_pts)) {  // registration.cpp:39 / :80
-      Vec3 nb[KM];
-#pragma unroll
-      for (int j = 0; j < KM; j++) {
-        if (j < kept) {
-          const GridPoint t = sp[nn[(1 + shift + j) * field + slot]];
-          nb[j] = v3(t.x, t.y, t.z);
-          if (j == 0) nearest = t.orig;
-        } else {
-          nb[j] = v3(0, 0, 0);
-        }
-      }
-      if (PLANE) {
-        Vec3 nrm;
-        double d;
-        const double avg = fit_plane<KM>(nb, kept, nrm, d);
-        valid = !(avg > C.max_avg_plane_dist);  // registration.cpp:90
-        prim[0] = nrm.x, prim[1] = nrm.y, prim[2] = nrm.z, prim[3] = d;
-      } else {
-        Vec3 a, b;
-        fit_line<KM>(nb, kept, a, b);
-        valid = !(kDblMax < C.min_line_cond);  // registration.cpp:49 (condition number is always DBL_MAX)
-        prim[0] = a.x, prim[1] = a.y, prim[2] = a.z, prim[3] = b.x, prim[4] = b.y, prim[5] = b.z;
-      }
-    }
-    double* __restrict__ rec = PLANE ? B.assoc.plane : B.assoc.edge;
-    rec[slot] = valid ? p.x : __longlong_as_double(0x7FF8000000000000ll);
-    rec[field + slot] = p.y;
-    rec[2 * field + slot] = p.z;
-#pragma unroll
-    for (int f = 0; f < (PLANE ? 4 : 6); f++) rec[(3 + f) * field + slot] = prim[f];
-    // detail capture is indexed by the caller's source index
-    (PLANE ? B.assoc.nearest_plane : B.assoc.nearest_edge)[pair * stride + sq.orig] = valid ? nearest : 0xFFFFFFFFu;
-  }
+  if (i < n_src && i < stride && nn[pair * stride + i] != 0xFFFFFFFFu) valid = fit_one<PLANE, KM>(B, C, S, pair, i, nn, pair * stride + i);
   const unsigned long long m = __ballot(valid);
   if ((threadIdx.x & 63) == 0) s_count[threadIdx.x >> 6] = (uint32_t)__popcll(m);
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t c = 0;
     for (int w = 0; w < kAssocThreads / 64; w++) c += s_count[w];
-    if (c) atomicAdd(&B.assoc.n_assoc[4 * pair + (PLANE ? 1 : 0)], c);
+    if (c) atomicAdd(&B.assoc.n_assoc[8 * pair + (PLANE ? 1 : 0)], c);
   }
+}
+
+// The queued queries, after associate_knn_rest_kernel / associate_knn_exact_kernel: same fit, results
+// read by queue position.
+template <bool PLANE, int KM>
+__global__ __launch_bounds__(kRestThreads) void associate_fit_queued_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
+  size_t pair;
+  uint32_t chunk0;
+  if (!xcd_pair_map(blockIdx.x, blocks_per_pair, B.n_pairs, pair, chunk0)) return;
+  const PairState& S = B.state[pair];
+  if (!S.active) return;                                              // uniform per workgroup
+  const uint32_t queued = B.assoc.n_assoc[8 * pair + (PLANE ? 3 : 2)];
+  if (queued == 0u) return;                                           // uniform per workgroup
+  const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
+  const uint32_t* __restrict__ rnn = PLANE ? B.assoc.rnn_plane : B.assoc.rnn_edge;
+  const uint32_t* __restrict__ rest = (PLANE ? B.assoc.rest_plane : B.assoc.rest_edge) + pair * stride;
+  uint32_t count = 0;
+  for (uint32_t t = chunk0 * kRestThreads + threadIdx.x; t < queued; t += blocks_per_pair * kRestThreads)
+    count += fit_one<PLANE, KM>(B, C, S, pair, rest[t], rnn, pair * stride + t) ? 1u : 0u;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) count += __shfl_xor(count, off);
+  if ((threadIdx.x & 63) == 0 && count) atomicAdd(&B.assoc.n_assoc[8 * pair + (PLANE ? 1 : 0)], count);
 }
 
 __global__ __launch_bounds__(64) void lm_begin_kernel(RegBatch B, RegConfig C, uint32_t iteration) {
@@ -364,11 +531,8 @@ __global__ __launch_bounds__(64) void lm_begin_kernel(RegBatch B, RegConfig C, u
   if (pair >= B.n_pairs) return;
   PairState& S = B.state[pair];
   if (!S.active) return;
-  const uint32_t ne = B.assoc.n_assoc[4 * pair], np = B.assoc.n_assoc[4 * pair + 1];
-  B.assoc.n_assoc[4 * pair] = 0;
-  B.assoc.n_assoc[4 * pair + 1] = 0;
-  B.assoc.n_assoc[4 * pair + 2] = 0;
-  B.assoc.n_assoc[4 * pair + 3] = 0;
+  const uint32_t ne = B.assoc.n_assoc[8 * pair], np = B.assoc.n_assoc[8 * pair + 1];
+  for (int c = 0; c < 6; c++) B.assoc.n_assoc[8 * pair + c] = 0;
   if ((uint64_t)ne + np < C.min_associations) {  // registration-inl.h:45-48
     S.termination = LOAMX_INSUFFICIENT_ASSOCIATIONS;
     S.active = 0;
@@ -561,38 +725,64 @@ void launch_state_init(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   hipLaunchKernelGGL(state_init_kernel, dim3(per_pair_grid(B.n_pairs)), dim3(64), 0, s, B, C);
 }
 
+#ifndef LOAMX_REST_BLOCKS
+#define LOAMX_REST_BLOCKS 16u
+#endif
 void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipStream_t aux, hipEvent_t ev_fork,
-                      hipEvent_t ev_join) {
+                      hipEvent_t ev_mid, hipEvent_t ev_join) {
   if (B.n_pairs == 0) return;
   const uint32_t be = (uint32_t)((B.edge_stride + kAssocThreads - 1) / kAssocThreads);
   const uint32_t bp = (uint32_t)((B.planar_stride + kAssocThreads - 1) / kAssocThreads);
   const size_t pair_groups = (B.n_pairs + 7) / 8;  // grid covers 8 XCD lanes x pair_groups x chunks
   // register-resident neighbour lists are instantiated for K <= 5 (the reference's default) and K <= 8
-#define LOAMX_LAUNCH_ASSOC(PL, KMV, nblk, st)                                                                \
-  do {                                                                                                       \
-    const dim3 grid_((unsigned)(pair_groups * 8 * (nblk)));                                                  \
-    hipLaunchKernelGGL((associate_knn_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, (st), B, C, (nblk));  \
-    const uint32_t xblk_ = (nblk) < 2u ? (nblk) : 2u;                                                         \
-    hipLaunchKernelGGL((associate_knn_exact_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * xblk_)),     \
-                       dim3(kAssocThreads), 0, (st), B, C, xblk_, (nblk));                                   \
-    hipLaunchKernelGGL((associate_fit_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, (st), B, C, (nblk));  \
+  // Per feature kind, two chains: A = brute force (small target sets) | round-1 k-NN -> fit of the
+  // finished queries; B = k-NN of the queued queries (all rounds, then exact) -> their fit. B needs
+  // only the round-1 kernel of A, and its short, uneven queues leave most of the GPU idle, so it runs on
+  // the auxiliary stream next to A's fit kernel. The edge chains (small sets) run on the auxiliary
+  // stream next to the plane round-1 kernel.
+#define LOAMX_ASSOC_A1(PL, KMV, nblk, st)                                                                         \
+  do {                                                                                                            \
+    const dim3 grid_((unsigned)(pair_groups * 8 * (nblk)));                                                       \
+    hipLaunchKernelGGL((associate_knn_brute_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, (st), B, C, (nblk)); \
+    hipLaunchKernelGGL((associate_knn_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, (st), B, C, (nblk));       \
   } while (0)
-  // The edge chain (small sets: a few latency-bound workgroups per pair) runs on the auxiliary stream
-  // next to the plane chain, which it shares no buffers with, instead of in front of it.
-  const bool fork = aux != nullptr && be != 0 && bp != 0 && hipEventRecord(ev_fork, s) == hipSuccess &&
+#define LOAMX_ASSOC_A2(PL, KMV, nblk, st)                                                                         \
+  hipLaunchKernelGGL((associate_fit_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * (nblk))), dim3(kAssocThreads), 0, \
+                     (st), B, C, (nblk))
+#define LOAMX_ASSOC_B(PL, KMV, nblk, st)                                                                          \
+  do {                                                                                                            \
+    const uint32_t rblk_ = LOAMX_REST_BLOCKS, xblk_ = (nblk) < 2u ? (nblk) : 2u;                                   \
+    hipLaunchKernelGGL((associate_knn_rest_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * rblk_)),           \
+                       dim3(kRestThreads), 0, (st), B, C, rblk_);                                                 \
+    hipLaunchKernelGGL((associate_knn_exact_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * xblk_)),          \
+                       dim3(kAssocThreads), 0, (st), B, C, xblk_);                                                \
+    hipLaunchKernelGGL((associate_fit_queued_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * rblk_)),         \
+                       dim3(kRestThreads), 0, (st), B, C, rblk_);                                                 \
+  } while (0)
+#define LOAMX_ASSOC_K(STEP, PL, nblk, st)                \
+  do {                                                   \
+    if ((PL ? C.k_plane : C.k_edge) <= 5) STEP(PL, 5, nblk, st); \
+    else STEP(PL, 8, nblk, st);                          \
+  } while (0)
+  const bool fork = aux != nullptr && hipEventRecord(ev_fork, s) == hipSuccess &&
                     hipStreamWaitEvent(aux, ev_fork, 0) == hipSuccess;
-  hipStream_t se = fork ? aux : s;
-  if (be) {
-    if (C.k_edge <= 5) LOAMX_LAUNCH_ASSOC(false, 5, be, se);
-    else LOAMX_LAUNCH_ASSOC(false, 8, be, se);
+  hipStream_t sa = fork ? aux : s;
+  if (be) {  // edge chains, whole
+    LOAMX_ASSOC_K(LOAMX_ASSOC_A1, false, be, sa);
+    LOAMX_ASSOC_K(LOAMX_ASSOC_A2, false, be, sa);
+    LOAMX_ASSOC_K(LOAMX_ASSOC_B, false, be, sa);
   }
-  if (fork) (void)hipEventRecord(ev_join, aux);
   if (bp) {
-    if (C.k_plane <= 5) LOAMX_LAUNCH_ASSOC(true, 5, bp, s);
-    else LOAMX_LAUNCH_ASSOC(true, 8, bp, s);
+    LOAMX_ASSOC_K(LOAMX_ASSOC_A1, true, bp, s);
+    const bool fork2 = fork && hipEventRecord(ev_mid, s) == hipSuccess && hipStreamWaitEvent(aux, ev_mid, 0) == hipSuccess;
+    LOAMX_ASSOC_K(LOAMX_ASSOC_A2, true, bp, s);
+    LOAMX_ASSOC_K(LOAMX_ASSOC_B, true, bp, (fork2 ? aux : s));
   }
-  if (fork) (void)hipStreamWaitEvent(s, ev_join, 0);
-#undef LOAMX_LAUNCH_ASSOC
+  if (fork && hipEventRecord(ev_join, aux) == hipSuccess) (void)hipStreamWaitEvent(s, ev_join, 0);
+#undef LOAMX_ASSOC_A1
+#undef LOAMX_ASSOC_A2
+#undef LOAMX_ASSOC_B
+#undef LOAMX_ASSOC_K
 }
 
 void launch_sweep(const RegBatch& B, hipStream_t s) {

@@ -246,12 +246,17 @@ static void build_grid(const double* pts, uint32_t n, double max_dist, HostGrid&
 extern "C++" {
 // Runs the keyed fast path (what the kernels run) and the exact collector on the same query and
 // requires identical answers; returns the answer. g_knn_fallbacks counts undecided keyed queries.
-static uint64_t g_knn_fallbacks = 0, g_knn_mismatch = 0;
+static uint64_t g_knn_fallbacks = 0, g_knn_mismatch = 0, g_knn_queued = 0;
 template <int KM>
 static int knn_both(const HostGrid& G, Vec3 q, int k, double max_dist, uint32_t pos[KM]) {
   uint32_t rows[18], fb = 0;
-  const int kept = knn_search_positions<KM>(G.g, G.cell_start.data(), G.sp.data(), q, k, max_dist, knn_radius_pass_max(max_dist), pos,
-                                            rows, 1, &fb);
+  // as the kernels do: round-1-only keyed search; what it cannot finish goes to the complete search
+  const double pass_max = knn_radius_pass_max(max_dist);
+  int kept = knn_search_keyed_round1<KM>(G.g, G.cell_start.data(), G.sp.data(), q, k, max_dist, pass_max, pos, rows, 1);
+  if (kept < 0) {
+    g_knn_queued++;
+    kept = knn_search_positions<KM>(G.g, G.cell_start.data(), G.sp.data(), q, k, max_dist, pass_max, pos, rows, 1, &fb);
+  }
   g_knn_fallbacks += fb;
   KnnResult<KM> r;
   const int kept_exact = knn_search(G.g, G.cell_start.data(), G.sp.data(), q, k, max_dist, r, rows, 1);
@@ -263,6 +268,7 @@ static int knn_both(const HostGrid& G, Vec3 q, int k, double max_dist, uint32_t 
 }
 }
 uint64_t hostcheck_knn_fallbacks(void) { return g_knn_fallbacks; }
+uint64_t hostcheck_knn_queued(void) { return g_knn_queued; }
 uint64_t hostcheck_knn_mismatches(void) { return g_knn_mismatch; }
 
 uint64_t hostcheck_knn(const double* pts, uint64_t n, const double q[3], uint64_t k, double max_dist, uint64_t* idx_out) {
