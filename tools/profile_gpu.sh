@@ -8,8 +8,13 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 D=$ROOT/gpurun_out/prof_$tag
 rm -rf "$D"; mkdir -p "$D"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$D/trace" --output-format csv -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 > "$D/bench_under_rocprof.log" 2> "$D/trace.err"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$D/trace" --output-format csv -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$D/bench_under_rocprof.log" 2> "$D/trace.err"
 echo "trace done"
+# the same with the association chains in sequence on one stream: clean per-kernel durations
+# (kernels that run concurrently on the auxiliary stream report inflated durations above)
+export LOAMX_NO_AUX_STREAM=1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$D/trace_seq" --output-format csv -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$D/bench_under_rocprof_seq.log" 2> "$D/trace_seq.err"
+echo "sequential trace done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d "$D/pmc_fetch" --output-format csv -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$D/pmc_fetch.log" 2> "$D/pmc_fetch.err"
 echo "fetch done"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d "$D/pmc_write" --output-format csv -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$D/pmc_write.log" 2> "$D/pmc_write.err"

@@ -36,28 +36,32 @@ def main():
     src, dst = sys.argv[1], sys.argv[2]
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     md = ["# rocprofv3 summary (" + os.path.basename(src) + ")", ""]
-    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
-    if stats:
+    for sub, log, title in (("trace", "bench_under_rocprof.log", "`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline`"),
+                            ("trace_seq", "bench_under_rocprof_seq.log", "the same with `LOAMX_NO_AUX_STREAM=1` (association chains in sequence on one stream: "
+                             "per-kernel durations without the inflation that concurrent kernels report)")):
+        stats = glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
+        if not stats:
+            continue
         rows = list(csv.DictReader(open(stats[0])))
-        with open(dst + "_kernel_stats.csv", "w") as f:
+        with open(dst + ("_kernel_stats.csv" if sub == "trace" else "_kernel_stats_seq.csv"), "w") as f:
             w = csv.writer(f)
             w.writerow(["kernel", "calls", "total_ns", "average_ns", "percentage"])
             for r in rows:
                 w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]])
-        md += ["## Kernel time (`rocprofv3 --kernel-trace --stats`)", "",
-               "| kernel | calls | avg µs | total ms | % |", "|---|---|---|---|---|"]
+        md += ["## Kernel time: " + title, "", "| kernel | calls | avg µs | total ms | % |", "|---|---|---|---|---|"]
         for r in rows:
             if float(r["Percentage"]) < 0.01:
                 continue
             md.append(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | "
                       f"{float(r['TotalDurationNs'])/1e6:.3f} | {float(r['Percentage']):.2f} |")
-        bj = bench_json(os.path.join(src, "bench_under_rocprof.log"))
+        bj = bench_json(os.path.join(src, log))
         if bj:
             md += ["", f"bench.py under the profiler: {bj['value']} {bj['unit']}, {bj['ms_per_step']} ms/step; "
                        "HIP-event averages measured inside bench.py for the same run:", "",
                    "| kernel (event scope) | launches | avg ms | algorithmic GB/s | frac of 8 TB/s |", "|---|---|---|---|---|"]
             for k, v in bj["kernels"].items():
                 md.append(f"| {k} | {v['launches']} | {v['avg_ms']} | {v['achieved_GBs']} | {v['hbm_frac']} |")
+        md.append("")
     pmc = {}
     for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         files = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
@@ -82,6 +86,7 @@ def main():
         out = {}
         alias = {"curvature_valid_kernel": "curvature_valid_kernel", "sweep_kernel": "sweep_kernel",
                  "select_kernel<4>": "select_kernel", "select_mis_kernel<2, 4>": "select_kernel"}
+        alias.update({k: "select_kernel" for k in pmc if k.startswith("select_mis_kernel")})
         for k in sorted(pmc):
             f = pmc[k].get("FETCH_SIZE", {"dispatches": 0, "kib_total_reported": 0.0})
             w = pmc[k].get("WRITE_SIZE", {"dispatches": 0, "kib_total_reported": 0.0})
