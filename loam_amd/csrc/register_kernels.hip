@@ -192,17 +192,19 @@ constexpr int kAssocThreads = 256;
 
 // Workgroup -> (pair, chunk) mapping: workgroups are dealt round-robin over the 8 XCDs, so all
 // chunks of one pair are given ids with the same id % 8 and share one XCD's L2 (the pair's target
-// index + points are ~0.5 MB). Placement only affects speed, never results.
+// index + points are ~0.5 MB). With fewer than 8 pairs (single registrations, scan-to-map) that would
+// leave XCDs idle, so the chunks are spread over all of them instead. Placement only affects speed,
+// never results. (Grids are sized ceil(n_pairs / 8) * 8 * blocks_per_pair for both mappings.)
 __device__ __forceinline__ bool xcd_pair_map(uint32_t block, uint32_t blocks_per_pair, size_t n_pairs, size_t& pair,
                                              uint32_t& chunk) {
-#ifdef LOAMX_LINEAR_PAIR_MAP
-  pair = block / blocks_per_pair;
-  chunk = block % blocks_per_pair;
-#else
-  const uint32_t xcd = block & 7u, slot = block >> 3;
-  pair = (size_t)xcd + 8u * (size_t)(slot / blocks_per_pair);
-  chunk = slot % blocks_per_pair;
-#endif
+  if (n_pairs < 8) {
+    pair = block / blocks_per_pair;
+    chunk = block % blocks_per_pair;
+  } else {
+    const uint32_t xcd = block & 7u, slot = block >> 3;
+    pair = (size_t)xcd + 8u * (size_t)(slot / blocks_per_pair);
+    chunk = slot % blocks_per_pair;
+  }
   return pair < n_pairs;
 }
 
@@ -726,8 +728,16 @@ void launch_state_init(const RegBatch& B, const RegConfig& C, hipStream_t s) {
 }
 
 #ifndef LOAMX_REST_BLOCKS
-#define LOAMX_REST_BLOCKS 16u
+#define LOAMX_REST_BLOCKS 32u
 #endif
+// workgroups (of kRestThreads) per pair for the queue kernels: a few for big batches (queues are short),
+// enough to cover a whole set when there are only a few pairs (scan-to-map: one pair, 40 k queries)
+static uint32_t rest_blocks(size_t n_pairs, uint32_t nblk) {
+  const uint32_t cover = nblk * (uint32_t)(kAssocThreads / kRestThreads);  // one pass over a full queue
+  uint32_t want = (uint32_t)(4096 / (n_pairs ? n_pairs : 1));
+  if (want < LOAMX_REST_BLOCKS) want = LOAMX_REST_BLOCKS;
+  return want < cover ? want : cover;
+}
 void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipStream_t aux, hipEvent_t ev_fork,
                       hipEvent_t ev_mid, hipEvent_t ev_join) {
   if (B.n_pairs == 0) return;
@@ -751,7 +761,7 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
                      (st), B, C, (nblk))
 #define LOAMX_ASSOC_B(PL, KMV, nblk, st)                                                                          \
   do {                                                                                                            \
-    const uint32_t rblk_ = LOAMX_REST_BLOCKS, xblk_ = (nblk) < 2u ? (nblk) : 2u;                                   \
+    const uint32_t rblk_ = rest_blocks(B.n_pairs, (nblk)), xblk_ = (nblk) < 2u ? (nblk) : 2u;                      \
     hipLaunchKernelGGL((associate_knn_rest_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * rblk_)),           \
                        dim3(kRestThreads), 0, (st), B, C, rblk_);                                                 \
     hipLaunchKernelGGL((associate_knn_exact_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * xblk_)),          \
