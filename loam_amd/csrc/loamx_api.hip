@@ -20,7 +20,7 @@ namespace {
 enum WsId {
   WS_XYZ = 0, WS_CURV, WS_MASK, WS_EDGE_STAGE, WS_PLANAR_STAGE, WS_EDGE_CNT, WS_PLANAR_CNT,
   WS_EDGE_IDX, WS_PLANAR_IDX, WS_N_EDGE, WS_N_PLANAR, WS_EDGE_XYZ, WS_PLANAR_XYZ,
-  WS_GRID_DESC_E, WS_GRID_DESC_P, WS_CELLS_E, WS_CELLS_P, WS_SORTED_E, WS_SORTED_P,
+  WS_GRID_DESC_E, WS_GRID_DESC_P, WS_CELLS_E, WS_CELLS_P, WS_SORTED_E, WS_SORTED_P, WS_REL_E, WS_REL_P,
   WS_SGRID_DESC_E, WS_SGRID_DESC_P, WS_SCELLS_E, WS_SCELLS_P, WS_SSORTED_E, WS_SSORTED_P, WS_SORT_SCRATCH, WS_ASSOC_E, WS_ASSOC_P, WS_NN_E, WS_NN_P, WS_RNN_E, WS_RNN_P, WS_NEAREST_E, WS_NEAREST_P, WS_REST_E, WS_REST_P, WS_EXACT_E, WS_EXACT_P, WS_NASSOC, WS_STATE, WS_PARTIALS,
   WS_COUNTERS, WS_ITERINFO, WS_SRC_E, WS_SRC_P, WS_TGT_E, WS_TGT_P, WS_FCOUNTS, WS_RESULTS, WS_INIT,
   WS_COUNT
@@ -59,6 +59,7 @@ struct loamx_target_index {
   GridDesc* desc[2] = {nullptr, nullptr};       // [edge, plane], one GridDesc each
   uint32_t* cells[2] = {nullptr, nullptr};      // kGridCellsCap + 1 entries each
   GridPoint* sorted[2] = {nullptr, nullptr};    // n + kGridPad entries each
+  float* rel[2] = {nullptr, nullptr};           // 3 x (n + kGridPad) single-precision offsets (FP32 pre-selection)
   size_t n[2] = {0, 0};
   double radius[2] = {0, 0};
 };
@@ -273,6 +274,8 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   ENSURE(ctx, WS_CELLS_P, np * (size_t)(kGridCellsCap + 1) * sizeof(uint32_t));
   ENSURE(ctx, WS_SORTED_E, np * (es + kGridPad) * sizeof(GridPoint));
   ENSURE(ctx, WS_SORTED_P, np * (ps + kGridPad) * sizeof(GridPoint));
+  ENSURE(ctx, WS_REL_E, np * 3 * (es + kGridPad) * sizeof(float));
+  ENSURE(ctx, WS_REL_P, np * 3 * (ps + kGridPad) * sizeof(float));
   ENSURE(ctx, WS_SGRID_DESC_E, np * sizeof(GridDesc));
   ENSURE(ctx, WS_SGRID_DESC_P, np * sizeof(GridDesc));
   ENSURE(ctx, WS_SCELLS_E, np * (size_t)(kGridCellsCap + 1) * sizeof(uint32_t));
@@ -302,10 +305,12 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
     if (fresh) HIP_TRY(ctx, hipMemsetAsync(ctx->ws[WS_COUNTERS].p, 0, 64, ctx->stream));
   }
   if (want_iter_info) ENSURE(ctx, WS_ITERINFO, np * (size_t)(C.max_iterations ? C.max_iterations : 1) * sizeof(loamx_iter_info));
-  B.grid_edge = GridSet{wsp<GridDesc>(ctx, WS_GRID_DESC_E), wsp<uint32_t>(ctx, WS_CELLS_E), wsp<GridPoint>(ctx, WS_SORTED_E), es + kGridPad};
-  B.grid_plane = GridSet{wsp<GridDesc>(ctx, WS_GRID_DESC_P), wsp<uint32_t>(ctx, WS_CELLS_P), wsp<GridPoint>(ctx, WS_SORTED_P), ps + kGridPad};
-  B.src_grid_edge = GridSet{wsp<GridDesc>(ctx, WS_SGRID_DESC_E), wsp<uint32_t>(ctx, WS_SCELLS_E), wsp<GridPoint>(ctx, WS_SSORTED_E), es};
-  B.src_grid_plane = GridSet{wsp<GridDesc>(ctx, WS_SGRID_DESC_P), wsp<uint32_t>(ctx, WS_SCELLS_P), wsp<GridPoint>(ctx, WS_SSORTED_P), ps};
+  B.grid_edge = GridSet{wsp<GridDesc>(ctx, WS_GRID_DESC_E), wsp<uint32_t>(ctx, WS_CELLS_E), wsp<GridPoint>(ctx, WS_SORTED_E), es + kGridPad,
+                        wsp<float>(ctx, WS_REL_E)};
+  B.grid_plane = GridSet{wsp<GridDesc>(ctx, WS_GRID_DESC_P), wsp<uint32_t>(ctx, WS_CELLS_P), wsp<GridPoint>(ctx, WS_SORTED_P), ps + kGridPad,
+                         wsp<float>(ctx, WS_REL_P)};
+  B.src_grid_edge = GridSet{wsp<GridDesc>(ctx, WS_SGRID_DESC_E), wsp<uint32_t>(ctx, WS_SCELLS_E), wsp<GridPoint>(ctx, WS_SSORTED_E), es, nullptr};
+  B.src_grid_plane = GridSet{wsp<GridDesc>(ctx, WS_SGRID_DESC_P), wsp<uint32_t>(ctx, WS_SCELLS_P), wsp<GridPoint>(ctx, WS_SSORTED_P), ps, nullptr};
   B.sort_scratch = wsp<GridPoint>(ctx, WS_SORT_SCRATCH);
   B.assoc = AssocBuffers{wsp<double>(ctx, WS_ASSOC_E), wsp<double>(ctx, WS_ASSOC_P), wsp<uint32_t>(ctx, WS_NN_E),
                          wsp<uint32_t>(ctx, WS_NN_P), wsp<uint32_t>(ctx, WS_RNN_E), wsp<uint32_t>(ctx, WS_RNN_P),
@@ -323,8 +328,8 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   hipStream_t s = ctx->stream;
 
   if (prebuilt) {  // persistent target index: only the source sets are (re)ordered
-    B.grid_edge = GridSet{prebuilt->desc[0], prebuilt->cells[0], prebuilt->sorted[0], prebuilt->n[0] + kGridPad};
-    B.grid_plane = GridSet{prebuilt->desc[1], prebuilt->cells[1], prebuilt->sorted[1], prebuilt->n[1] + kGridPad};
+    B.grid_edge = GridSet{prebuilt->desc[0], prebuilt->cells[0], prebuilt->sorted[0], prebuilt->n[0] + kGridPad, prebuilt->rel[0]};
+    B.grid_plane = GridSet{prebuilt->desc[1], prebuilt->cells[1], prebuilt->sorted[1], prebuilt->n[1] + kGridPad, prebuilt->rel[1]};
   }
   {
     TimedScope t(ctx, LOAMX_K_GRID, 0.0);
@@ -694,6 +699,7 @@ void loamx_target_index_destroy(loamx_ctx* ctx, loamx_target_index* index) {
     if (index->desc[k]) (void)hipFree(index->desc[k]);
     if (index->cells[k]) (void)hipFree(index->cells[k]);
     if (index->sorted[k]) (void)hipFree(index->sorted[k]);
+    if (index->rel[k]) (void)hipFree(index->rel[k]);
   }
   delete index;
 }
@@ -723,7 +729,8 @@ int loamx_target_index_create(loamx_ctx* ctx, const double* tgt_edge, size_t n_t
     if (rc != LOAMX_OK) break;
     if (hipMalloc(reinterpret_cast<void**>(&idx->desc[k]), sizeof(GridDesc)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&idx->cells[k]), (size_t)(kGridCellsCap + 1) * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&idx->sorted[k]), (n + kGridPad) * sizeof(GridPoint)) != hipSuccess) {
+        hipMalloc(reinterpret_cast<void**>(&idx->sorted[k]), (n + kGridPad) * sizeof(GridPoint)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&idx->rel[k]), 3 * (n + kGridPad) * sizeof(float)) != hipSuccess) {
       rc = fail(ctx, LOAMX_ERR_HIP, "hipMalloc failed for the target index");
       break;
     }
@@ -735,8 +742,8 @@ int loamx_target_index_create(loamx_ctx* ctx, const double* tgt_edge, size_t n_t
     B.edge_stride = n_te ? n_te : 1, B.planar_stride = n_tp ? n_tp : 1;
     B.tgt_edge = wsp<double>(ctx, WS_TGT_E), B.tgt_planar = wsp<double>(ctx, WS_TGT_P);
     B.n_tgt_edge = wsp<uint32_t>(ctx, WS_FCOUNTS) + 2, B.n_tgt_planar = wsp<uint32_t>(ctx, WS_FCOUNTS) + 3;
-    B.grid_edge = GridSet{idx->desc[0], idx->cells[0], idx->sorted[0], n_te + kGridPad};
-    B.grid_plane = GridSet{idx->desc[1], idx->cells[1], idx->sorted[1], n_tp + kGridPad};
+    B.grid_edge = GridSet{idx->desc[0], idx->cells[0], idx->sorted[0], n_te + kGridPad, idx->rel[0]};
+    B.grid_plane = GridSet{idx->desc[1], idx->cells[1], idx->sorted[1], n_tp + kGridPad, idx->rel[1]};
     {
       TimedScope t(ctx, LOAMX_K_GRID, 0.0);
       launch_grid_build_targets(B, C, s);
@@ -749,6 +756,7 @@ int loamx_target_index_create(loamx_ctx* ctx, const double* tgt_edge, size_t n_t
       if (idx->desc[k]) (void)hipFree(idx->desc[k]);
       if (idx->cells[k]) (void)hipFree(idx->cells[k]);
       if (idx->sorted[k]) (void)hipFree(idx->sorted[k]);
+      if (idx->rel[k]) (void)hipFree(idx->rel[k]);
     }
     delete idx;
     return rc;

@@ -49,6 +49,8 @@ struct GridSet {
   uint32_t* cell_start;  // [n_pairs][kGridCellsCap + 1]
   GridPoint* sorted;     // [n_pairs][stride] points re-ordered cell by cell (32 B each: xyz + original index)
   size_t stride;
+  float* rel;            // [n_pairs][3][stride] single-precision offsets of the sorted points from the grid origin
+                         // (x plane, y plane, z plane) for the FP32 pre-selection; nullptr for source sets
 };
 
 // Association records, structure-of-arrays over the whole batch (field-major) so the residual

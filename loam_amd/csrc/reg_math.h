@@ -445,18 +445,11 @@ LOAMX_HD double knn_radius_bound(double max_dist) { return max_dist > 0.0 ? max_
 // The rounds of the search. Cubes of cells of growing half-width w around the query cell are
 // visited; after round w every unvisited point is farther than w*h along some axis.
 
-// Round 1 when it starts at the query's own cell: the 3x3x3 block, as one flattened candidate stream.
-template <class Coll>
-LOAMX_HD void knn_round1(const GridDesc& g, const uint32_t* __restrict__ cell_start, const GridPoint* __restrict__ sp, Vec3 q,
-                         int k, double r2, int32_t cx, int32_t cy, int32_t cz, Coll& r, uint32_t* row_scratch,
-                         int row_stride) {
-  // Common case: the 3x3x3 block. The cell_start entries of its nine rows are fetched up front
-  // (18 independent loads instead of nine dependent round trips). The non-empty rows are written
-  // to a small per-thread list (LDS in the kernels) in the order centre, faces, corners, and the
-  // lane then walks ONE flattened stream of 4-wide candidate batches over that list, skipping a
-  // row when its slab is already farther than the current bound. Flattening matters on the GPU:
-  // a wavefront then runs for max_lanes(sum of batches) instead of sum_rows(max_lanes(batches))
-  // (measured on the 64x1024 workload: 20.4 vs 37.0 batch steps per wavefront).
+// The per-thread list of the non-empty rows of the 3x3x3 block around cell (cx, cy, cz), in the order
+// centre, faces, corners: entry = {begin | row code << 28, end}. The 18 cell_start entries are fetched
+// up front (independent loads instead of nine dependent round trips). Returns the number of entries.
+LOAMX_HD int knn_round1_list(const GridDesc& g, const uint32_t* __restrict__ cell_start, int32_t cx, int32_t cy, int32_t cz,
+                             uint32_t* row_scratch, int row_stride) {
   uint32_t rb[9], re[9];
   const int32_t xa = cx - 1 < 0 ? 0 : cx - 1, xb = cx + 1 > g.nx - 1 ? g.nx - 1 : cx + 1;
 #pragma unroll
@@ -478,6 +471,22 @@ LOAMX_HD void knn_round1(const GridDesc& g, const uint32_t* __restrict__ cell_st
       nrow++;
     }
   }
+  return nrow;
+}
+
+// Round 1 when it starts at the query's own cell: the 3x3x3 block, as one flattened candidate stream.
+template <class Coll>
+LOAMX_HD void knn_round1(const GridDesc& g, const uint32_t* __restrict__ cell_start, const GridPoint* __restrict__ sp, Vec3 q,
+                         int k, double r2, int32_t cx, int32_t cy, int32_t cz, Coll& r, uint32_t* row_scratch,
+                         int row_stride) {
+  // Common case: the 3x3x3 block. The cell_start entries of its nine rows are fetched up front
+  // (18 independent loads instead of nine dependent round trips). The non-empty rows are written
+  // to a small per-thread list (LDS in the kernels) in the order centre, faces, corners, and the
+  // lane then walks ONE flattened stream of 4-wide candidate batches over that list, skipping a
+  // row when its slab is already farther than the current bound. Flattening matters on the GPU:
+  // a wavefront then runs for max_lanes(sum of batches) instead of sum_rows(max_lanes(batches))
+  // (measured on the 64x1024 workload: 20.4 vs 37.0 batch steps per wavefront).
+  const int nrow = knn_round1_list(g, cell_start, cx, cy, cz, row_scratch, row_stride);
   // squared slab distances to the neighbouring rows (the query's own row is at distance 0)
   double sy2m = slab_dist(q.y, g.oy, g.h, cy - 1), sy2p = slab_dist(q.y, g.oy, g.h, cy + 1);
   double sz2m = slab_dist(q.z, g.oz, g.h, cz - 1), sz2p = slab_dist(q.z, g.oz, g.h, cz + 1);
@@ -772,6 +781,264 @@ LOAMX_HD int knn_search_keyed_round1(const GridDesc& g, const uint32_t* __restri
   knn_round1(g, cell_start, sp, q, k, knn_radius_bound(max_dist), cx, cy, cz, c, row_scratch, row_stride);
   if (!knn_done(g, q, k, max_dist, cx, cy, cz, c, 1)) return -1;
   return knn_keys_finish(c, k, pass_max, pos);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * FP32 pre-selection (round 1 of the fast kernel).
+ *
+ * The candidate loop of the keyed collector above is VALU-bound: 8 FP64 operations for the distance
+ * and 11 for the insertion, per candidate. Here the loop runs on single-precision copies of the
+ * target coordinates (relative to the grid origin, SoA: x[], y[], z[]): ~3 packed instructions for
+ * the distance, and a 32-bit key — the bits of the float d2 with the low 8 bits replaced by the
+ * candidate's running number in this query's stream — kept in a sorted list of k+1 by v_med3_u32
+ * (new slot j = median(old slot j-1, old slot j, key): one instruction per slot, no carry chain).
+ *
+ * Exactness is restored afterwards, per query: the k selected candidates are fetched in FP64, their
+ * exact d2 (bit-identical to what the FP64 collectors compute) must be strictly ascending, and the
+ * best rejected key T6 must exceed the exact k-th distance D5 by more than the rigorous error of
+ * the FP32 evaluation at that distance:
+ *     |d2_32 - d2| <= 2*sqrt(3)*a*d + 3*a^2 + 4*u*d2,   a = 3*u*L,  u = 2^-24,
+ * L = largest coordinate offset from the grid origin that can occur (grid extent + 2 cells): the
+ * stored offsets and the query's are rounded once (u*L each), their difference once more. Every
+ * rejected candidate has d2_32 >= T6, hence d2 >= T6 - err(d); if it were <= D5 its error would be
+ * <= err(sqrt(D5)), so T6 - err(sqrt(D5)) > D5 rules that out. Whatever fails a check (ties, an
+ * inversion, a near-tie at the boundary, > 63 batches, non-finite values) is "undecided" and goes
+ * to the queue like a query that needs more rounds: the result is always that of the exact search.
+ * Pruning uses the same inequality the other way round (an upper bound on the true k-th d2).
+ * ---------------------------------------------------------------------------------------------- */
+template <int KM>
+struct KnnKeys32 {
+  uint32_t key[KM + 1];  // ascending: KM-k sentinels (0), then the k+1 smallest keys; 0xFFFFFFFF = empty
+};
+
+LOAMX_HD uint32_t knn_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+LOAMX_HD uint32_t knn_umed3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+#else
+  const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+  return c < lo ? lo : (c > hi ? hi : c);
+#endif
+}
+LOAMX_HD uint32_t knn_f32_bits(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __float_as_uint(v);
+#else
+  uint32_t b;
+  __builtin_memcpy(&b, &v, 4);
+  return b;
+#endif
+}
+LOAMX_HD float knn_bits_f32(uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __uint_as_float(b);
+#else
+  float v;
+  __builtin_memcpy(&v, &b, 4);
+  return v;
+#endif
+}
+template <int KM>
+LOAMX_HD void knn_init(KnnKeys32<KM>& c, int k) {
+#pragma unroll
+  for (int j = 0; j <= KM; j++) c.key[j] = j < KM - k ? 0u : 0xFFFFFFFFu;
+}
+template <int KM>
+LOAMX_HD void knn_key32_insert(KnnKeys32<KM>& c, uint32_t x) {
+  uint32_t nk[KM + 1];
+  nk[0] = knn_umin(c.key[0], x);
+#pragma unroll
+  for (int j = 1; j <= KM; j++) nk[j] = knn_umed3(c.key[j - 1], c.key[j], x);
+#pragma unroll
+  for (int j = 0; j <= KM; j++) c.key[j] = nk[j];
+}
+// error unit a = 3 u L of the FP32 evaluation on grid g
+LOAMX_HD double knn_f32_err_unit(const GridDesc& g) {
+  int32_t m = g.nx > g.ny ? g.nx : g.ny;
+  m = m > g.nz ? m : g.nz;
+  return 3.0 * 5.9604644775390625e-8 * ((double)(m + 2) * g.h);
+}
+// rigorous upper bound on the true k-th squared distance (DBL_MAX until k keys are held):
+// d2 <= d2_32 + 2 sqrt(3) a d + 3 a^2 + 4 u d2 and 2 sqrt(3) a d <= 1e-3 d2 + 3000 a^2
+template <int KM>
+LOAMX_HD double knn_bound32(const KnnKeys32<KM>& c, double a) {
+  const uint32_t kth = c.key[KM - 1];
+  if (kth >= 0x7F800000u) return kDblMax;  // empty or not finite
+  const double hi = (double)knn_bits_f32(kth | 0xFFu);
+  return (hi + 3003.0 * a * a) * 1.002;
+}
+
+struct alignas(4) KnnF4 {
+  float v[4];
+};
+// four candidates p..p+3 of the SoA copy (planes x, y, z of `plane` floats each); lidx = 4 * batch number
+template <int KM>
+LOAMX_HD void knn_scan_batch_f32(KnnKeys32<KM>& c, float qx, float qy, float qz, const float* __restrict__ rel,
+                                 uint32_t plane, uint32_t p, uint32_t n, uint32_t lidx) {
+  const char* __restrict__ base = reinterpret_cast<const char*>(rel) + (uint32_t)(p << 2);
+  const KnnF4 x = *reinterpret_cast<const KnnF4*>(base);
+  const KnnF4 y = *reinterpret_cast<const KnnF4*>(base + (size_t)plane * 4);
+  const KnnF4 z = *reinterpret_cast<const KnnF4*>(base + (size_t)plane * 8);
+#if defined(LOAMX_KNN_STATS)
+  g_cand += n < 4u ? n : 4u;
+#endif
+  uint32_t key[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 mqx = {-qx, -qx}, mqy = {-qy, -qy}, mqz = {-qz, -qz};
+  const f2 x01 = {x.v[0], x.v[1]}, x23 = {x.v[2], x.v[3]}, y01 = {y.v[0], y.v[1]}, y23 = {y.v[2], y.v[3]};
+  const f2 z01 = {z.v[0], z.v[1]}, z23 = {z.v[2], z.v[3]};
+  const f2 dx01 = x01 + mqx, dx23 = x23 + mqx, dy01 = y01 + mqy, dy23 = y23 + mqy, dz01 = z01 + mqz, dz23 = z23 + mqz;
+  f2 s01 = dx01 * dx01, s23 = dx23 * dx23;
+  s01 = __builtin_elementwise_fma(dy01, dy01, s01), s23 = __builtin_elementwise_fma(dy23, dy23, s23);
+  s01 = __builtin_elementwise_fma(dz01, dz01, s01), s23 = __builtin_elementwise_fma(dz23, dz23, s23);
+  const float d[4] = {s01.x, s01.y, s23.x, s23.y};
+#else
+  float d[4];
+  for (int i = 0; i < 4; i++) {
+    const float dx = x.v[i] - qx, dy = y.v[i] - qy, dz = z.v[i] - qz;
+    d[i] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+  }
+#endif
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    key[i] = (knn_f32_bits(d[i]) & 0xFFFFFF00u) | (lidx + (uint32_t)i);
+    if ((uint32_t)i >= n) key[i] = 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) knn_key32_insert(c, key[i]);
+}
+
+// Round 1 with the FP32 collector. Returns the number of neighbours kept, or -1 (undecided / needs
+// more rounds: queue it). pos as in knn_search_keyed (neighbour j in pos[(KM - k) + j]).
+// `rel` = SoA single-precision offsets of the sorted target points from the grid origin, planes of
+// `plane` floats.
+template <int KM>
+LOAMX_HD int knn_search_f32_round1(const GridDesc& g, const uint32_t* __restrict__ cell_start,
+                                   const GridPoint* __restrict__ sp, const float* __restrict__ rel, uint32_t plane, Vec3 q,
+                                   int k, double max_dist, double pass_max, uint32_t pos[KM], uint32_t* row_scratch,
+                                   int row_stride) {
+#pragma unroll
+  for (int j = 0; j < KM; j++) pos[j] = 0;
+  if (g.n_points == 0 || k <= 0) return 0;
+  if (k > KM) k = KM;
+  const int32_t cx = grid_cell_coord(q.x, g.ox, g.inv_h);
+  const int32_t cy = grid_cell_coord(q.y, g.oy, g.inv_h);
+  const int32_t cz = grid_cell_coord(q.z, g.oz, g.inv_h);
+  const int32_t out = grid_outside_distance(g, cx, cy, cz);
+  if (max_dist > 0.0 && out >= 1 && (double)(out - 1) * g.h >= max_dist) return 0;
+  if (out > 1) return -1;
+  const double a = knn_f32_err_unit(g);
+  const double r2 = knn_radius_bound(max_dist);
+  const float qx = (float)(q.x - g.ox), qy = (float)(q.y - g.oy), qz = (float)(q.z - g.oz);
+  KnnKeys32<KM> c;
+  knn_init(c, k);
+  const int nrow = knn_round1_list(g, cell_start, cx, cy, cz, row_scratch, row_stride);
+  // row pruning in single precision, conservatively: slab distances rounded down, the bound up
+  const float kDown = 0.99999f, kUp = 1.00001f;
+  double sy2m = slab_dist(q.y, g.oy, g.h, cy - 1), sy2p = slab_dist(q.y, g.oy, g.h, cy + 1);
+  double sz2m = slab_dist(q.z, g.oz, g.h, cz - 1), sz2p = slab_dist(q.z, g.oz, g.h, cz + 1);
+  const float fy2m = (float)(sy2m * sy2m) * kDown, fy2p = (float)(sy2p * sy2p) * kDown;
+  const float fz2m = (float)(sz2m * sz2m) * kDown, fz2p = (float)(sz2p * sz2p) * kDown;
+  const float fr2 = r2 < 1e37 ? (float)r2 * kUp : 3.0e38f;
+  const float fa2 = (float)(3003.0 * a * a) * kUp;
+  uint32_t p = 0, e = 0, t = 0;  // t = batches consumed so far (the key carries 4 t + i in 8 bits)
+  int ri = 0;
+  for (;;) {
+    while (p >= e && ri < nrow) {  // next admissible row
+      const uint32_t bj = row_scratch[(2 * ri) * row_stride], e2 = row_scratch[(2 * ri + 1) * row_stride];
+      const int j = (int)(bj >> 28), jy = j % 3, jz = j / 3;
+      const float sy2 = jy == 0 ? fy2m : (jy == 1 ? 0.0f : fy2p), sz2 = jz == 0 ? fz2m : (jz == 1 ? 0.0f : fz2p);
+      // upper bound on the true k-th d2 (see knn_bound32), evaluated in float with upward slack
+      const uint32_t kth = c.key[KM - 1];
+      const float worst = kth >= 0x7F800000u ? 3.0e38f : (knn_bits_f32(kth | 0xFFu) + fa2) * (1.002f * kUp);
+      const float bound = worst < fr2 ? worst : fr2;
+      if (sy2 + sz2 <= bound) {
+#if defined(LOAMX_KNN_STATS)
+        g_rows++;
+#endif
+        p = bj & 0x0FFFFFFFu, e = e2;
+        row_scratch[(2 * ri + 1) * row_stride] = 0x80000000u | t;  // visited: remember where its batches start
+      }
+      ri++;
+    }
+    if (p >= e || t >= 64u) break;
+    knn_scan_batch_f32(c, qx, qy, qz, rel, plane, p, e - p, t << 2);
+    p += 4, t++;
+  }
+  if (p < e) return -1;  // more than 63 batches: the 8-bit running number is exhausted
+  // ---- is the search over after the 3x3x3 block? (same test as knn_done, with the rigorous bound)
+  {
+    double guard = kDblMax;
+    const double m = 1e-9 * g.h;
+    const int32_t c3[3] = {cx, cy, cz}, n3[3] = {g.nx, g.ny, g.nz};
+    const double q3[3] = {q.x, q.y, q.z}, o3[3] = {g.ox, g.oy, g.oz};
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) {
+      if (c3[ax] - 1 > 0) {
+        const double d = (q3[ax] - (o3[ax] + (double)(c3[ax] - 1) * g.h)) * (1.0 - 1e-9) - m;
+        guard = d < guard ? d : guard;
+      }
+      if (c3[ax] + 1 < n3[ax] - 1) {
+        const double d = ((o3[ax] + (double)(c3[ax] + 2) * g.h) - q3[ax]) * (1.0 - 1e-9) - m;
+        guard = d < guard ? d : guard;
+      }
+    }
+    if (guard < 0.0) guard = 0.0;
+    const bool done = guard == kDblMax || knn_bound32(c, a) < guard * guard || (max_dist > 0.0 && guard >= max_dist);
+    if (!done) return -1;
+  }
+  // ---- exact verification of the k selected candidates
+  // running number -> position: the visited row with the largest first batch <= the key's batch
+  uint32_t wbegin[KM], wts[KM];
+#pragma unroll
+  for (int i = 0; i < KM; i++) wbegin[i] = 0u, wts[i] = 0u;
+  for (int rr = 0; rr < nrow; rr++) {
+    const uint32_t w0 = row_scratch[(2 * rr) * row_stride] & 0x0FFFFFFFu, w1 = row_scratch[(2 * rr + 1) * row_stride];
+    const uint32_t rts = w1 & 0x7FFFFFFFu;
+    const bool visited = (w1 & 0x80000000u) != 0u;
+#pragma unroll
+    for (int i = 0; i < KM; i++) {
+      const uint32_t tb = (c.key[i] & 0xFFu) >> 2;
+      const bool take = visited && rts <= tb && rts >= wts[i];
+      wbegin[i] = take ? w0 : wbegin[i];
+      wts[i] = take ? rts : wts[i];
+    }
+  }
+  int count = 0, kept = 0;
+  bool undecided = false, open = true;
+  double prev = -1.0, d5 = 0.0;
+#pragma unroll
+  for (int i = 0; i < KM; i++) {
+    const uint32_t key = c.key[i];
+    const bool real = i >= KM - k && key != 0xFFFFFFFFu;
+    if (real) {
+      if (key >= 0x7F800000u) undecided = true;
+      const uint32_t tb = (key & 0xFFu) >> 2, ii = key & 3u;
+      const uint32_t pp = wbegin[i] + (tb - wts[i]) * 4u + ii;
+      pos[i] = pp;
+      const GridPoint tp = sp[pp];
+      const double dx = q.x - tp.x, dy = q.y - tp.y, dz = q.z - tp.z;
+      const double d2 = dx * dx + dy * dy + dz * dz;  // as knn_scan_batch
+      if (!(d2 > prev)) undecided = true;             // a tie or an inversion: the exact order is not this one
+      if (!(d2 <= kDblMax)) undecided = true;
+      prev = d2, d5 = d2;
+      count++;
+      if (open) {
+        if (d2 <= pass_max) kept++;
+        else open = false;
+      }
+    }
+  }
+  const uint32_t k6 = c.key[KM];
+  if (count == k && k6 != 0xFFFFFFFFu) {
+    const double t6 = (double)knn_bits_f32(k6 & 0xFFFFFF00u);
+    const double err = 2.0 * (3.4641016151377544 * a * sqrt(d5) + 3.0 * a * a + 2.384185791015625e-7 * d5);  // x2 safety
+    if (!(t6 > d5 + err)) undecided = true;
+  }
+  return undecided ? -1 : kept;
 }
 
 // The complete search: keyed collector over all rounds, then the exact collector for a query whose

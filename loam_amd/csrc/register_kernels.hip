@@ -137,12 +137,24 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
       if (cell < nc) {
         const uint32_t pos = atomicAdd(&s_cells[cell], 1u);
         dst[pos] = GridPoint{x, y, z, i, 0u};
+
       }
     }
     carry += pass_total;
     __syncthreads();
   }
   if (tid == 0) cs[ncell] = n;
+  if (!ORDERED && gs.rel) {
+    // single-precision offsets from the grid origin, SoA (FP32 pre-selection of the k-NN): one coalesced
+    // pass over the finished cell order instead of three scattered 4-byte writes per point
+    __syncthreads();
+    __threadfence_block();
+    float* __restrict__ rel = gs.rel + pair * 3 * gs.stride;
+    for (uint32_t p = tid; p < n; p += kBuildThreads) {
+      const GridPoint e = sp[p];
+      rel[p] = (float)(e.x - g.ox), rel[gs.stride + p] = (float)(e.y - g.oy), rel[2 * gs.stride + p] = (float)(e.z - g.oz);
+    }
+  }
 }
 
 // Second half of the ORDERED build (source sets): every point of the scratch copy is placed at
@@ -331,8 +343,10 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_kn
   const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
   __shared__ uint32_t s_rows[18 * kAssocThreads];  // per-thread list of non-empty rows, [word][thread] (conflict free)
   uint32_t pos[KM];
-  const int kept = knn_search_keyed_round1<KM>(g, cs, sp, p, PLANE ? C.k_plane : C.k_edge, PLANE ? C.r_plane : C.r_edge,
-                                               PLANE ? C.pass_plane : C.pass_edge, pos, s_rows + threadIdx.x, kAssocThreads);
+  const float* __restrict__ rel = gs.rel + pair * 3 * gs.stride;
+  const int kept = knn_search_f32_round1<KM>(g, cs, sp, rel, (uint32_t)gs.stride, p, PLANE ? C.k_plane : C.k_edge,
+                                             PLANE ? C.r_plane : C.r_edge, PLANE ? C.pass_plane : C.pass_edge, pos,
+                                             s_rows + threadIdx.x, kAssocThreads);
   const size_t field = B.n_pairs * stride, slot = pair * stride + i;
   uint32_t* __restrict__ nn = PLANE ? B.assoc.nn_plane : B.assoc.nn_edge;  // [1 + KM][n_pairs * stride]
   nn[slot] = (uint32_t)kept;

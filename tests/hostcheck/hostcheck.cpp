@@ -214,6 +214,7 @@ struct HostGrid {
   GridDesc g;
   std::vector<uint32_t> cell_start;
   std::vector<GridPoint> sp;
+  std::vector<float> rel;  // 3 planes of sp.size() floats: offsets from the grid origin (FP32 pre-selection)
 };
 
 static void build_grid(const double* pts, uint32_t n, double max_dist, HostGrid& G) {
@@ -241,6 +242,12 @@ static void build_grid(const double* pts, uint32_t n, double max_dist, HostGrid&
     const uint32_t pos = cursor[cell[k]]++;
     G.sp[pos] = GridPoint{pts[3 * k], pts[3 * k + 1], pts[3 * k + 2], k, 0};
   }
+  const size_t plane = G.sp.size();
+  G.rel.assign(3 * plane, 0.0f);
+  for (uint32_t p = 0; p < n; p++) {
+    G.rel[p] = (float)(G.sp[p].x - G.g.ox), G.rel[plane + p] = (float)(G.sp[p].y - G.g.oy);
+    G.rel[2 * plane + p] = (float)(G.sp[p].z - G.g.oz);
+  }
 }
 
 extern "C++" {
@@ -252,7 +259,8 @@ static int knn_both(const HostGrid& G, Vec3 q, int k, double max_dist, uint32_t 
   uint32_t rows[18], fb = 0;
   // as the kernels do: round-1-only keyed search; what it cannot finish goes to the complete search
   const double pass_max = knn_radius_pass_max(max_dist);
-  int kept = knn_search_keyed_round1<KM>(G.g, G.cell_start.data(), G.sp.data(), q, k, max_dist, pass_max, pos, rows, 1);
+  int kept = knn_search_f32_round1<KM>(G.g, G.cell_start.data(), G.sp.data(), G.rel.data(), (uint32_t)G.sp.size(), q, k, max_dist,
+                                       pass_max, pos, rows, 1);
   if (kept < 0) {
     g_knn_queued++;
     kept = knn_search_positions<KM>(G.g, G.cell_start.data(), G.sp.data(), q, k, max_dist, pass_max, pos, rows, 1, &fb);
