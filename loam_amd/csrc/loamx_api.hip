@@ -325,6 +325,7 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   B.sweep_slots = reinterpret_cast<unsigned long long*>(wsp<unsigned char>(ctx, WS_COUNTERS) + 8);
   B.assoc_slots = B.sweep_slots + 2;
   B.iter_info = want_iter_info ? wsp<loamx_iter_info>(ctx, WS_ITERINFO) : nullptr;
+  B.want_nearest = hook ? 1u : 0u;
   hipStream_t s = ctx->stream;
 
   if (prebuilt) {  // persistent target index: only the source sets are (re)ordered

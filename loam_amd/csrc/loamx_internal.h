@@ -117,6 +117,7 @@ struct RegBatch {
   unsigned long long* sweep_slots;  // [2] edge / plane association slots streamed by sweep_kernel (roofline bytes)
   unsigned long long* assoc_slots;  // [2] edge / plane source features processed by associate_kernel
   loamx_iter_info* iter_info;  // optional [n_pairs][max_iterations]
+  uint32_t want_nearest;  // 1: a detail hook will read nearest_* (RegistrationDetail pairs); 0: the fit kernels skip that write
 };
 
 void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_t s);

@@ -491,13 +491,17 @@ __device__ __forceinline__ bool fit_one(const RegBatch& B, const RegConfig& C, c
 #pragma unroll
   for (int f = 0; f < (PLANE ? 4 : 6); f++) rec[(3 + f) * field + slot] = prim[f];
   // detail capture is indexed by the caller's source index
-  (PLANE ? B.assoc.nearest_plane : B.assoc.nearest_edge)[pair * stride + sq.orig] = valid ? nearest : 0xFFFFFFFFu;
+  if (B.want_nearest) (PLANE ? B.assoc.nearest_plane : B.assoc.nearest_edge)[pair * stride + sq.orig] = valid ? nearest : 0xFFFFFFFFu;
   return valid;
 }
 
 // The queries round 1 of the k-NN finished (everything but the queued ones, whose count stays 0xFFFFFFFF in nn).
+#ifndef LOAMX_FIT_WAVES
+#define LOAMX_FIT_WAVES 4
+#endif
 template <bool PLANE, int KM>
-__global__ __launch_bounds__(kAssocThreads) void associate_fit_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
+__global__ __launch_bounds__(kAssocThreads, LOAMX_FIT_WAVES) void associate_fit_kernel(RegBatch B, RegConfig C,
+                                                                                        uint32_t blocks_per_pair) {
   __shared__ uint32_t s_count[kAssocThreads / 64];
   size_t pair;
   uint32_t chunk;
