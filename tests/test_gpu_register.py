@@ -71,6 +71,33 @@ def test_synthetic_pair_with_detail(oracle, H, W, seed, pair):
     assert rot < 1e-2 and trans < 3e-2
 
 
+def test_dense_target_and_far_origin(oracle):
+    """Adverse inputs for the FP32 pre-selection of the k-NN: (a) a target set with many jittered copies of
+    every feature (hundreds of candidates per cell: the 8-bit running number overflows and the queries go
+    through the queue kernels), (b) the whole scene 7 000 km from the origin. Associations (which depend on
+    the exact neighbour sets) and poses must still match the oracle."""
+    H, W = 32, 512
+    A = capi.synth_scan_host(11, 0, 0, H, W, 0.01)
+    B = capi.synth_scan_host(11, 0, 1, H, W, 0.01)
+    ea, pa = oracle.extract_features(A, H, W, 1.0, 120.0)
+    eb, pb = oracle.extract_features(B, H, W, 1.0, 120.0)
+    rng = np.random.default_rng(5)
+    dense_p = np.vstack([A[pa] + rng.normal(size=A[pa].shape) * 2e-3 for _ in range(24)])
+    dense_e = np.vstack([A[ea] + rng.normal(size=A[ea].shape) * 2e-3 for _ in range(4)])
+    for shift in (np.zeros(3), np.array([4.0e6, -7.0e6, 1.0e5])):
+        se, sp_, te, tp = B[eb] + shift, B[pb] + shift, dense_e + shift, dense_p + shift
+        po, to, io, info = oracle.register_features(se, sp_, te, tp, want_info=True)
+        pg, tg, ig, det = ctx().register_features(se, sp_, te, tp, want_detail=True)
+        assert (tg, ig) == (to, io)
+        for a, b in zip(info, det["iterations"]):
+            assert (a.n_edge_assoc, a.n_plane_assoc) == (b["n_edge"], b["n_plane"])
+        valid, nearest, _, _ = oracle.associate(sp_, tp, np.array([0, 0, 0, 1, 0, 0, 0.0]), True)
+        pairs = det["iterations"][0]["plane_pairs"]
+        assert np.array_equal(pairs[:, 0], np.nonzero(valid)[0]) and np.array_equal(pairs[:, 1], nearest[valid])
+        rot, trans = pose_diff(oracle, po, pg)
+        assert rot < SE3_TOL and trans < (SE3_TOL if shift[0] == 0 else 1e-4), (rot, trans)
+
+
 def test_scan_pair_batch_matches_oracle(oracle):
     """loamx_register_scan_pairs_dev: extract x2 + register for a batch, pair by pair vs the oracle."""
     H, W, n_pairs, seed = 32, 512, 6, 13

@@ -151,6 +151,32 @@ def test_keyed_knn_ties_and_radius_edges(oracle):
     assert Hc.knn_mismatches() == 0
 
 
+def test_fp32_preselection_is_exact_in_adverse_cases(oracle):
+    """Round 1 of the kernels' search runs on single-precision copies with 32-bit keys; whatever it cannot
+    certify (error bound, running-number overflow, near ties) must fall through to the FP64 paths."""
+    rng = np.random.default_rng(7)
+    before = Hc.knn_mismatches()
+    # (a) 3000 points inside one grid cell: more than 63 candidate batches for one query
+    dense = rng.uniform(0.0, 0.2, size=(3000, 3))
+    dense = np.vstack([dense, rng.uniform(-5, 5, size=(50, 3))])
+    for q in (dense[5] + 1e-3, np.array([0.1, 0.1, 0.1])):
+        for k in (1, 5, 8):
+            assert np.array_equal(oracle.knn_bruteforce(dense, q, k, 2.0), Hc.knn(dense, q, k, 2.0))
+    # (b) far from the origin and a huge extent: the FP32 offsets lose the digits that separate neighbours
+    far = rng.normal(size=(400, 3)) * 0.05 + np.array([4.0e6, -7.0e6, 1.0e5])
+    far = np.vstack([far, far[0] + np.array([3.0e4, 0, 0])])  # stretches the grid to 30 km
+    for _ in range(30):
+        q = far[rng.integers(400)] + rng.normal(size=3) * 0.01
+        assert np.array_equal(oracle.knn_bruteforce(far, q, 5, -1.0), Hc.knn(far, q, 5, -1.0))
+    # (c) 5th and 6th neighbour separated by one part in 1e9 / 1e12, and an exact tie
+    base = np.array([[0.1, 0, 0], [0, 0.2, 0], [0, 0, 0.3], [0.4, 0, 0], [0, 0.5, 0]])
+    for rel in (1e-9, 1e-12, 0.0):
+        pts = np.vstack([base, [[0, 0, 0.5 * (1 + rel)]], rng.uniform(2, 3, size=(20, 3))])
+        got = Hc.knn(pts, np.zeros(3), 5, -1.0)
+        assert np.array_equal(oracle.knn_bruteforce(pts, np.zeros(3), 5, -1.0), got), rel
+    assert Hc.knn_mismatches() == before
+
+
 @pytest.mark.parametrize("case", K.REGISTRATION_CASES, ids=lambda c: c["name"])
 def test_registration_math_on_reference_scenes(oracle, case):
     tgt_e, tgt_p = K.registration_scene()
