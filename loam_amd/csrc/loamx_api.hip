@@ -35,6 +35,7 @@ struct PendingEvent {
   int kernel;
   hipEvent_t e0, e1;
   double bytes;
+  bool own_e0;  // false: e0 is the previous scope's e1 (back-to-back scopes share the event between them)
 };
 
 }  // namespace
@@ -50,6 +51,8 @@ struct loamx_ctx {
   bool timing = false;
   std::vector<PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;
+  hipEvent_t tail_event = nullptr;  // end event of the last timed scope ...
+  bool tail_fresh = false;          // ... and nothing has been enqueued on the stream since
   loamx_kernel_stat stats[LOAMX_K_COUNT] = {};
   unsigned long long sweep_slots_base[2] = {0, 0};
   std::mutex mu;
@@ -125,17 +128,23 @@ struct TimedScope {
   TimedScope(loamx_ctx* c, int kernel, double bytes) : ctx(c), on(c->timing) {
     if (on) {
       pe.kernel = kernel, pe.bytes = bytes;
-      pe.e0 = take_event(ctx), pe.e1 = take_event(ctx);
-      (void)hipEventRecord(pe.e0, ctx->stream);
+      // back-to-back scopes share one event: half the event packets between the kernels
+      pe.own_e0 = !(ctx->tail_fresh && ctx->tail_event);
+      pe.e0 = pe.own_e0 ? take_event(ctx) : ctx->tail_event;
+      pe.e1 = take_event(ctx);
+      if (pe.own_e0) (void)hipEventRecord(pe.e0, ctx->stream);
     }
   }
   ~TimedScope() {
     if (on) {
       (void)hipEventRecord(pe.e1, ctx->stream);
       ctx->pending.push_back(pe);
+      ctx->tail_event = pe.e1, ctx->tail_fresh = true;
     }
   }
 };
+// call before enqueueing anything outside a TimedScope: the next scope must record its own start
+inline void untimed(loamx_ctx* ctx) { ctx->tail_fresh = false; }
 
 int check_launch(loamx_ctx* ctx, const char* what) {
   hipError_t e = hipGetLastError();
@@ -209,8 +218,10 @@ int extract_dev(loamx_ctx* ctx, const double* d_xyz, size_t n_scans, const Extra
                 double* d_planar_xyz, bool only_curvature_mask) {
   const size_t N = (size_t)P.H * P.W;
   if (n_scans == 0) return LOAMX_OK;
+  untimed(ctx);
   if (N == 0) {
     if (!only_curvature_mask) {
+      untimed(ctx);
       HIP_TRY(ctx, hipMemsetAsync(d_n_edge, 0, n_scans * sizeof(uint32_t), ctx->stream));
       HIP_TRY(ctx, hipMemsetAsync(d_n_planar, 0, n_scans * sizeof(uint32_t), ctx->stream));
     }
@@ -260,6 +271,7 @@ typedef int (*AfterAssocHook)(loamx_ctx*, const RegBatch&, uint32_t it, void* us
 int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_reg_result* d_results, bool want_iter_info,
                  AfterAssocHook hook, void* hook_user, const loamx_target_index* prebuilt = nullptr) {
   if (in.n_pairs == 0) return LOAMX_OK;
+  untimed(ctx);
   if (in.n_pairs > 0x7FFFFFFFull / 128) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "too many pairs in one call");
   const size_t np = in.n_pairs, es = in.edge_stride ? in.edge_stride : 1, ps = in.planar_stride ? in.planar_stride : 1;
   if (es > 0x7FFFFFFFull || ps > 0x7FFFFFFFull) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "feature set too large");
@@ -302,6 +314,7 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   {
     const bool fresh = ctx->ws[WS_COUNTERS].cap == 0;
     ENSURE(ctx, WS_COUNTERS, 64);
+    untimed(ctx);
     if (fresh) HIP_TRY(ctx, hipMemsetAsync(ctx->ws[WS_COUNTERS].p, 0, 64, ctx->stream));
   }
   if (want_iter_info) ENSURE(ctx, WS_ITERINFO, np * (size_t)(C.max_iterations ? C.max_iterations : 1) * sizeof(loamx_iter_info));
@@ -338,6 +351,7 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
     launch_grid_build_sources(B, C, s);
   }
   CHECK_LAUNCH(ctx, "grid_build_kernel");
+  untimed(ctx);
   launch_state_init(B, C, s);
   CHECK_LAUNCH(ctx, "state_init_kernel");
   for (uint32_t it = 0; it < C.max_iterations; it++) {
@@ -347,6 +361,7 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
     }
     CHECK_LAUNCH(ctx, "associate_kernel");
     if (hook) {
+      untimed(ctx);
       int rc = hook(ctx, B, it, hook_user);
       if (rc != LOAMX_OK) return rc;
     }
@@ -365,6 +380,7 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
       }
     }
     CHECK_LAUNCH(ctx, "sweep/lm kernels");
+    untimed(ctx);
     HIP_TRY(ctx, hipMemsetAsync(B.n_active, 0, sizeof(uint32_t), s));
     {
       TimedScope t(ctx, LOAMX_K_LM, 0.0);
@@ -373,11 +389,13 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
     CHECK_LAUNCH(ctx, "outer_update_kernel");
     if (it + 1 < C.max_iterations) {
       // one 4-byte readback per outer iteration: stop as soon as every pair has terminated
+      untimed(ctx);
       HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, B.n_active, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
       HIP_TRY(ctx, hipStreamSynchronize(s));
       if (ctx->h_pinned[0] == 0) break;
     }
   }
+  untimed(ctx);
   launch_write_results(B, d_results, s);
   CHECK_LAUNCH(ctx, "write_results_kernel");
   return LOAMX_OK;
@@ -393,10 +411,11 @@ int resolve_events(loamx_ctx* ctx) {
       ctx->stats[pe.kernel].total_ms += (double)ms;
       ctx->stats[pe.kernel].algorithmic_bytes += pe.bytes;
     }
-    ctx->event_pool.push_back(pe.e0);
+    if (pe.own_e0) ctx->event_pool.push_back(pe.e0);
     ctx->event_pool.push_back(pe.e1);
   }
   ctx->pending.clear();
+  ctx->tail_fresh = false;
   return LOAMX_OK;
 }
 
@@ -458,7 +477,7 @@ void loamx_ctx_destroy(loamx_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (PendingEvent& pe : ctx->pending) {
-    (void)hipEventDestroy(pe.e0);
+    if (pe.own_e0) (void)hipEventDestroy(pe.e0);
     (void)hipEventDestroy(pe.e1);
   }
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -745,6 +764,7 @@ int loamx_target_index_create(loamx_ctx* ctx, const double* tgt_edge, size_t n_t
     B.n_tgt_edge = wsp<uint32_t>(ctx, WS_FCOUNTS) + 2, B.n_tgt_planar = wsp<uint32_t>(ctx, WS_FCOUNTS) + 3;
     B.grid_edge = GridSet{idx->desc[0], idx->cells[0], idx->sorted[0], n_te + kGridPad, idx->rel[0]};
     B.grid_plane = GridSet{idx->desc[1], idx->cells[1], idx->sorted[1], n_tp + kGridPad, idx->rel[1]};
+    untimed(ctx);
     {
       TimedScope t(ctx, LOAMX_K_GRID, 0.0);
       launch_grid_build_targets(B, C, s);
