@@ -757,32 +757,6 @@ LOAMX_HD int knn_search_keyed(const GridDesc& g, const uint32_t* __restrict__ ce
   return knn_keys_finish(c, k, pass_max, pos);
 }
 
-// The fast kernel's search: keyed collector, round 1 only. Returns the number of neighbours kept, or
-// -1 when the query needs more than that — it starts outside the grid's first shell, the search is
-// not over after the 3x3x3 block, or the keys are undecided. Such queries (a few per cent, in sparse
-// regions) are queued and searched completely by a second kernel on dense wavefronts, instead of
-// dragging every wavefront of this one through the row-by-row outer rounds.
-template <int KM>
-LOAMX_HD int knn_search_keyed_round1(const GridDesc& g, const uint32_t* __restrict__ cell_start,
-                                     const GridPoint* __restrict__ sp, Vec3 q, int k, double max_dist, double pass_max,
-                                     uint32_t pos[KM], uint32_t* row_scratch, int row_stride) {
-#pragma unroll
-  for (int j = 0; j < KM; j++) pos[j] = 0;
-  if (g.n_points == 0 || k <= 0) return 0;
-  if (k > KM) k = KM;
-  const int32_t cx = grid_cell_coord(q.x, g.ox, g.inv_h);
-  const int32_t cy = grid_cell_coord(q.y, g.oy, g.inv_h);
-  const int32_t cz = grid_cell_coord(q.z, g.oz, g.inv_h);
-  const int32_t out = grid_outside_distance(g, cx, cy, cz);
-  if (max_dist > 0.0 && out >= 1 && (double)(out - 1) * g.h >= max_dist) return 0;
-  if (out > 1) return -1;
-  KnnKeys<KM> c;
-  knn_init(c, k, g.n_points);
-  knn_round1(g, cell_start, sp, q, k, knn_radius_bound(max_dist), cx, cy, cz, c, row_scratch, row_stride);
-  if (!knn_done(g, q, k, max_dist, cx, cy, cz, c, 1)) return -1;
-  return knn_keys_finish(c, k, pass_max, pos);
-}
-
 /* ------------------------------------------------------------------------------------------------
  * FP32 pre-selection (round 1 of the fast kernel).
  *
