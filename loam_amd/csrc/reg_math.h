@@ -449,7 +449,7 @@ LOAMX_HD double knn_radius_bound(double max_dist) { return max_dist > 0.0 ? max_
 // centre, faces, corners: entry = {begin | row code << 28, end}. The 18 cell_start entries are fetched
 // up front (independent loads instead of nine dependent round trips). Returns the number of entries.
 LOAMX_HD int knn_round1_list(const GridDesc& g, const uint32_t* __restrict__ cell_start, int32_t cx, int32_t cy, int32_t cz,
-                             uint32_t* row_scratch, int row_stride) {
+                             uint32_t* row_scratch, int row_stride, uint32_t* population = nullptr) {
   uint32_t rb[9], re[9];
   const int32_t xa = cx - 1 < 0 ? 0 : cx - 1, xb = cx + 1 > g.nx - 1 ? g.nx - 1 : cx + 1;
 #pragma unroll
@@ -461,6 +461,7 @@ LOAMX_HD int knn_round1_list(const GridDesc& g, const uint32_t* __restrict__ cel
     re[j] = ok ? cell_start_at(cell_start, row + (uint32_t)xb + 1u) : 0u;
   }
   int nrow = 0;
+  uint32_t pop = 0;
 #pragma unroll
   for (int o = 0; o < 9; o++) {
     constexpr int kOrder[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
@@ -469,8 +470,10 @@ LOAMX_HD int knn_round1_list(const GridDesc& g, const uint32_t* __restrict__ cel
       row_scratch[(2 * nrow) * row_stride] = rb[j] | ((uint32_t)j << 28);  // set sizes stay below 2^28
       row_scratch[(2 * nrow + 1) * row_stride] = re[j];
       nrow++;
+      pop += re[j] - rb[j];
     }
   }
+  if (population) *population = pop;
   return nrow;
 }
 
@@ -837,10 +840,10 @@ LOAMX_HD double knn_f32_err_unit(const GridDesc& g) {
 // rigorous upper bound on the true k-th squared distance (DBL_MAX until k keys are held):
 // d2 <= d2_32 + 2 sqrt(3) a d + 3 a^2 + 4 u d2 and 2 sqrt(3) a d <= 1e-3 d2 + 3000 a^2
 template <int KM>
-LOAMX_HD double knn_bound32(const KnnKeys32<KM>& c, double a) {
+LOAMX_HD double knn_bound32(const KnnKeys32<KM>& c, double a, uint32_t imask) {
   const uint32_t kth = c.key[KM - 1];
   if (kth >= 0x7F800000u) return kDblMax;  // empty or not finite
-  const double hi = (double)knn_bits_f32(kth | 0xFFu);
+  const double hi = (double)knn_bits_f32(kth | imask);
   return (hi + 3003.0 * a * a) * 1.002;
 }
 
@@ -850,7 +853,7 @@ struct alignas(4) KnnF4 {
 // four candidates p..p+3 of the SoA copy (planes x, y, z of `plane` floats each); lidx = 4 * batch number
 template <int KM>
 LOAMX_HD void knn_scan_batch_f32(KnnKeys32<KM>& c, float qx, float qy, float qz, const float* __restrict__ rel,
-                                 uint32_t plane, uint32_t p, uint32_t n, uint32_t lidx) {
+                                 uint32_t plane, uint32_t p, uint32_t n, uint32_t lidx, uint32_t imask) {
   const char* __restrict__ base = reinterpret_cast<const char*>(rel) + (uint32_t)(p << 2);
   const KnnF4 x = *reinterpret_cast<const KnnF4*>(base);
   const KnnF4 y = *reinterpret_cast<const KnnF4*>(base + (size_t)plane * 4);
@@ -878,7 +881,7 @@ LOAMX_HD void knn_scan_batch_f32(KnnKeys32<KM>& c, float qx, float qy, float qz,
 #endif
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    key[i] = (knn_f32_bits(d[i]) & 0xFFFFFF00u) | (lidx + (uint32_t)i);
+    key[i] = (knn_f32_bits(d[i]) & ~imask) | (lidx + (uint32_t)i);
     if ((uint32_t)i >= n) key[i] = 0xFFFFFFFFu;
   }
 #pragma unroll
@@ -889,27 +892,19 @@ LOAMX_HD void knn_scan_batch_f32(KnnKeys32<KM>& c, float qx, float qy, float qz,
 // more rounds: queue it). pos as in knn_search_keyed (neighbour j in pos[(KM - k) + j]).
 // `rel` = SoA single-precision offsets of the sorted target points from the grid origin, planes of
 // `plane` floats.
-template <int KM>
-LOAMX_HD int knn_search_f32_round1(const GridDesc& g, const uint32_t* __restrict__ cell_start,
-                                   const GridPoint* __restrict__ sp, const float* __restrict__ rel, uint32_t plane, Vec3 q,
-                                   int k, double max_dist, double pass_max, uint32_t pos[KM], uint32_t* row_scratch,
-                                   int row_stride) {
-#pragma unroll
-  for (int j = 0; j < KM; j++) pos[j] = 0;
-  if (g.n_points == 0 || k <= 0) return 0;
-  if (k > KM) k = KM;
-  const int32_t cx = grid_cell_coord(q.x, g.ox, g.inv_h);
-  const int32_t cy = grid_cell_coord(q.y, g.oy, g.inv_h);
-  const int32_t cz = grid_cell_coord(q.z, g.oz, g.inv_h);
-  const int32_t out = grid_outside_distance(g, cx, cy, cz);
-  if (max_dist > 0.0 && out >= 1 && (double)(out - 1) * g.h >= max_dist) return 0;
-  if (out > 1) return -1;
+// Walk, termination test and exact verification of knn_search_f32_round1. WIDE = the running number takes
+// 10 or 12 bits (retry of a query that ran out of the 8-bit numbers); the 8-bit variant keeps its masks as
+// instruction constants. Returns kept >= 0, -1 (undecided / more rounds) or -2 (running number exhausted).
+template <int KM, bool WIDE>
+LOAMX_HD int knn_f32_round1_body(const GridDesc& g, const GridPoint* __restrict__ sp, const float* __restrict__ rel,
+                                 uint32_t plane, Vec3 q, int k, double max_dist, double pass_max, uint32_t pos[KM],
+                                 uint32_t* row_scratch, int row_stride, int32_t cx, int32_t cy, int32_t cz, int nrow,
+                                 uint32_t slots) {
   const double a = knn_f32_err_unit(g);
   const double r2 = knn_radius_bound(max_dist);
   const float qx = (float)(q.x - g.ox), qy = (float)(q.y - g.oy), qz = (float)(q.z - g.oz);
   KnnKeys32<KM> c;
   knn_init(c, k);
-  const int nrow = knn_round1_list(g, cell_start, cx, cy, cz, row_scratch, row_stride);
   // row pruning in single precision, conservatively: slab distances rounded down, the bound up
   const float kDown = 0.99999f, kUp = 1.00001f;
   double sy2m = slab_dist(q.y, g.oy, g.h, cy - 1), sy2p = slab_dist(q.y, g.oy, g.h, cy + 1);
@@ -918,7 +913,9 @@ LOAMX_HD int knn_search_f32_round1(const GridDesc& g, const uint32_t* __restrict
   const float fz2m = (float)(sz2m * sz2m) * kDown, fz2p = (float)(sz2p * sz2p) * kDown;
   const float fr2 = r2 < 1e37 ? (float)r2 * kUp : 3.0e38f;
   const float fa2 = (float)(3003.0 * a * a) * kUp;
-  uint32_t p = 0, e = 0, t = 0;  // t = batches consumed so far (the key carries 4 t + i in 8 bits)
+  const uint32_t imask = WIDE ? (slots <= 1024u ? 0x3FFu : 0xFFFu) : 0xFFu;  // (a compile-time constant when !WIDE)
+  const uint32_t tmax = (imask + 1u) >> 2;
+  uint32_t p = 0, e = 0, t = 0;  // t = batches consumed so far
   int ri = 0;
   for (;;) {
     while (p >= e && ri < nrow) {  // next admissible row
@@ -927,7 +924,7 @@ LOAMX_HD int knn_search_f32_round1(const GridDesc& g, const uint32_t* __restrict
       const float sy2 = jy == 0 ? fy2m : (jy == 1 ? 0.0f : fy2p), sz2 = jz == 0 ? fz2m : (jz == 1 ? 0.0f : fz2p);
       // upper bound on the true k-th d2 (see knn_bound32), evaluated in float with upward slack
       const uint32_t kth = c.key[KM - 1];
-      const float worst = kth >= 0x7F800000u ? 3.0e38f : (knn_bits_f32(kth | 0xFFu) + fa2) * (1.002f * kUp);
+      const float worst = kth >= 0x7F800000u ? 3.0e38f : (knn_bits_f32(kth | imask) + fa2) * (1.002f * kUp);
       const float bound = worst < fr2 ? worst : fr2;
       if (sy2 + sz2 <= bound) {
 #if defined(LOAMX_KNN_STATS)
@@ -938,11 +935,11 @@ LOAMX_HD int knn_search_f32_round1(const GridDesc& g, const uint32_t* __restrict
       }
       ri++;
     }
-    if (p >= e || t >= 64u) break;
-    knn_scan_batch_f32(c, qx, qy, qz, rel, plane, p, e - p, t << 2);
+    if (p >= e || t >= tmax) break;
+    knn_scan_batch_f32(c, qx, qy, qz, rel, plane, p, e - p, t << 2, imask);
     p += 4, t++;
   }
-  if (p < e) return -1;  // more than 63 batches: the 8-bit running number is exhausted
+  if (p < e) return -2;  // the running number is exhausted (more than 63 / 255 / 1 023 batches)
   // ---- is the search over after the 3x3x3 block? (same test as knn_done, with the rigorous bound)
   {
     double guard = kDblMax;
@@ -961,7 +958,7 @@ LOAMX_HD int knn_search_f32_round1(const GridDesc& g, const uint32_t* __restrict
       }
     }
     if (guard < 0.0) guard = 0.0;
-    const bool done = guard == kDblMax || knn_bound32(c, a) < guard * guard || (max_dist > 0.0 && guard >= max_dist);
+    const bool done = guard == kDblMax || knn_bound32(c, a, imask) < guard * guard || (max_dist > 0.0 && guard >= max_dist);
     if (!done) return -1;
   }
   // ---- exact verification of the k selected candidates
@@ -975,7 +972,7 @@ LOAMX_HD int knn_search_f32_round1(const GridDesc& g, const uint32_t* __restrict
     const bool visited = (w1 & 0x80000000u) != 0u;
 #pragma unroll
     for (int i = 0; i < KM; i++) {
-      const uint32_t tb = (c.key[i] & 0xFFu) >> 2;
+      const uint32_t tb = (c.key[i] & imask) >> 2;
       const bool take = visited && rts <= tb && rts >= wts[i];
       wbegin[i] = take ? w0 : wbegin[i];
       wts[i] = take ? rts : wts[i];
@@ -990,7 +987,7 @@ LOAMX_HD int knn_search_f32_round1(const GridDesc& g, const uint32_t* __restrict
     const bool real = i >= KM - k && key != 0xFFFFFFFFu;
     if (real) {
       if (key >= 0x7F800000u) undecided = true;
-      const uint32_t tb = (key & 0xFFu) >> 2, ii = key & 3u;
+      const uint32_t tb = (key & imask) >> 2, ii = key & 3u;
       const uint32_t pp = wbegin[i] + (tb - wts[i]) * 4u + ii;
       pos[i] = pp;
       const GridPoint tp = sp[pp];
@@ -1008,11 +1005,39 @@ LOAMX_HD int knn_search_f32_round1(const GridDesc& g, const uint32_t* __restrict
   }
   const uint32_t k6 = c.key[KM];
   if (count == k && k6 != 0xFFFFFFFFu) {
-    const double t6 = (double)knn_bits_f32(k6 & 0xFFFFFF00u);
+    const double t6 = (double)knn_bits_f32(k6 & ~imask);
     const double err = 2.0 * (3.4641016151377544 * a * sqrt(d5) + 3.0 * a * a + 2.384185791015625e-7 * d5);  // x2 safety
     if (!(t6 > d5 + err)) undecided = true;
   }
   return undecided ? -1 : kept;
+}
+
+
+// WIDE = false: 8-bit running numbers (the fast kernel; a query with more than 63 batches is queued);
+// WIDE = true: 10 or 12 bits (the queue kernel tries this before the FP64 search: dense local maps).
+template <int KM, bool WIDE = false>
+LOAMX_HD int knn_search_f32_round1(const GridDesc& g, const uint32_t* __restrict__ cell_start,
+                                   const GridPoint* __restrict__ sp, const float* __restrict__ rel, uint32_t plane, Vec3 q,
+                                   int k, double max_dist, double pass_max, uint32_t pos[KM], uint32_t* row_scratch,
+                                   int row_stride) {
+#pragma unroll
+  for (int j = 0; j < KM; j++) pos[j] = 0;
+  if (g.n_points == 0 || k <= 0) return 0;
+  if (k > KM) k = KM;
+  const int32_t cx = grid_cell_coord(q.x, g.ox, g.inv_h);
+  const int32_t cy = grid_cell_coord(q.y, g.oy, g.inv_h);
+  const int32_t cz = grid_cell_coord(q.z, g.oz, g.inv_h);
+  const int32_t out = grid_outside_distance(g, cx, cy, cz);
+  if (max_dist > 0.0 && out >= 1 && (double)(out - 1) * g.h >= max_dist) return 0;
+  if (out > 1) return -1;
+  uint32_t pop = 0;
+  const int nrow = knn_round1_list(g, cell_start, cx, cy, cz, row_scratch, row_stride, &pop);
+  // the key carries the candidate's running number 4 t + i in its low bits: 8 bits (63 batches) cover a
+  // scan-sized target; a denser block (a local map) takes more bits at the price of a coarser pre-selection
+  const uint32_t slots = pop + 4u * (uint32_t)nrow + 4u;  // every row may end in a partly filled batch
+  const int kept = knn_f32_round1_body<KM, WIDE>(g, sp, rel, plane, q, k, max_dist, pass_max, pos, row_scratch, row_stride, cx,
+                                                 cy, cz, nrow, slots);
+  return kept;  // >= 0, -1 (undecided / needs more rounds) or -2 (ran out of running numbers)
 }
 
 // The complete search: keyed collector over all rounds, then the exact collector for a query whose

@@ -349,10 +349,12 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_kn
                                              s_rows + threadIdx.x, kAssocThreads);
   const size_t field = B.n_pairs * stride, slot = pair * stride + i;
   uint32_t* __restrict__ nn = PLANE ? B.assoc.nn_plane : B.assoc.nn_edge;  // [1 + KM][n_pairs * stride]
-  nn[slot] = (uint32_t)kept;
+  nn[slot] = kept < 0 ? 0xFFFFFFFFu : (uint32_t)kept;
   if (kept < 0) {  // not finished by round 1: queued for associate_knn_rest_kernel
     const uint32_t at = atomicAdd(&B.assoc.n_assoc[8 * pair + (PLANE ? 3 : 2)], 1u);
-    (PLANE ? B.assoc.rest_plane : B.assoc.rest_edge)[pair * stride + at] = i;
+    // (bit 31: the query only ran out of 8-bit running numbers — a dense block: the queue kernel retries the
+    // FP32 pre-selection with wide numbers before the FP64 search)
+    (PLANE ? B.assoc.rest_plane : B.assoc.rest_edge)[pair * stride + at] = i | (kept == -2 ? 0x80000000u : 0u);
   }
 #pragma unroll
   for (int j = 0; j < KM; j++) nn[(1 + j) * field + slot] = pos[j];  // neighbour j is slot (KM - k) + j
@@ -389,13 +391,21 @@ __global__ __launch_bounds__(kRestThreads) void associate_knn_rest_kernel(RegBat
   const uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
   const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
   for (uint32_t t = chunk0 * kRestThreads + threadIdx.x; t < queued; t += blocks_per_pair * kRestThreads) {
-    const uint32_t i = rest[t];
+    const uint32_t entry = rest[t], i = entry & 0x7FFFFFFFu;
     const size_t slot = pair * stride + t;  // (queue position, not query index)
     const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
     const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));
     uint32_t pos[KM];
-    const int kept = knn_search_keyed<KM>(g, cs, sp, p, PLANE ? C.k_plane : C.k_edge, PLANE ? C.r_plane : C.r_edge,
-                                          PLANE ? C.pass_plane : C.pass_edge, pos, s_rows + threadIdx.x, kRestThreads);
+    // first the FP32 pre-selection with wide running numbers (queries of dense blocks that ran out of the 8-bit
+    // numbers in the round-1 kernel), then the FP64 keyed collector over all rounds
+    int kept = -1;
+    if (entry & 0x80000000u)
+      kept = knn_search_f32_round1<KM, true>(g, cs, sp, gs.rel + pair * 3 * gs.stride, (uint32_t)gs.stride, p,
+                                              PLANE ? C.k_plane : C.k_edge, PLANE ? C.r_plane : C.r_edge,
+                                              PLANE ? C.pass_plane : C.pass_edge, pos, s_rows + threadIdx.x, kRestThreads);
+    if (kept < 0)
+      kept = knn_search_keyed<KM>(g, cs, sp, p, PLANE ? C.k_plane : C.k_edge, PLANE ? C.r_plane : C.r_edge,
+                                  PLANE ? C.pass_plane : C.pass_edge, pos, s_rows + threadIdx.x, kRestThreads);
     rnn[slot] = (uint32_t)kept;
     if (kept < 0) exact[atomicAdd(&B.assoc.n_assoc[8 * pair + (PLANE ? 5 : 4)], 1u)] = t;
 #pragma unroll
@@ -428,7 +438,7 @@ __global__ __launch_bounds__(kAssocThreads) void associate_knn_exact_kernel(RegB
   int k = PLANE ? C.k_plane : C.k_edge;
   k = k < KM ? k : KM;
   for (uint32_t t = chunk0 * kAssocThreads + threadIdx.x; t < queued; t += blocks_per_pair * kAssocThreads) {
-    const uint32_t qpos = exact[t], i = rest[qpos];
+    const uint32_t qpos = exact[t], i = rest[qpos] & 0x7FFFFFFFu;
     const size_t slot = pair * stride + qpos;
     const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
     const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));
@@ -540,7 +550,7 @@ __global__ __launch_bounds__(kRestThreads) void associate_fit_queued_kernel(RegB
   const uint32_t* __restrict__ rest = (PLANE ? B.assoc.rest_plane : B.assoc.rest_edge) + pair * stride;
   uint32_t count = 0;
   for (uint32_t t = chunk0 * kRestThreads + threadIdx.x; t < queued; t += blocks_per_pair * kRestThreads)
-    count += fit_one<PLANE, KM>(B, C, S, pair, rest[t], rnn, pair * stride + t) ? 1u : 0u;
+    count += fit_one<PLANE, KM>(B, C, S, pair, rest[t] & 0x7FFFFFFFu, rnn, pair * stride + t) ? 1u : 0u;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) count += __shfl_xor(count, off);
   if ((threadIdx.x & 63) == 0 && count) atomicAdd(&B.assoc.n_assoc[8 * pair + (PLANE ? 1 : 0)], count);

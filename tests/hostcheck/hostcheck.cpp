@@ -263,6 +263,13 @@ static int knn_both(const HostGrid& G, Vec3 q, int k, double max_dist, uint32_t 
                                        pass_max, pos, rows, 1);
   if (kept < 0) {
     g_knn_queued++;
+    // the queue kernel: a query that only ran out of 8-bit running numbers retries the FP32 pre-selection with
+    // wide ones; then the complete FP64 search
+    if (kept == -2)
+      kept = knn_search_f32_round1<KM, true>(G.g, G.cell_start.data(), G.sp.data(), G.rel.data(), (uint32_t)G.sp.size(), q, k,
+                                             max_dist, pass_max, pos, rows, 1);
+  }
+  if (kept < 0) {
     kept = knn_search_positions<KM>(G.g, G.cell_start.data(), G.sp.data(), q, k, max_dist, pass_max, pos, rows, 1, &fb);
   }
   g_knn_fallbacks += fb;
