@@ -460,7 +460,13 @@ int loamx_ctx_create(int device, loamx_ctx** out) {
   }
   ctx->stream = ctx->own_stream;
   // optional: without the auxiliary stream the edge and plane association chains simply run in sequence
-  if (!getenv("LOAMX_NO_AUX_STREAM") && hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) == hipSuccess) {
+  // The auxiliary stream carries small, latency-bound kernels next to the big ones of the main stream: it gets the
+  // highest priority so that their workgroups are dispatched as soon as they are ready instead of after the main
+  // stream's kernel has handed out all of its own (measured: association 2.61 -> 2.57 ms).
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  if (!getenv("LOAMX_NO_AUX_STREAM") &&
+      hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, getenv("LOAMX_AUX_NORMAL_PRIO") ? prio_least : prio_greatest) == hipSuccess) {
     if (hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_mid, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {

@@ -781,8 +781,8 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
 #define LOAMX_ASSOC_A1(PL, KMV, nblk, st)                                                                         \
   do {                                                                                                            \
     const dim3 grid_((unsigned)(pair_groups * 8 * (nblk)));                                                       \
-    hipLaunchKernelGGL((associate_knn_brute_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, (st), B, C, (nblk)); \
     hipLaunchKernelGGL((associate_knn_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, (st), B, C, (nblk));       \
+    hipLaunchKernelGGL((associate_knn_brute_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, (st), B, C, (nblk)); \
   } while (0)
 #define LOAMX_ASSOC_A2(PL, KMV, nblk, st)                                                                         \
   hipLaunchKernelGGL((associate_fit_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * (nblk))), dim3(kAssocThreads), 0, \
