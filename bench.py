@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=1024, help="scan pairs per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="pairs timed on the CPU oracle (default: 8 per thread, <= 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=SEED, help="seed of the synthetic scan pairs (default: the benchmark's)")
     args = ap.parse_args()
 
     import numpy as np
@@ -106,7 +107,7 @@ def main():
     xyz = torch.empty(P * 2 * N * 3, dtype=torch.float64, device=dev)  # inputs resident in HBM
     results = torch.zeros(P * 64, dtype=torch.uint8, device=dev)
     from loam_amd import distributed as D
-    ctx.synth_scan_pairs_dev(SEED, first_pair, P, H, W, SIGMA, xyz.data_ptr())
+    ctx.synth_scan_pairs_dev(args.seed, first_pair, P, H, W, SIGMA, xyz.data_ptr())
     torch.cuda.synchronize()
 
     def step():
@@ -187,7 +188,7 @@ def main():
             "config": {"workload": f"batch of {P} independent 64x1024 scan pairs per GPU (BASELINE configs[2]/[3]); "
                                    "step = extractFeatures x2 + registerFeatures per pair, inputs resident in HBM",
                        "pairs_per_gpu": P, "scan": "64x1024", "sharding": "by pair id, no data-path collective",
-                       "seed": SEED, "range_noise_sigma_m": SIGMA},
+                       "seed": args.seed, "range_noise_sigma_m": SIGMA},
             "roofline": roofline,
             "kernels": kern,
             "results": {"converged": int((res["termination"] == 0).sum()), "max_iter": int((res["termination"] == 1).sum()),
