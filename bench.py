@@ -165,7 +165,7 @@ def main():
 
         # the dominant scope (exact FP64 k-NN + fits) is instruction / latency bound; the HBM-bound kernels of
         # the path (the ones north_star prices against the roofline) are reported next to it
-        roofline["hbm_bound_kernels"] = {n: kern[n]["hbm_frac"] for n in ("curvature_valid_kernel", "sweep_kernel") if n in kern}
+        roofline["hbm_bound_kernels"] = {n: kern[n]["hbm_frac"] for n in ("curvature_valid_kernel", "sweep_kernel", "moment_kernel") if n in kern}
         # HBM traffic per launch of the dominant kernel, from the committed rocprofv3 PMC passes of this
         # same command (profiles/r01_pmc.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); null if absent
         try:

@@ -196,9 +196,10 @@ enum {
   LOAMX_K_COMPACT = 2,   /* feature gather */
   LOAMX_K_GRID = 3,      /* target spatial index build */
   LOAMX_K_ASSOC = 4,     /* kNN + line/plane fit */
-  LOAMX_K_SWEEP = 5,     /* residual / Jacobian / normal equations, 56 B per plane + 72 B per edge slot */
+  LOAMX_K_SWEEP = 5,     /* residual / Jacobian / normal equations, 56 B per plane + 72 B per edge slot streamed */
   LOAMX_K_LM = 6,        /* per-pair trust-region bookkeeping */
-  LOAMX_K_COUNT = 7
+  LOAMX_K_MOMENT = 7,    /* plane moment pass (Gram matrix of the plane coefficients), 56 B per plane slot */
+  LOAMX_K_COUNT = 8
 };
 typedef struct {
   uint64_t launches;

@@ -21,7 +21,7 @@ enum WsId {
   WS_XYZ = 0, WS_CURV, WS_MASK, WS_EDGE_STAGE, WS_PLANAR_STAGE, WS_EDGE_CNT, WS_PLANAR_CNT,
   WS_EDGE_IDX, WS_PLANAR_IDX, WS_N_EDGE, WS_N_PLANAR, WS_EDGE_XYZ, WS_PLANAR_XYZ,
   WS_GRID_DESC_E, WS_GRID_DESC_P, WS_CELLS_E, WS_CELLS_P, WS_SORTED_E, WS_SORTED_P, WS_REL_E, WS_REL_P,
-  WS_SGRID_DESC_E, WS_SGRID_DESC_P, WS_SCELLS_E, WS_SCELLS_P, WS_SSORTED_E, WS_SSORTED_P, WS_SORT_SCRATCH, WS_ASSOC_E, WS_ASSOC_P, WS_NN_E, WS_NN_P, WS_RNN_E, WS_RNN_P, WS_NEAREST_E, WS_NEAREST_P, WS_REST_E, WS_REST_P, WS_EXACT_E, WS_EXACT_P, WS_NASSOC, WS_STATE, WS_PARTIALS,
+  WS_SGRID_DESC_E, WS_SGRID_DESC_P, WS_SCELLS_E, WS_SCELLS_P, WS_SSORTED_E, WS_SSORTED_P, WS_SORT_SCRATCH, WS_ASSOC_E, WS_ASSOC_P, WS_NN_E, WS_NN_P, WS_RNN_E, WS_RNN_P, WS_NEAREST_E, WS_NEAREST_P, WS_REST_E, WS_REST_P, WS_EXACT_E, WS_EXACT_P, WS_NASSOC, WS_STATE, WS_PARTIALS, WS_MOM_PARTIALS, WS_MOMENTS, WS_FLAGGED_LIST, WS_FLAGGED_COUNT,
   WS_COUNTERS, WS_ITERINFO, WS_SRC_E, WS_SRC_P, WS_TGT_E, WS_TGT_P, WS_FCOUNTS, WS_RESULTS, WS_INIT,
   WS_COUNT
 };
@@ -71,7 +71,7 @@ namespace {
 
 const char* kKernelNames[LOAMX_K_COUNT] = {"curvature_valid_kernel", "select_kernel", "compact_kernel",
                                            "grid_build_kernel",      "associate_kernel", "sweep_kernel",
-                                           "lm_kernels"};
+                                           "lm_kernels",             "moment_kernel"};
 
 int fail(loamx_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->last_error = msg;
@@ -311,6 +311,11 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   ENSURE(ctx, WS_STATE, np * sizeof(PairState));
   B.blocks_per_pair = (uint32_t)((es + ps + kSweepChunk - 1) / kSweepChunk);
   ENSURE(ctx, WS_PARTIALS, np * B.blocks_per_pair * kAccSize * sizeof(double));
+  B.mom_blocks_per_pair = (uint32_t)((ps + kSweepChunk - 1) / kSweepChunk);
+  ENSURE(ctx, WS_MOM_PARTIALS, np * B.mom_blocks_per_pair * 4 * (size_t)(kMomSize + 2) * sizeof(double));
+  ENSURE(ctx, WS_MOMENTS, np * (size_t)(kMomSize + 2) * sizeof(double));
+  ENSURE(ctx, WS_FLAGGED_LIST, np * (size_t)B.mom_blocks_per_pair * kSweepChunk * sizeof(uint32_t));
+  ENSURE(ctx, WS_FLAGGED_COUNT, np * (size_t)B.mom_blocks_per_pair * 4 * sizeof(uint32_t));
   {
     const bool fresh = ctx->ws[WS_COUNTERS].cap == 0;
     ENSURE(ctx, WS_COUNTERS, 64);
@@ -333,6 +338,10 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
                          wsp<uint32_t>(ctx, WS_NASSOC)};
   B.state = wsp<PairState>(ctx, WS_STATE);
   B.partials = wsp<double>(ctx, WS_PARTIALS);
+  B.mom_partials = wsp<double>(ctx, WS_MOM_PARTIALS);
+  B.moments = wsp<double>(ctx, WS_MOMENTS);
+  B.flagged_list = wsp<uint32_t>(ctx, WS_FLAGGED_LIST);
+  B.flagged_count = wsp<uint32_t>(ctx, WS_FLAGGED_COUNT);
   // counters: [0] n_active (u32), [8..24) sweep slot counters (2 x u64)
   B.n_active = wsp<uint32_t>(ctx, WS_COUNTERS);
   B.sweep_slots = reinterpret_cast<unsigned long long*>(wsp<unsigned char>(ctx, WS_COUNTERS) + 8);
@@ -368,6 +377,10 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
     {
       TimedScope t(ctx, LOAMX_K_LM, 0.0);
       launch_lm_begin(B, C, it, s);
+    }
+    {
+      TimedScope t(ctx, LOAMX_K_MOMENT, 0.0);
+      launch_moments(B, s);
     }
     for (int k = 0; k < 5; k++) {  // iteration-0 evaluation + max_num_iterations = 4 candidates
       {
@@ -865,10 +878,10 @@ int loamx_ctx_enable_kernel_timing(loamx_ctx* ctx, int enable) {
   return LOAMX_OK;
 }
 
-static int read_sweep_slots(loamx_ctx* ctx, unsigned long long out[4]) {
-  out[0] = out[1] = out[2] = out[3] = 0;
+static int read_sweep_slots(loamx_ctx* ctx, unsigned long long out[5]) {
+  out[0] = out[1] = out[2] = out[3] = out[4] = 0;
   if (!ctx->ws[WS_COUNTERS].p) return LOAMX_OK;
-  HIP_TRY(ctx, hipMemcpy(out, wsp<unsigned char>(ctx, WS_COUNTERS) + 8, 32, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(out, wsp<unsigned char>(ctx, WS_COUNTERS) + 8, 40, hipMemcpyDeviceToHost));
   return LOAMX_OK;
 }
 
@@ -880,7 +893,7 @@ int loamx_ctx_reset_kernel_stats(loamx_ctx* ctx) {
   if (rc != LOAMX_OK) return rc;
   memset(ctx->stats, 0, sizeof(ctx->stats));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->ws[WS_COUNTERS].p) HIP_TRY(ctx, hipMemset(wsp<unsigned char>(ctx, WS_COUNTERS) + 8, 0, 32));
+  if (ctx->ws[WS_COUNTERS].p) HIP_TRY(ctx, hipMemset(wsp<unsigned char>(ctx, WS_COUNTERS) + 8, 0, 40));
   return LOAMX_OK;
 }
 
@@ -891,7 +904,7 @@ int loamx_ctx_get_kernel_stats(loamx_ctx* ctx, loamx_kernel_stat* stats) {
   int rc = resolve_events(ctx);
   if (rc != LOAMX_OK) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  unsigned long long slots[4];
+  unsigned long long slots[5];
   rc = read_sweep_slots(ctx, slots);
   if (rc != LOAMX_OK) return rc;
   memcpy(stats, ctx->stats, sizeof(ctx->stats));
@@ -899,6 +912,7 @@ int loamx_ctx_get_kernel_stats(loamx_ctx* ctx, loamx_kernel_stat* stats) {
   stats[LOAMX_K_SWEEP].algorithmic_bytes = 72.0 * (double)slots[0] + 56.0 * (double)slots[1];
   // associate: read the 24 B source point, write the record + the 4 B nearest index
   stats[LOAMX_K_ASSOC].algorithmic_bytes = 100.0 * (double)slots[2] + 84.0 * (double)slots[3];
+  stats[LOAMX_K_MOMENT].algorithmic_bytes = 56.0 * (double)slots[4];  // moment pass: every plane record once
   return LOAMX_OK;
 }
 

@@ -82,6 +82,8 @@ struct PairState {
   uint32_t termination;
   uint32_t iterations;
   uint32_t first_sweep;  // next sweep is the iteration-0 evaluation
+  uint32_t stream_planes;  // 1: the next sweep streams this pair's plane records (its moments cannot stand in for them)
+  uint32_t use_moments;    // this ICF iteration runs the moment pass for the pair
 };
 
 constexpr int kSweepThreads = 256;
@@ -112,9 +114,15 @@ struct RegBatch {
   AssocBuffers assoc;
   PairState* state;      // [n_pairs]
   double* partials;      // [n_pairs][blocks_per_pair][kAccSize]
+  double* mom_partials;  // [n_pairs][mom_blocks_per_pair][4][kMomSize + 2] wavefront tiles of the moment pass
+  double* moments;       // [n_pairs][kMomSize + 2] plane moment matrix (16x16), max |s0|, max |v|^2 (reg_math.h)
+  uint32_t mom_blocks_per_pair;
+  uint32_t* flagged_list;   // [n_pairs][mom_blocks_per_pair][4 wavefronts][kSweepChunk / 4] plane slots the moments leave out, in slot order
+  uint32_t* flagged_count;  // [n_pairs][mom_blocks_per_pair][4]
   uint32_t blocks_per_pair;
   uint32_t* n_active;    // device counter read back by the host after every outer iteration
-  unsigned long long* sweep_slots;  // [2] edge / plane association slots streamed by sweep_kernel (roofline bytes)
+  unsigned long long* sweep_slots;  // [0,1] edge / plane association slots streamed by sweep_kernel (roofline bytes);
+                                    // [2,3] assoc_slots; [4] plane slots streamed by the moment pass
   unsigned long long* assoc_slots;  // [2] edge / plane source features processed by associate_kernel
   loamx_iter_info* iter_info;  // optional [n_pairs][max_iterations]
   uint32_t want_nearest;  // 1: a detail hook will read nearest_* (RegistrationDetail pairs); 0: the fit kernels skip that write
@@ -128,6 +136,7 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
 void launch_lm_begin(const RegBatch& B, const RegConfig& C, uint32_t iteration, hipStream_t s);
 void launch_sweep(const RegBatch& B, hipStream_t s);
 void launch_lm_step(const RegBatch& B, hipStream_t s);
+void launch_moments(const RegBatch& B, hipStream_t s);
 void launch_outer_update(const RegBatch& B, const RegConfig& C, uint32_t iteration, hipStream_t s);
 void launch_write_results(const RegBatch& B, loamx_reg_result* d_results, hipStream_t s);
 

@@ -1407,6 +1407,113 @@ LOAMX_HD void residual_accumulate(bool is_plane, Vec3 v, const double prim[6], c
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * Plane residuals through moments.
+ *
+ * The signed point-to-plane residual is a polynomial in the ambient update x = (u, w, t) whose
+ * coefficients depend on the association record (moved point v, normal n, offset d) only:
+ *     s(x) = n.(v + 2w (u x v) + 2 u x (u x v) + t) - d  =  c . phi(x),
+ *     c   = [n.v - d,  v x n (3),  q_xx q_yy q_zz q_xy q_xz q_yz,  n (3)]        (13 numbers per record)
+ *     phi = [1, 2w u (3), ux^2 uy^2 uz^2 ux*uy ux*uz uy*uz, t (3)],
+ *     q_aa = 2 n_a v_a - 2 n.v,  q_ab = 2 (n_a v_b + n_b v_a).
+ * The residual block is |s| with Jacobian sign(s) ds/dx, so J^T J, J^T f and the cost only see s.
+ * While every |s| stays below the Huber threshold (1.0: the corrector is the identity there) the sums
+ * over all plane records of one pair are therefore
+ *     cost = phi^T M phi / 2,   J^T f = Z^T M phi,   J^T J = Z^T M Z,     M = sum c c^T  (13x13),
+ * Z(x) = d phi / d tangent (13x6, with the same QuaternionManifold convention as residual_accumulate).
+ * M is a Gram matrix: accumulated once per ICF iteration by streaming the records through FP64 MFMA
+ * (moment_kernel); the evaluations of the trust-region solve then cost O(1) per pair instead of a pass
+ * over the records each. The guarantee |s_i(x)| <= max|s_i(0)| + |pp_i(x) - v_i| < 1 is checked per pair
+ * and candidate from the two maxima the moment pass also delivers; a pair / candidate that fails it
+ * streams its plane records as before (the first ICF iteration usually does: its update is large).
+ * ---------------------------------------------------------------------------------------------- */
+constexpr int kMomDim = 13;
+constexpr int kMomStride = 16;                       // the moment matrix is kept as 16x16 (MFMA tile), rows/cols 13..15 zero
+constexpr int kMomSize = kMomStride * kMomStride;    // doubles per pair, + 2 maxima
+constexpr double kMomInlier = 0.5;  // plane records with |s0| above this stay out of the moments (evaluated one by one)
+LOAMX_HD void plane_coeffs(Vec3 v, Vec3 n, double d, double c[kMomDim]) {
+  const double nv = vdot(n, v);
+  c[0] = nv - d;
+  const Vec3 m = vcross(v, n);
+  c[1] = m.x, c[2] = m.y, c[3] = m.z;
+  c[4] = 2.0 * n.x * v.x - 2.0 * nv, c[5] = 2.0 * n.y * v.y - 2.0 * nv, c[6] = 2.0 * n.z * v.z - 2.0 * nv;
+  c[7] = 2.0 * (n.x * v.y + n.y * v.x), c[8] = 2.0 * (n.x * v.z + n.z * v.x), c[9] = 2.0 * (n.y * v.z + n.z * v.y);
+  c[10] = n.x, c[11] = n.y, c[12] = n.z;
+}
+// adds the plane terms of one pair at x to acc (layout of residual_accumulate); M = 16x16 row-major
+LOAMX_HD void plane_eval_from_moments(const double* M, const double x[7], double acc[29]) {
+  const double ux = x[0], uy = x[1], uz = x[2], w = x[3];
+  double phi[kMomDim] = {1.0, 2.0 * w * ux, 2.0 * w * uy, 2.0 * w * uz, ux * ux, uy * uy, uz * uz,
+                         ux * uy, ux * uz, uy * uz, x[4], x[5], x[6]};
+  // ambient gradient of phi wrt (ux, uy, uz, w), then the tangent map of residual_accumulate
+  double A[kMomDim][4];
+#pragma unroll
+  for (int j = 0; j < kMomDim; j++) A[j][0] = A[j][1] = A[j][2] = A[j][3] = 0.0;
+  A[1][0] = 2.0 * w, A[1][3] = 2.0 * ux;
+  A[2][1] = 2.0 * w, A[2][3] = 2.0 * uy;
+  A[3][2] = 2.0 * w, A[3][3] = 2.0 * uz;
+  A[4][0] = 2.0 * ux, A[5][1] = 2.0 * uy, A[6][2] = 2.0 * uz;
+  A[7][0] = uy, A[7][1] = ux;
+  A[8][0] = uz, A[8][2] = ux;
+  A[9][1] = uz, A[9][2] = uy;
+  const double W = x[0], X = x[1], Y = x[2], Zq = x[3];
+  double Z[kMomDim][6];
+#pragma unroll
+  for (int j = 0; j < kMomDim; j++) {
+    Z[j][0] = A[j][0] * (-X) + A[j][1] * W + A[j][2] * (-Zq) + A[j][3] * Y;
+    Z[j][1] = A[j][0] * (-Y) + A[j][1] * Zq + A[j][2] * W + A[j][3] * (-X);
+    Z[j][2] = A[j][0] * (-Zq) + A[j][1] * (-Y) + A[j][2] * X + A[j][3] * W;
+    Z[j][3] = j == 10 ? 1.0 : 0.0, Z[j][4] = j == 11 ? 1.0 : 0.0, Z[j][5] = j == 12 ? 1.0 : 0.0;
+  }
+  double y[kMomDim], T[kMomDim][6];
+#pragma unroll
+  for (int i = 0; i < kMomDim; i++) {
+    double yi = 0.0, ti[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < kMomDim; j++) {
+      const double mij = M[i * kMomStride + j];
+      yi += mij * phi[j];
+#pragma unroll
+      for (int a = 0; a < 6; a++) ti[a] += mij * Z[j][a];
+    }
+    y[i] = yi;
+#pragma unroll
+    for (int a = 0; a < 6; a++) T[i][a] = ti[a];
+  }
+  int t = 0;
+#pragma unroll
+  for (int a = 0; a < 6; a++) {
+#pragma unroll
+    for (int b = a; b < 6; b++) {
+      double sum = 0.0;
+#pragma unroll
+      for (int i = 0; i < kMomDim; i++) sum += Z[i][a] * T[i][b];
+      acc[t++] += sum;
+    }
+  }
+  double cost = 0.0;
+#pragma unroll
+  for (int i = 0; i < kMomDim; i++) cost += phi[i] * y[i];
+#pragma unroll
+  for (int a = 0; a < 6; a++) {
+    double sum = 0.0;
+#pragma unroll
+    for (int i = 0; i < kMomDim; i++) sum += Z[i][a] * y[i];
+    acc[21 + a] += sum;
+  }
+  acc[27] += 0.5 * cost;
+  if (!(cost - cost == 0.0)) acc[28] += 1.0;  // non-finite moments: as a failed evaluation
+}
+// May the moments stand in for the plane records at x? Yes if every |s_i(x)| is provably below the
+// Huber threshold: |s_i(x)| <= |s_i(0)| + |pp_i(x) - v_i|, and for the quaternion formula (also for
+// non-unit quaternions) |pp - v - t| = |2w u x v + 2 (u (u.v) - v (u.u))| <= (2 |w| |u| + 4 |u|^2) |v|.
+LOAMX_HD bool plane_moments_valid_at(double s0max, double v2max, const double x[7]) {
+  const double uu = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+  const double rot = 2.0 * fabs(x[3]) * sqrt(uu) + 4.0 * uu;
+  const double trans = sqrt(x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
+  return s0max + rot * sqrt(v2max) + trans < 0.999;  // (NaN compares false)
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Ceres manifold Plus for the 7 ambient doubles (QuaternionManifold on raw storage read as
  * (W,X,Y,Z), EuclideanManifold<3>)
  * ---------------------------------------------------------------------------------------------- */

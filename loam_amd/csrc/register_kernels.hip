@@ -193,6 +193,8 @@ __global__ void state_init_kernel(RegBatch B, RegConfig C) {
   S.termination = LOAMX_MAX_ITER;  // registration-inl.h:27
   S.iterations = 0;
   S.first_sweep = 0;
+  S.stream_planes = 1;
+  S.use_moments = 0;
   S.lm.active = 0;
   for (int c = 0; c < 6; c++) B.assoc.n_assoc[8 * pair + c] = 0;
 }
@@ -601,13 +603,18 @@ __global__ __launch_bounds__(kSweepThreads, LOAMX_SWEEP_WAVES) void sweep_kernel
   double acc[kAccSize];
 #pragma unroll
   for (int j = 0; j < kAccSize; j++) acc[j] = 0.0;
-  // the slot space of a pair is [edges 0..n_se) ++ [planes 0..n_sp); chunk `blk` of it
+  // the slot space of a pair is [edges 0..n_se) ++ [planes 0..n_sp); chunk `blk` of it. A pair whose moment
+  // matrix can stand in for its plane records at this point (reg_math.h: "Plane residuals through moments") is
+  // left to sweep_light_kernel.
+  if (S.stream_planes == 0u) return;  // uniform: sweep_light_kernel evaluates this pair (moments + listed records)
   const uint32_t total = n_se + n_sp;
   const uint32_t base = blk * kSweepChunk;
+  if (base >= total) return;  // uniform per workgroup
   if (blk == 0 && threadIdx.x == 0 && B.sweep_slots) {
     atomicAdd(&B.sweep_slots[0], (unsigned long long)n_se);
     atomicAdd(&B.sweep_slots[1], (unsigned long long)n_sp);
   }
+  {
   // software-pipelined: the record of item it+1 is in flight while item it is evaluated
   struct Rec {
     double f[9];
@@ -644,6 +651,7 @@ __global__ __launch_bounds__(kSweepThreads, LOAMX_SWEEP_WAVES) void sweep_kernel
     }
     cur = nxt;
   }
+  }  // streaming path
   // wavefront shuffle reduction, then LDS across the 4 wavefronts, fixed order => deterministic
 #pragma unroll
   for (int j = 0; j < kAccSize; j++) {
@@ -665,6 +673,133 @@ __global__ __launch_bounds__(kSweepThreads, LOAMX_SWEEP_WAVES) void sweep_kernel
   }
 }
 
+/* The sweep of a pair that is on moments: one workgroup evaluates its edge records and the listed
+ * (far-from-plane) plane records one by one, adds the plane terms of all other records from the moment
+ * matrix (the 13x7 products M [Z | phi] spread over the threads), and writes the pair's single partial. */
+__global__ __launch_bounds__(kSweepThreads) void sweep_light_kernel(RegBatch B) {
+  __shared__ double s_part[kSweepThreads / 64][kAccSize];
+  __shared__ double s_T[kMomDim][7], s_Z[kMomDim][7];
+  const size_t pair = blockIdx.x;
+  const PairState& S = B.state[pair];
+  if (!S.active || !S.lm.active || S.stream_planes != 0u) return;  // uniform per workgroup
+  double x[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) x[i] = S.lm.xeval[i];
+  const uint32_t n_se_raw = B.n_src_edge[pair * B.in_pitch], n_sp_raw = B.n_src_planar[pair * B.in_pitch];
+  const uint32_t n_se = n_se_raw < B.edge_stride ? n_se_raw : (uint32_t)B.edge_stride;
+  const uint32_t n_sp = n_sp_raw < B.planar_stride ? n_sp_raw : (uint32_t)B.planar_stride;
+  const size_t efield = B.n_pairs * B.edge_stride, pfield = B.n_pairs * B.planar_stride;
+  const double* __restrict__ E = B.assoc.edge + pair * B.edge_stride;
+  const double* __restrict__ Pl = B.assoc.plane + pair * B.planar_stride;
+  if (threadIdx.x == 0 && B.sweep_slots) atomicAdd(&B.sweep_slots[0], (unsigned long long)n_se);
+  double acc[kAccSize];
+#pragma unroll
+  for (int j = 0; j < kAccSize; j++) acc[j] = 0.0;
+  for (uint32_t v = threadIdx.x; v < n_se; v += kSweepThreads) {
+    const double f0 = E[v];
+    if (f0 == f0) {  // NaN in field 0 marks an invalid slot
+      double prim[6];
+#pragma unroll
+      for (int f = 0; f < 6; f++) prim[f] = E[(3 + f) * efield + v];
+      residual_accumulate(false, v3(f0, E[efield + v], E[2 * efield + v]), prim, x, acc);
+    }
+  }
+  for (uint32_t lb = 0; lb < B.mom_blocks_per_pair * 4 && (lb / 4) * kSweepChunk < n_sp; lb++) {
+    const uint32_t cnt = B.flagged_count[pair * B.mom_blocks_per_pair * 4 + lb];
+    const uint32_t* __restrict__ fl = B.flagged_list + (pair * B.mom_blocks_per_pair * 4 + lb) * (size_t)(kSweepChunk / 4);
+    for (uint32_t k = threadIdx.x; k < cnt; k += kSweepThreads) {
+      const uint32_t q = fl[k];
+      const double prim[6] = {Pl[3 * pfield + q], Pl[4 * pfield + q], Pl[5 * pfield + q], Pl[6 * pfield + q], 0.0, 0.0};
+      residual_accumulate(true, v3(Pl[q], Pl[pfield + q], Pl[2 * pfield + q]), prim, x, acc);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kAccSize; j++) {
+    double v = acc[j];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off);
+    acc[j] = v;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < kAccSize; j++) s_part[wave][j] = acc[j];
+  }
+  // ---- plane terms from the moments: [Z | phi] (13 x 7), T = M [Z | phi], then Z^T T
+  const double* __restrict__ mom = B.moments + pair * (size_t)(kMomSize + 2);
+  if (threadIdx.x < kMomDim * 7) {
+    const int j = threadIdx.x / 7, a = threadIdx.x % 7;
+    const double ux = x[0], uy = x[1], uz = x[2], w = x[3];
+    double val;
+    if (a == 6) {  // phi_j
+      const double phi[kMomDim] = {1.0, 2.0 * w * ux, 2.0 * w * uy, 2.0 * w * uz, ux * ux, uy * uy, uz * uz,
+                                   ux * uy, ux * uz, uy * uz, x[4], x[5], x[6]};
+      val = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < kMomDim; jj++)
+        if (jj == j) val = phi[jj];
+    } else {  // Z_ja: ambient gradient of phi_j, then the tangent map (as plane_eval_from_moments)
+      double A[kMomDim][4];
+#pragma unroll
+      for (int jj = 0; jj < kMomDim; jj++) A[jj][0] = A[jj][1] = A[jj][2] = A[jj][3] = 0.0;
+      A[1][0] = 2.0 * w, A[1][3] = 2.0 * ux;
+      A[2][1] = 2.0 * w, A[2][3] = 2.0 * uy;
+      A[3][2] = 2.0 * w, A[3][3] = 2.0 * uz;
+      A[4][0] = 2.0 * ux, A[5][1] = 2.0 * uy, A[6][2] = 2.0 * uz;
+      A[7][0] = uy, A[7][1] = ux;
+      A[8][0] = uz, A[8][2] = ux;
+      A[9][1] = uz, A[9][2] = uy;
+      double g[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int jj = 0; jj < kMomDim; jj++)
+        if (jj == j) g[0] = A[jj][0], g[1] = A[jj][1], g[2] = A[jj][2], g[3] = A[jj][3];
+      const double W = x[0], X = x[1], Y = x[2], Zq = x[3];
+      const double z0 = g[0] * (-X) + g[1] * W + g[2] * (-Zq) + g[3] * Y;
+      const double z1 = g[0] * (-Y) + g[1] * Zq + g[2] * W + g[3] * (-X);
+      const double z2 = g[0] * (-Zq) + g[1] * (-Y) + g[2] * X + g[3] * W;
+      val = a == 0 ? z0 : (a == 1 ? z1 : (a == 2 ? z2 : ((j == 10 + (a - 3)) ? 1.0 : 0.0)));
+    }
+    s_Z[j][a] = val;
+  }
+  __syncthreads();
+  if (threadIdx.x < kMomDim * 7) {
+    const int i = threadIdx.x / 7, a = threadIdx.x % 7;
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < kMomDim; j++) t += mom[i * kMomStride + j] * s_Z[j][a];
+    s_T[i][a] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < kAccSize) {
+    const int o = threadIdx.x;
+    double v = s_part[0][o];
+    for (int wv = 1; wv < kSweepThreads / 64; wv++) v += s_part[wv][o];
+    // plane terms: o < 21: (Z^T T)[a][b]; 21..26: Z^T (M phi); 27: phi . (M phi) / 2; 28: non-finite flag
+    if (o < 21) {
+      int a = 0, rem = o;
+      while (rem >= 6 - a) rem -= 6 - a, a++;
+      const int b = a + rem;
+      double sum = 0.0;
+#pragma unroll
+      for (int i = 0; i < kMomDim; i++) sum += s_Z[i][a] * s_T[i][b];
+      v += sum;
+    } else if (o < 27) {
+      const int a = o - 21;
+      double sum = 0.0;
+#pragma unroll
+      for (int i = 0; i < kMomDim; i++) sum += s_Z[i][a] * s_T[i][6];
+      v += sum;
+    } else {
+      double cost = 0.0;
+#pragma unroll
+      for (int i = 0; i < kMomDim; i++) cost += s_Z[i][6] * s_T[i][6];
+      if (o == 27) v += 0.5 * cost;
+      else if (!(cost - cost == 0.0)) v += 1.0;
+    }
+    B.partials[(pair * B.blocks_per_pair) * kAccSize + o] = v;
+  }
+}
+
 __global__ __launch_bounds__(64) void lm_step_kernel(RegBatch B) {  // one wavefront: the 6x6 solve may use the whole register file
   const size_t pair = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pair >= B.n_pairs) return;
@@ -673,17 +808,148 @@ __global__ __launch_bounds__(64) void lm_step_kernel(RegBatch B) {  // one wavef
   const uint32_t n_se_raw = B.n_src_edge[pair * B.in_pitch], n_sp_raw = B.n_src_planar[pair * B.in_pitch];
   const uint32_t n_se = n_se_raw < B.edge_stride ? n_se_raw : (uint32_t)B.edge_stride;
   const uint32_t n_sp = n_sp_raw < B.planar_stride ? n_sp_raw : (uint32_t)B.planar_stride;
-  const uint32_t used = (n_se + n_sp + kSweepChunk - 1) / kSweepChunk;  // blocks that wrote a partial
+  const uint32_t used = S.stream_planes ? (n_se + n_sp + kSweepChunk - 1) / kSweepChunk : 1u;  // blocks that wrote a partial
   double acc[kAccSize];
   for (int j = 0; j < kAccSize; j++) acc[j] = 0.0;
   for (uint32_t b = 0; b < used && b < B.blocks_per_pair; b++) {
     const double* __restrict__ p = B.partials + (pair * B.blocks_per_pair + b) * kAccSize;
     for (int j = 0; j < kAccSize; j++) acc[j] += p[j];
   }
+  const double* __restrict__ mom = B.moments + pair * (size_t)(kMomSize + 2);
   LmState lm = S.lm;
   lm_consume(lm, acc, S.first_sweep != 0);
   S.lm = lm;
   S.first_sweep = 0;
+  // the next sweep: may the moments stand in for the plane records at the new candidate?
+  S.stream_planes = (!S.use_moments || (lm.active && !plane_moments_valid_at(mom[kMomSize], mom[kMomSize + 1], lm.xeval))) ? 1u : 0u;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Moment pass (reg_math.h: "Plane residuals through moments"): M = sum c c^T over the plane records of a
+ * pair is a Gram matrix — the one dense contraction on this path — and is accumulated with
+ * v_mfma_f64_16x16x4f64: A = B^T = 4 coefficient vectors (13 numbers, padded to 16) per instruction.
+ * Every lane loads one record (coalesced), computes its 13 coefficients, stages them in its wavefront's
+ * LDS tile, and the wavefront then issues 16 MFMAs over the 64 staged records (lane l feeds c[l % 16]
+ * of record 4 t + l / 16 as both operands). Same chunking as sweep_kernel; every wavefront writes its
+ * 16x16 tile, moment_finish_kernel adds the tiles of a pair in a fixed order.
+ * ---------------------------------------------------------------------------------------------- */
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+constexpr int kMomLdsRow = 65;  // 64 records + 1: the 16 rows of a tile start in different banks
+
+__global__ __launch_bounds__(kSweepThreads) void moment_kernel(RegBatch B) {
+  __shared__ double s_c[kSweepThreads / 64][kMomStride][kMomLdsRow];
+  const size_t pair = blockIdx.x / B.mom_blocks_per_pair;
+  const uint32_t blk = blockIdx.x % B.mom_blocks_per_pair;
+  const PairState& S = B.state[pair];
+  if (!S.active || !S.lm.active || !S.use_moments) return;  // uniform per workgroup
+  const uint32_t n_sp_raw = B.n_src_planar[pair * B.in_pitch];
+  const uint32_t n_sp = n_sp_raw < B.planar_stride ? n_sp_raw : (uint32_t)B.planar_stride;
+  const uint32_t base = blk * kSweepChunk;
+  if (base >= n_sp) return;  // uniform per workgroup
+  if (blk == 0 && threadIdx.x == 0 && B.sweep_slots) atomicAdd(&B.sweep_slots[4], (unsigned long long)n_sp);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t pfield = B.n_pairs * B.planar_stride;
+  const double* __restrict__ Pl = B.assoc.plane + pair * B.planar_stride;
+  double(*tile)[kMomLdsRow] = s_c[wave];
+#pragma unroll
+  for (int j = kMomDim; j < kMomStride; j++) tile[j][lane] = 0.0;  // padding rows
+  v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+  double s0max = 0.0, v2max = 0.0;
+  // the wavefront's own list of flagged slots (a quarter of the workgroup's chunk of capacity), in slot order
+  uint32_t* __restrict__ flist = B.flagged_list + ((pair * B.mom_blocks_per_pair + blk) * 4 + wave) * (size_t)(kSweepChunk / 4);
+  uint32_t n_flagged = 0;  // uniform in the wavefront
+  struct Rec {
+    double f[7];
+    bool in;
+  };
+  auto load_rec = [&](uint32_t q) {
+    Rec R;
+    R.in = q < n_sp;
+#pragma unroll
+    for (int f = 0; f < 7; f++) R.f[f] = R.in ? Pl[f * pfield + q] : 0.0;
+    return R;
+  };
+  constexpr int kIters = kSweepChunk / kSweepThreads;  // sub-chunks of 256 records (64 per wavefront)
+  Rec cur = load_rec(base + threadIdx.x);
+#pragma unroll 1
+  for (int it = 0; it < kIters; it++) {
+    const Rec nxt = (it + 1 < kIters) ? load_rec(base + (it + 1) * kSweepThreads + threadIdx.x) : Rec{{0, 0, 0, 0, 0, 0, 0}, false};
+    double c[kMomDim];
+#pragma unroll
+    for (int j = 0; j < kMomDim; j++) c[j] = 0.0;
+    bool flagged = false;
+    if (cur.in && cur.f[0] == cur.f[0]) {  // NaN in field 0 marks an invalid slot
+      const Vec3 v = v3(cur.f[0], cur.f[1], cur.f[2]);
+      plane_coeffs(v, v3(cur.f[3], cur.f[4], cur.f[5]), cur.f[6], c);
+      const double a0 = fabs(c[0]), vv = vdot(v, v);
+      // a record that starts far from its plane may reach the Huber threshold: it stays out of the moments and
+      // is listed (in slot order) for the sweeps, which evaluate the listed records one by one
+      flagged = !(a0 <= kMomInlier);
+      if (flagged) {
+#pragma unroll
+        for (int j = 0; j < kMomDim; j++) c[j] = 0.0;
+      } else {
+        s0max = a0 > s0max ? a0 : s0max;
+        v2max = vv > v2max ? vv : v2max;
+      }
+    }
+    // (the tile and the list are private to the wavefront: no workgroup barrier in this loop, only the ordering
+    // of this wavefront's own LDS traffic)
+    const unsigned long long fm = __ballot(flagged);
+    if (flagged) flist[n_flagged + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = base + it * kSweepThreads + threadIdx.x;
+    n_flagged += (uint32_t)__popcll(fm);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < kMomDim; j++) tile[j][lane] = c[j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int t = 0; t < 16; t++) {  // (four independent accumulator chains were measured: slower)
+      const double a = tile[lane & 15][4 * t + (lane >> 4)];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+    }
+    cur = nxt;
+  }
+  // the wavefront's tile: lane l holds D[l / 16 + 4 r][l % 16], r = 0..3 (measured: tools/probes/mfma_f64_layout.hip)
+  double* __restrict__ out = B.mom_partials + ((pair * B.mom_blocks_per_pair + blk) * 4 + wave) * (size_t)(kMomSize + 2);
+#pragma unroll
+  for (int r = 0; r < 4; r++) out[((lane >> 4) + 4 * r) * kMomStride + (lane & 15)] = acc[r];
+  s0max = wave_max(s0max), v2max = wave_max(v2max);
+  if (lane == 0) out[kMomSize] = s0max, out[kMomSize + 1] = v2max;
+  if (lane == 0) B.flagged_count[(pair * B.mom_blocks_per_pair + blk) * 4 + wave] = n_flagged;
+}
+
+// one workgroup per pair: fixed-order sum of the wavefront tiles, the two maxima, and whether the first
+// sweep (x = identity) may use the moments
+__global__ __launch_bounds__(kMomSize) void moment_finish_kernel(RegBatch B) {
+  const size_t pair = blockIdx.x;
+  PairState& S = B.state[pair];
+  if (!S.active || !S.lm.active) return;  // uniform
+  if (!S.use_moments) {
+    if (threadIdx.x == 0) S.stream_planes = 1;
+    return;
+  }
+  const uint32_t n_sp_raw = B.n_src_planar[pair * B.in_pitch];
+  const uint32_t n_sp = n_sp_raw < B.planar_stride ? n_sp_raw : (uint32_t)B.planar_stride;
+  uint32_t used = (n_sp + kSweepChunk - 1) / kSweepChunk;
+  used = used < B.mom_blocks_per_pair ? used : B.mom_blocks_per_pair;
+  const double* __restrict__ part = B.mom_partials + pair * B.mom_blocks_per_pair * 4 * (size_t)(kMomSize + 2);
+  double* __restrict__ mom = B.moments + pair * (size_t)(kMomSize + 2);
+  double v = 0.0;
+  for (uint32_t t = 0; t < used * 4; t++) v += part[t * (size_t)(kMomSize + 2) + threadIdx.x];
+  mom[threadIdx.x] = v;
+  if (threadIdx.x == 0) {
+    double s0max = 0.0, v2max = 0.0;
+    for (uint32_t t = 0; t < used * 4; t++) {
+      s0max = fmax(s0max, part[t * (size_t)(kMomSize + 2) + kMomSize]);
+      v2max = fmax(v2max, part[t * (size_t)(kMomSize + 2) + kMomSize + 1]);
+    }
+    mom[kMomSize] = s0max, mom[kMomSize + 1] = v2max;
+    const double ident[7] = {0, 0, 0, 1, 0, 0, 0};
+    S.stream_planes = plane_moments_valid_at(s0max, v2max, ident) ? 0u : 1u;
+  }
 }
 
 __global__ void outer_update_kernel(RegBatch B, RegConfig C, uint32_t iteration) {
@@ -701,6 +967,9 @@ __global__ void outer_update_kernel(RegBatch B, RegConfig C, uint32_t iteration)
   double est[7];
   for (int i = 0; i < 7; i++) est[i] = S.est[i];
   const bool converged = outer_update(est, upd, C.rot_thresh, C.pos_thresh);  // registration-inl.h:65-73
+  // From the second ICF iteration on the updates are small and the moment pass pays off (the first one usually
+  // moves the pose by more than the validity bound of the moments allows: its sweeps stream the records).
+  S.use_moments = 1u;
   for (int i = 0; i < 7; i++) S.est[i] = est[i];
   if (converged) {
     S.termination = LOAMX_CONVERGED;
@@ -826,6 +1095,13 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
 void launch_sweep(const RegBatch& B, hipStream_t s) {
   if (B.n_pairs == 0 || B.blocks_per_pair == 0) return;
   hipLaunchKernelGGL(sweep_kernel, dim3((unsigned)(B.n_pairs * B.blocks_per_pair)), dim3(kSweepThreads), 0, s, B);
+  hipLaunchKernelGGL(sweep_light_kernel, dim3((unsigned)B.n_pairs), dim3(kSweepThreads), 0, s, B);
+}
+
+void launch_moments(const RegBatch& B, hipStream_t s) {
+  if (B.n_pairs == 0 || B.mom_blocks_per_pair == 0) return;
+  hipLaunchKernelGGL(moment_kernel, dim3((unsigned)(B.n_pairs * B.mom_blocks_per_pair)), dim3(kSweepThreads), 0, s, B);
+  hipLaunchKernelGGL(moment_finish_kernel, dim3((unsigned)B.n_pairs), dim3(kMomSize), 0, s, B);
 }
 
 void launch_lm_step(const RegBatch& B, hipStream_t s) {

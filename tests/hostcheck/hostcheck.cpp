@@ -253,6 +253,7 @@ static void build_grid(const double* pts, uint32_t n, double max_dist, HostGrid&
 extern "C++" {
 // Runs the keyed fast path (what the kernels run) and the exact collector on the same query and
 // requires identical answers; returns the answer. g_knn_fallbacks counts undecided keyed queries.
+static uint64_t g_plane_streams = 0;
 static uint64_t g_knn_fallbacks = 0, g_knn_mismatch = 0, g_knn_queued = 0;
 template <int KM>
 static int knn_both(const HostGrid& G, Vec3 q, int k, double max_dist, uint32_t pos[KM]) {
@@ -282,6 +283,7 @@ static int knn_both(const HostGrid& G, Vec3 q, int k, double max_dist, uint32_t 
   return kept;
 }
 }
+uint64_t hostcheck_plane_streams(void) { return g_plane_streams; }
 uint64_t hostcheck_knn_fallbacks(void) { return g_knn_fallbacks; }
 uint64_t hostcheck_knn_queued(void) { return g_knn_queued; }
 uint64_t hostcheck_knn_mismatches(void) { return g_knn_mismatch; }
@@ -425,6 +427,28 @@ static void sweep(const std::vector<Slot>& edges, const std::vector<Slot>& plane
     if (s.valid) residual_accumulate(true, s.p, s.prim, x, acc);
 }
 
+// plane terms of the normal equations at x: per-record accumulation vs the moment matrix
+void hostcheck_plane_moments(const double* v, const double* n, const double* d, uint64_t count, const double x[7],
+                             double direct[kAccSize], double moments[kAccSize], double bound_inputs[2]) {
+  for (int j = 0; j < kAccSize; j++) direct[j] = moments[j] = 0.0;
+  double M[kMomSize];
+  for (int j = 0; j < kMomSize; j++) M[j] = 0.0;
+  double s0max = 0.0, v2max = 0.0;
+  for (uint64_t i = 0; i < count; i++) {
+    const Vec3 vv = v3(v[3 * i], v[3 * i + 1], v[3 * i + 2]), nn = v3(n[3 * i], n[3 * i + 1], n[3 * i + 2]);
+    const double prim[6] = {nn.x, nn.y, nn.z, d[i], 0, 0};
+    residual_accumulate(true, vv, prim, x, direct);
+    double c[kMomDim];
+    plane_coeffs(vv, nn, d[i], c);
+    for (int a = 0; a < kMomDim; a++)
+      for (int b = 0; b < kMomDim; b++) M[a * kMomStride + b] += c[a] * c[b];
+    s0max = std::max(s0max, fabs(c[0]));
+    v2max = std::max(v2max, vdot(vv, vv));
+  }
+  plane_eval_from_moments(M, x, moments);
+  bound_inputs[0] = s0max, bound_inputs[1] = plane_moments_valid_at(s0max, v2max, x) ? 1.0 : 0.0;
+}
+
 int hostcheck_register(const double* src_edge, uint64_t n_se, const double* src_planar, uint64_t n_sp,
                        const double* tgt_edge, uint64_t n_te, const double* tgt_planar, uint64_t n_tp,
                        const double init[7], const loamx_reg_params* prm, loamx_reg_result* out,
@@ -445,10 +469,33 @@ int hostcheck_register(const double* src_edge, uint64_t n_se, const double* src_
     }
     LmState st;
     lm_init(st);
+    // as the kernels: from the second ICF iteration on the plane records enter through their moment matrix
+    // while that is provably exact (Huber inactive at the candidate), else they are streamed like the edges
+    const bool use_moments = it >= 1;
+    std::vector<double> M(kMomSize + 2, 0.0);
+    std::vector<Slot> flagged;  // plane records that start far from their plane: evaluated one by one
+    if (use_moments) {
+      for (const Slot& sl : planes) {
+        if (!sl.valid) continue;
+        double c[kMomDim];
+        plane_coeffs(sl.p, v3(sl.prim[0], sl.prim[1], sl.prim[2]), sl.prim[3], c);
+        if (!(fabs(c[0]) <= kMomInlier)) {
+          flagged.push_back(sl);
+          continue;
+        }
+        for (int a = 0; a < kMomDim; a++)
+          for (int b = 0; b < kMomDim; b++) M[a * kMomStride + b] += c[a] * c[b];
+        M[kMomSize] = std::max(M[kMomSize], fabs(c[0]));
+        M[kMomSize + 1] = std::max(M[kMomSize + 1], vdot(sl.p, sl.p));
+      }
+    }
     double acc[kAccSize];
     bool first = true;
     while (st.active) {
-      sweep(edges, planes, st.xeval, acc);
+      const bool stream = !use_moments || !plane_moments_valid_at(M[kMomSize], M[kMomSize + 1], st.xeval);
+      sweep(edges, stream ? planes : flagged, st.xeval, acc);
+      if (!stream) plane_eval_from_moments(M.data(), st.xeval, acc);
+      else g_plane_streams++;
       lm_consume(st, acc, first);
       first = false;
     }

@@ -84,7 +84,7 @@ def main():
                "| kernel | dispatches | fetch MB (corrected) | write MB | traffic MB | algorithmic MB | traffic / algorithmic |",
                "|---|---|---|---|---|---|---|"]
         out = {}
-        alias = {"curvature_valid_kernel": "curvature_valid_kernel", "sweep_kernel": "sweep_kernel",
+        alias = {"curvature_valid_kernel": "curvature_valid_kernel", "sweep_kernel": "sweep_kernel", "moment_kernel": "moment_kernel",
                  "select_kernel<4>": "select_kernel", "select_mis_kernel<2, 4>": "select_kernel"}
         alias.update({k: "select_kernel" for k in pmc if k.startswith("select_mis_kernel")})
         for k in sorted(pmc):
