@@ -182,3 +182,11 @@ def knn_fallbacks():
 def knn_mismatches():
     """queries on which the keyed path and the exact collector disagreed (must stay 0)"""
     return int(lib().hostcheck_knn_mismatches())
+
+
+def plane_moments(v, n, d, x):
+    """(direct, via_moments, max|s0|, valid): plane terms of the normal equations at ambient point x"""
+    v, n, d, x = (np.ascontiguousarray(a, dtype=np.float64) for a in (v, n, d, x))
+    a, b, bi = np.zeros(30), np.zeros(30), np.zeros(2)
+    lib().hostcheck_plane_moments(_dp(v), _dp(n), _dp(d), C.c_uint64(len(d)), _dp(x), _dp(a), _dp(b), _dp(bi))
+    return a[:29], b[:29], bi[0], bool(bi[1])

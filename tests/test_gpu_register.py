@@ -98,6 +98,33 @@ def test_dense_target_and_far_origin(oracle):
         assert rot < SE3_TOL and trans < (SE3_TOL if shift[0] == 0 else 1e-4), (rot, trans)
 
 
+def test_outliers_and_large_updates_keep_huber_exact(oracle):
+    """The plane residuals go through their moment matrix only while every residual is provably inside the
+    quadratic zone of the Huber loss. Sources with gross outliers (1-2 m off their planes) and a poor initial
+    guess (large first updates) must give the oracle's iterations and poses: listed records, streamed sweeps."""
+    H, W = 32, 512
+    A = capi.synth_scan_host(21, 0, 0, H, W, 0.01)
+    B = capi.synth_scan_host(21, 0, 1, H, W, 0.01)
+    ea, pa = oracle.extract_features(A, H, W, 1.0, 120.0)
+    eb, pb = oracle.extract_features(B, H, W, 1.0, 120.0)
+    rng = np.random.default_rng(9)
+    src_p = B[pb].copy()
+    bad = rng.choice(len(src_p), size=len(src_p) // 25, replace=False)
+    src_p[bad] += rng.normal(size=(len(bad), 3)) * 0.9  # 4 % gross outliers
+    for init in (np.array([0, 0, 0, 1, 0, 0, 0.0]), np.array([0.02, -0.015, 0.03, 0.99924, 0.25, -0.2, 0.1])):
+        init = init.copy()
+        init[:4] /= np.linalg.norm(init[:4])
+        po, to, io, info = oracle.register_features(B[eb], src_p, A[ea], A[pa], init, want_info=True)
+        pg, tg, ig, det = ctx().register_features(B[eb], src_p, A[ea], A[pa], init, want_detail=True)
+        assert (tg, ig) == (to, io)
+        for a, b in zip(info, det["iterations"]):
+            assert (a.n_edge_assoc, a.n_plane_assoc) == (b["n_edge"], b["n_plane"])
+            r, t = pose_diff(oracle, np.array(list(a.update)), b["estimate_update"])
+            assert r < SE3_TOL and t < SE3_TOL
+        rot, trans = pose_diff(oracle, po, pg)
+        assert rot < SE3_TOL and trans < SE3_TOL, (rot, trans)
+
+
 def test_scan_pair_batch_matches_oracle(oracle):
     """loamx_register_scan_pairs_dev: extract x2 + register for a batch, pair by pair vs the oracle."""
     H, W, n_pairs, seed = 32, 512, 6, 13

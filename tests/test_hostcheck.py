@@ -177,6 +177,29 @@ def test_fp32_preselection_is_exact_in_adverse_cases(oracle):
     assert Hc.knn_mismatches() == before
 
 
+def test_plane_moments_equal_per_record_sums():
+    """Sum over plane records of cost / J^T f / J^T J == the same from the 13x13 moment matrix, wherever the
+    validity bound holds (Huber inactive); where the bound fails the kernels stream the records instead."""
+    rng = np.random.default_rng(0)
+    N = 5000
+    v = rng.uniform(-10, 10, size=(N, 3))
+    n = rng.normal(size=(N, 3))
+    n /= np.linalg.norm(n, axis=1)[:, None]
+    d = (v * n).sum(1) + rng.normal(size=N) * 0.02
+    for x in ([0, 0, 0, 1, 0, 0, 0], [0.003, -0.002, 0.004, 0.99999, 0.02, -0.01, 0.03], [1e-4, 2e-4, -1e-4, 1.0, 1e-3, 2e-3, -1e-3]):
+        direct, mom, s0max, valid = Hc.plane_moments(v, n, d, x)
+        assert valid and s0max < 0.2
+        scale = np.abs(direct).max()
+        assert np.abs(direct - mom).max() <= 1e-11 * scale
+    # a large step: some |s| exceed the Huber threshold, the sums differ, and the bound says so
+    direct, mom, _, valid = Hc.plane_moments(v, n, d, [0.02, 0.01, -0.03, 0.9993, 0.1, 0.2, -0.1])
+    assert not valid and not np.allclose(direct, mom, rtol=1e-6)
+    # records far from their plane from the start
+    d2 = d.copy()
+    d2[::50] += 2.0
+    assert not Hc.plane_moments(v, n, d2, [0, 0, 0, 1, 0, 0, 0])[3]
+
+
 @pytest.mark.parametrize("case", K.REGISTRATION_CASES, ids=lambda c: c["name"])
 def test_registration_math_on_reference_scenes(oracle, case):
     tgt_e, tgt_p = K.registration_scene()
