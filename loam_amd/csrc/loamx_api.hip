@@ -389,6 +389,7 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
       }
       {
         TimedScope t(ctx, LOAMX_K_LM, 0.0);
+        launch_sweep_light(B, s);
         launch_lm_step(B, s);
       }
     }

@@ -135,6 +135,7 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
                       hipEvent_t ev_mid, hipEvent_t ev_join);  // aux == nullptr: everything on s
 void launch_lm_begin(const RegBatch& B, const RegConfig& C, uint32_t iteration, hipStream_t s);
 void launch_sweep(const RegBatch& B, hipStream_t s);
+void launch_sweep_light(const RegBatch& B, hipStream_t s);
 void launch_lm_step(const RegBatch& B, hipStream_t s);
 void launch_moments(const RegBatch& B, hipStream_t s);
 void launch_outer_update(const RegBatch& B, const RegConfig& C, uint32_t iteration, hipStream_t s);

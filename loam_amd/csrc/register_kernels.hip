@@ -1095,6 +1095,11 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
 void launch_sweep(const RegBatch& B, hipStream_t s) {
   if (B.n_pairs == 0 || B.blocks_per_pair == 0) return;
   hipLaunchKernelGGL(sweep_kernel, dim3((unsigned)(B.n_pairs * B.blocks_per_pair)), dim3(kSweepThreads), 0, s, B);
+}
+
+// the same evaluation for the pairs that are on moments (timed with the LM kernels: it streams next to nothing)
+void launch_sweep_light(const RegBatch& B, hipStream_t s) {
+  if (B.n_pairs == 0 || B.blocks_per_pair == 0) return;
   hipLaunchKernelGGL(sweep_light_kernel, dim3((unsigned)B.n_pairs), dim3(kSweepThreads), 0, s, B);
 }
 
