@@ -28,15 +28,30 @@ constexpr int kCurvThreads = LOAMX_CURV_THREADS;
 constexpr int kHaloMax = kMaxNeighborPoints + 1;
 constexpr int kLocalMax = kTile + 2 * kHaloMax;
 
+constexpr int kCodeWords = (kLocalMax + 63) / 64 + 1;  // 64 local columns per word, one more for the window reads
+
+// any flag set among the `len` (<= 64) local columns from `start` on?
+__device__ __forceinline__ bool code_window(const unsigned long long* bits, int start, int len) {
+  const int w = start >> 6, b = start & 63;
+  const unsigned long long lo = bits[w], hi = bits[w + 1];
+  const unsigned long long v = (lo >> b) | (b ? hi << (64 - b) : 0ull);
+  const unsigned long long m = len >= 64 ? ~0ull : (1ull << len) - 1ull;
+  return (v & m) != 0ull;
+}
+
+// NP: neighbor_points when it is known at compile time (the curvature sum unrolls), 0 = read it from P.
+// The invalidation codes of a tile are kept as four flag words per 64 local columns (wavefront ballots):
+// valid_from_codes (extract_math.h) then is three window tests on them instead of a loop over the neighbours.
+template <int NP>
 __global__ __launch_bounds__(kCurvThreads) void curvature_valid_kernel(const double* __restrict__ xyz, ExtractParams P,
                                                               double* __restrict__ curv_out,
                                                               uint8_t* __restrict__ mask_out) {
   __shared__ double s_xyz[kLocalMax * 3];
   __shared__ double s_r[kLocalMax];
-  __shared__ uint8_t s_code[kLocalMax];
+  __shared__ unsigned long long s_bits[4][kCodeWords];  // range / occlusion 1 / occlusion 2 / parallel
   const int tid = threadIdx.x;
   const size_t line = blockIdx.x;  // scan * H + line
-  const int W = (int)P.W, np = (int)P.np;
+  const int W = (int)P.W, np = NP ? NP : (int)P.np;
   const int halo = np + 1;
   const int t0 = (int)blockIdx.y * kTile;
   const int base = t0 - halo;  // column of local index 0
@@ -56,10 +71,14 @@ __global__ __launch_bounds__(kCurvThreads) void curvature_valid_kernel(const dou
   {
     const int clo = t0 - np > 0 ? t0 - np : 0;
     const int chi = t0 + kTile + np < W ? t0 + kTile + np : W;
-    for (int c = clo + tid; c < chi; c += kCurvThreads) {
-      const int li = c - base;
-      s_code[li] = is_line_end((uint32_t)c, P.W, P.np) ? (uint8_t)kCodeNone
-                                                         : point_code(s_r[li - 1], s_r[li], s_r[li + 1], P);
+    for (int l0 = 0; l0 < kCodeWords * 64; l0 += kCurvThreads) {  // whole wavefronts: the ballots below need every lane
+      const int li = l0 + tid, c = base + li;
+      uint8_t code = kCodeNone;
+      if (c >= clo && c < chi && !is_line_end((uint32_t)c, P.W, (uint32_t)np)) code = point_code(s_r[li - 1], s_r[li], s_r[li + 1], P);
+      const unsigned long long b1 = __ballot(code == kCodeRange), b2 = __ballot(code == kCodeOcc1);
+      const unsigned long long b3 = __ballot(code == kCodeOcc2), b4 = __ballot(code == kCodeParallel);
+      const int w = li >> 6;
+      if ((tid & 63) == 0 && w < kCodeWords) s_bits[0][w] = b1, s_bits[1][w] = b2, s_bits[2][w] = b3, s_bits[3][w] = b4;
     }
   }
   __syncthreads();
@@ -67,8 +86,11 @@ __global__ __launch_bounds__(kCurvThreads) void curvature_valid_kernel(const dou
     const int c = t0 + k;
     if (c >= W) break;
     const int li = c - base;
-    const double cv = is_line_end((uint32_t)c, P.W, P.np) ? -1.0 : curvature_at(s_xyz, li, P.np);
-    const bool ok = valid_from_codes(s_code, li, (uint32_t)c, P.W, P.np);
+    const bool end = is_line_end((uint32_t)c, P.W, (uint32_t)np);
+    const double cv = end ? -1.0 : curvature_at(s_xyz, li, (uint32_t)np);
+    // code 1 at j clears j-np..j+np, code 2 j+1..j+np, code 3 j-(np-1)..j, code 4 j (extract_math.h)
+    const bool ok = !end && !code_window(s_bits[0], li - np, 2 * np + 1) && !code_window(s_bits[1], li - np, np) &&
+                    !code_window(s_bits[2], li, np) && !code_window(s_bits[3], li, 1);
     curv_out[line * (size_t)W + c] = cv;
     mask_out[line * (size_t)W + c] = ok ? 1 : 0;
   }
@@ -396,12 +418,19 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
   return incl - v;
 }
 
+// kCompactSplit workgroups share a scan: every one of them runs the (cheap) prefix over the sector counts and
+// copies an interleaved share of the items; a thread keeps kCompactBatch items in flight (stage index ->
+// gathered point -> store is a chain of dependent HBM accesses, so the copy is bound by latency, not bytes).
+constexpr uint32_t kCompactSplit = 4, kCompactBatch = 4;
+
 __device__ __forceinline__ void compact_one(const double* __restrict__ scan_xyz, uint32_t groups, uint32_t cap,
                                             const uint32_t* __restrict__ stage, const uint32_t* __restrict__ cnt,
                                             uint32_t* __restrict__ out_idx, double* __restrict__ out_xyz,
-                                            uint32_t* __restrict__ out_n, uint32_t* s_scan, uint32_t* s_off,
+                                            uint32_t* __restrict__ out_n, uint32_t split, uint32_t* s_scan, uint32_t* s_off,
                                             uint32_t* s_cnt) {
   const int tid = threadIdx.x;
+  // it / cap by multiplication: exact while it * cap < 2^32 (it < 256 * cap)
+  const uint32_t magic = (cap > 1 && cap < 4096) ? 0xFFFFFFFFu / cap + 1u : 0u;
   uint32_t carry = 0;
   for (uint32_t g0 = 0; g0 < groups; g0 += 256) {
     const uint32_t g = g0 + tid;
@@ -413,23 +442,42 @@ __device__ __forceinline__ void compact_one(const double* __restrict__ scan_xyz,
     __syncthreads();
     const uint32_t chunk_groups = groups - g0 < 256 ? groups - g0 : 256;
     const uint32_t items = chunk_groups * cap;
-    for (uint32_t it = tid; it < items; it += 256) {
-      const uint32_t gl = it / cap, j = it - gl * cap;
-      if (j < s_cnt[gl]) {
-        const uint32_t idx = stage[(size_t)(g0 + gl) * cap + j];
-        const uint32_t o = s_off[gl] + j;
-        out_idx[o] = idx;
-        if (out_xyz) {
-          out_xyz[3 * (size_t)o] = scan_xyz[3 * (size_t)idx];
-          out_xyz[3 * (size_t)o + 1] = scan_xyz[3 * (size_t)idx + 1];
-          out_xyz[3 * (size_t)o + 2] = scan_xyz[3 * (size_t)idx + 2];
+    constexpr uint32_t step = 256 * kCompactSplit;
+    for (uint32_t it0 = split * 256 + tid; it0 < items; it0 += step * kCompactBatch) {
+      uint32_t idx[kCompactBatch], o[kCompactBatch];
+      bool ok[kCompactBatch];
+#pragma unroll
+      for (uint32_t b = 0; b < kCompactBatch; b++) {
+        const uint32_t it = it0 + b * step;
+        ok[b] = it < items;
+        const uint32_t gl = ok[b] ? (magic ? __umulhi(it, magic) : it / cap) : 0u, j = it - gl * cap;
+        ok[b] = ok[b] && j < s_cnt[gl];
+        o[b] = s_off[gl] + j;
+        idx[b] = ok[b] ? stage[(size_t)(g0 + gl) * cap + j] : 0u;
+      }
+      if (out_xyz) {
+        double v[kCompactBatch][3];
+#pragma unroll
+        for (uint32_t b = 0; b < kCompactBatch; b++) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) v[b][k] = ok[b] ? scan_xyz[3 * (size_t)idx[b] + k] : 0.0;
+        }
+#pragma unroll
+        for (uint32_t b = 0; b < kCompactBatch; b++) {
+          if (ok[b]) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) out_xyz[3 * (size_t)o[b] + k] = v[b][k];
+          }
         }
       }
+#pragma unroll
+      for (uint32_t b = 0; b < kCompactBatch; b++)
+        if (ok[b]) out_idx[o[b]] = idx[b];
     }
     carry += total;
     __syncthreads();
   }
-  if (tid == 0) *out_n = carry;
+  if (tid == 0 && split == 0) *out_n = carry;
 }
 
 __global__ __launch_bounds__(256) void compact_kernel(const double* __restrict__ xyz, ExtractParams P, ExtractStage st,
@@ -439,15 +487,16 @@ __global__ __launch_bounds__(256) void compact_kernel(const double* __restrict__
                                                       uint32_t* __restrict__ n_planar, double* __restrict__ planar_xyz,
                                                       size_t planar_stride) {
   __shared__ uint32_t s_scan[256], s_off[256], s_cnt[256];
-  const size_t scan = blockIdx.x;
+  const size_t scan = blockIdx.x / kCompactSplit;
+  const uint32_t split = blockIdx.x % kCompactSplit;
   const uint32_t groups = P.H * P.S;
   const double* scan_xyz = xyz + scan * (size_t)P.H * P.W * 3;
   compact_one(scan_xyz, groups, P.cap_edge, st.edge_stage + scan * (size_t)groups * P.cap_edge,
               st.edge_cnt + scan * (size_t)groups, edge_idx + scan * edge_stride,
-              edge_xyz ? edge_xyz + scan * edge_stride * 3 : nullptr, n_edge + scan, s_scan, s_off, s_cnt);
+              edge_xyz ? edge_xyz + scan * edge_stride * 3 : nullptr, n_edge + scan, split, s_scan, s_off, s_cnt);
   compact_one(scan_xyz, groups, P.cap_planar, st.planar_stage + scan * (size_t)groups * P.cap_planar,
               st.planar_cnt + scan * (size_t)groups, planar_idx + scan * planar_stride,
-              planar_xyz ? planar_xyz + scan * planar_stride * 3 : nullptr, n_planar + scan, s_scan, s_off, s_cnt);
+              planar_xyz ? planar_xyz + scan * planar_stride * 3 : nullptr, n_planar + scan, split, s_scan, s_off, s_cnt);
 }
 
 }  // namespace
@@ -457,7 +506,10 @@ void launch_curvature_valid(const double* d_xyz, size_t n_scans, const ExtractPa
   const size_t n_lines = n_scans * P.H;
   if (n_lines == 0 || P.W == 0) return;
   const dim3 grid((unsigned)n_lines, (P.W + kTile - 1) / kTile);
-  hipLaunchKernelGGL(curvature_valid_kernel, grid, dim3(kCurvThreads), 0, s, d_xyz, P, d_curv, d_mask);
+  if (P.np == 3)  // the reference's default neighbor_points (features.h:40)
+    hipLaunchKernelGGL(curvature_valid_kernel<3>, grid, dim3(kCurvThreads), 0, s, d_xyz, P, d_curv, d_mask);
+  else
+    hipLaunchKernelGGL(curvature_valid_kernel<0>, grid, dim3(kCurvThreads), 0, s, d_xyz, P, d_curv, d_mask);
 }
 
 
@@ -507,7 +559,7 @@ void launch_compact(const double* d_xyz, size_t n_scans, const ExtractParams& P,
                     uint32_t* d_planar_idx, uint32_t* d_n_planar, double* d_planar_xyz, size_t planar_stride,
                     hipStream_t s) {
   if (n_scans == 0) return;
-  hipLaunchKernelGGL(compact_kernel, dim3((unsigned)n_scans), dim3(256), 0, s, d_xyz, P, st, d_edge_idx, d_n_edge,
+  hipLaunchKernelGGL(compact_kernel, dim3((unsigned)(n_scans * kCompactSplit)), dim3(256), 0, s, d_xyz, P, st, d_edge_idx, d_n_edge,
                      d_edge_xyz, edge_stride, d_planar_idx, d_n_planar, d_planar_xyz, planar_stride);
 }
 
