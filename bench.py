@@ -65,6 +65,9 @@ def main():
     ap.add_argument("--pairs", type=int, default=1024, help="scan pairs per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="pairs timed on the CPU oracle (default: 8 per thread, <= 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--input", choices=["f64", "f32"], default="f64",
+                    help="scalar type of the resident scans: f64 (the headline workload) or f32 (SURVEY 8f4: sensor data as "
+                         "floats, widened on load; arithmetic stays FP64)")
     ap.add_argument("--seed", type=int, default=SEED, help="seed of the synthetic scan pairs (default: the benchmark's)")
     args = ap.parse_args()
 
@@ -109,9 +112,13 @@ def main():
     from loam_amd import distributed as D
     ctx.synth_scan_pairs_dev(args.seed, first_pair, P, H, W, SIGMA, xyz.data_ptr())
     torch.cuda.synchronize()
+    f32 = args.input == "f32"
+    if f32:  # the same scans rounded to float: half the resident bytes
+        xyz = xyz.float()
+        torch.cuda.synchronize()
 
     def step():
-        ctx.register_scan_pairs_dev(xyz.data_ptr(), P, lidar, fe, reg, results.data_ptr())
+        ctx.register_scan_pairs_dev(xyz.data_ptr(), P, lidar, fe, reg, results.data_ptr(), f32=f32)
         if world > 1:  # the only collective: gather of 64-byte result records (RCCL over xGMI)
             D.gather_results(results if backend == "nccl" else results.cpu(), world * P)
 
@@ -188,7 +195,7 @@ def main():
             "config": {"workload": f"batch of {P} independent 64x1024 scan pairs per GPU (BASELINE configs[2]/[3]); "
                                    "step = extractFeatures x2 + registerFeatures per pair, inputs resident in HBM",
                        "pairs_per_gpu": P, "scan": "64x1024", "sharding": "by pair id, no data-path collective",
-                       "seed": args.seed, "range_noise_sigma_m": SIGMA},
+                       "seed": args.seed, "range_noise_sigma_m": SIGMA, "input_scalar": args.input},
             "roofline": roofline,
             "kernels": kern,
             "results": {"converged": int((res["termination"] == 0).sum()), "max_iter": int((res["termination"] == 1).sum()),
@@ -200,7 +207,7 @@ def main():
         if n_gpus == 1 and not args.no_cpu_baseline:
             threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))  # the GPU box's CPU share for one GPU is 16 cores
             n_sample = args.cpu_sample if args.cpu_sample > 0 else min(256, 16 * threads, P)  # ~13 s of CPU work at 51 ms/pair
-            scans = xyz[: n_sample * 2 * N * 3].cpu().numpy().reshape(n_sample * 2, N, 3)
+            scans = xyz[: n_sample * 2 * N * 3].double().cpu().numpy().reshape(n_sample * 2, N, 3)
             import oracle_lib as O
             cpu_out, dt = cpu_baseline(scans, n_sample, threads)
             out["cpu_baseline"] = {"value": round(n_sample / dt, 3), "unit": "pairs/s", "cores": threads, "kind": "port",

@@ -11,6 +11,8 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../loamx.h"
@@ -130,6 +132,31 @@ std::vector<double> pack(const std::vector<PointType, Alloc>& pts) {
     xyz[3 * i + 1] = Accessor<PointType>::y(pts[i]);
     xyz[3 * i + 2] = Accessor<PointType>::z(pts[i]);
   }
+  return xyz;
+}
+
+/// Scans of points whose x, y, z are float fields read through FieldAccessor (PCL points) go to the device as
+/// floats: FieldAccessor widens every coordinate to double before any arithmetic (reference common.h:55-60), and
+/// the FP32-input entry points of the C ABI do the same on load, so the results are identical at half the bytes.
+template <template <typename> class A, template <typename> class B>
+struct same_accessor : std::false_type {};
+template <template <typename> class A>
+struct same_accessor<A, A> : std::true_type {};
+template <typename P, typename = void>
+struct has_float_fields : std::false_type {};
+template <typename P>
+struct has_float_fields<P, std::void_t<decltype(std::declval<P>().x), decltype(std::declval<P>().y), decltype(std::declval<P>().z)>>
+    : std::integral_constant<bool, std::is_same<std::decay_t<decltype(std::declval<P>().x)>, float>::value &&
+                                       std::is_same<std::decay_t<decltype(std::declval<P>().y)>, float>::value &&
+                                       std::is_same<std::decay_t<decltype(std::declval<P>().z)>, float>::value> {};
+template <template <typename> class Accessor, typename PointType>
+constexpr bool float_scan_v = same_accessor<Accessor, FieldAccessor>::value && has_float_fields<PointType>::value;
+
+/// Packs a container of float-field points into row-major N x 3 floats
+template <typename PointType, typename Alloc>
+std::vector<float> packFloat(const std::vector<PointType, Alloc>& pts) {
+  std::vector<float> xyz(pts.size() * 3);
+  for (size_t i = 0; i < pts.size(); i++) xyz[3 * i] = pts[i].x, xyz[3 * i + 1] = pts[i].y, xyz[3 * i + 2] = pts[i].z;
   return xyz;
 }
 

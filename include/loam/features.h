@@ -59,11 +59,17 @@ LoamFeatures<PointType, Alloc> extractFeatures(const std::vector<PointType, Allo
   loamx_ctx* ctx = gpu::defaultContext();
   const loamx_lidar_params lp = gpu::toC(lidar_params);
   const loamx_fe_params fp = gpu::toC(params);
-  const std::vector<double> xyz = gpu::pack<Accessor>(input_scan);
   std::vector<uint32_t> edge(loamx_edge_capacity(&lp, &fp) + 1), planar(loamx_planar_capacity(&lp, &fp) + 1);
   size_t n_edge = 0, n_planar = 0;
-  gpu::check(ctx, loamx_extract_features(ctx, xyz.data(), input_scan.size(), &lp, &fp, edge.data(), edge.size(), &n_edge,
-                                         planar.data(), planar.size(), &n_planar));
+  if constexpr (gpu::float_scan_v<Accessor, PointType>) {  // PCL-style float points: FP32-input path
+    const std::vector<float> xyz = gpu::packFloat(input_scan);
+    gpu::check(ctx, loamx_extract_features_f32(ctx, xyz.data(), input_scan.size(), &lp, &fp, edge.data(), edge.size(), &n_edge,
+                                               planar.data(), planar.size(), &n_planar));
+  } else {
+    const std::vector<double> xyz = gpu::pack<Accessor>(input_scan);
+    gpu::check(ctx, loamx_extract_features(ctx, xyz.data(), input_scan.size(), &lp, &fp, edge.data(), edge.size(), &n_edge,
+                                           planar.data(), planar.size(), &n_planar));
+  }
   out.edge_points.reserve(n_edge);
   out.planar_points.reserve(n_planar);
   for (size_t i = 0; i < n_edge; i++) out.edge_points.push_back(input_scan.at(edge[i]));  // copies, like the reference
@@ -82,9 +88,14 @@ std::vector<PointCurvature> computeCurvature(const std::vector<PointType, Alloc<
   loamx_ctx* ctx = gpu::defaultContext();
   const loamx_lidar_params lp = gpu::toC(lidar_params);
   const loamx_fe_params fp = gpu::toC(params);
-  const std::vector<double> xyz = gpu::pack<Accessor>(input_scan);
   std::vector<double> curv(input_scan.size());
-  gpu::check(ctx, loamx_compute_curvature(ctx, xyz.data(), input_scan.size(), &lp, &fp, curv.data()));
+  if constexpr (gpu::float_scan_v<Accessor, PointType>) {
+    const std::vector<float> xyz = gpu::packFloat(input_scan);
+    gpu::check(ctx, loamx_compute_curvature_f32(ctx, xyz.data(), input_scan.size(), &lp, &fp, curv.data()));
+  } else {
+    const std::vector<double> xyz = gpu::pack<Accessor>(input_scan);
+    gpu::check(ctx, loamx_compute_curvature(ctx, xyz.data(), input_scan.size(), &lp, &fp, curv.data()));
+  }
   out.reserve(curv.size());
   for (size_t i = 0; i < curv.size(); i++) out.emplace_back(i, curv[i]);
   return out;
@@ -101,9 +112,14 @@ std::vector<bool> computeValidPoints(const std::vector<PointType, Alloc<PointTyp
   loamx_ctx* ctx = gpu::defaultContext();
   const loamx_lidar_params lp = gpu::toC(lidar_params);
   const loamx_fe_params fp = gpu::toC(params);
-  const std::vector<double> xyz = gpu::pack<Accessor>(input_scan);
   std::vector<uint8_t> mask(input_scan.size());
-  gpu::check(ctx, loamx_compute_valid_points(ctx, xyz.data(), input_scan.size(), &lp, &fp, mask.data()));
+  if constexpr (gpu::float_scan_v<Accessor, PointType>) {
+    const std::vector<float> xyz = gpu::packFloat(input_scan);
+    gpu::check(ctx, loamx_compute_valid_points_f32(ctx, xyz.data(), input_scan.size(), &lp, &fp, mask.data()));
+  } else {
+    const std::vector<double> xyz = gpu::pack<Accessor>(input_scan);
+    gpu::check(ctx, loamx_compute_valid_points(ctx, xyz.data(), input_scan.size(), &lp, &fp, mask.data()));
+  }
   out.assign(mask.begin(), mask.end());
   return out;
 }

@@ -135,6 +135,16 @@ int loamx_compute_valid_points(loamx_ctx* ctx, const double* xyz, size_t n_point
 int loamx_extract_features(loamx_ctx* ctx, const double* xyz, size_t n_points, const loamx_lidar_params* lidar,
                            const loamx_fe_params* fe, uint32_t* edge_idx, size_t edge_cap, size_t* n_edge,
                            uint32_t* planar_idx, size_t planar_cap, size_t* n_planar);
+/* FP32-input twins: xyz as n_points x 3 floats, e.g. PCL points. The reference's FieldAccessor
+ * (common.h:55-60) widens every coordinate to double before any arithmetic; the kernels do the same on load,
+ * so the results are those of the FP64 entry points on the widened values, bit for bit, at half the input bytes. */
+int loamx_compute_curvature_f32(loamx_ctx* ctx, const float* xyz, size_t n_points, const loamx_lidar_params* lidar,
+                                const loamx_fe_params* fe, double* curvature_out);
+int loamx_compute_valid_points_f32(loamx_ctx* ctx, const float* xyz, size_t n_points,
+                                   const loamx_lidar_params* lidar, const loamx_fe_params* fe, uint8_t* mask_out);
+int loamx_extract_features_f32(loamx_ctx* ctx, const float* xyz, size_t n_points, const loamx_lidar_params* lidar,
+                               const loamx_fe_params* fe, uint32_t* edge_idx, size_t edge_cap, size_t* n_edge,
+                               uint32_t* planar_idx, size_t planar_cap, size_t* n_planar);
 /* loam::registerFeatures (registration.h:128-131, registration-inl.h:11-78). detail may be NULL. */
 int loamx_register_features(loamx_ctx* ctx, const double* src_edge, size_t n_src_edge, const double* src_planar,
                             size_t n_src_planar, const double* tgt_edge, size_t n_tgt_edge,
@@ -172,6 +182,12 @@ int loamx_extract_features_batch_dev(loamx_ctx* ctx, const double* d_xyz, size_t
                                      uint32_t* d_edge_idx, uint32_t* d_n_edge, double* d_edge_xyz,
                                      uint32_t* d_planar_idx, uint32_t* d_n_planar, double* d_planar_xyz);
 
+/* the same over float scans (d_xyz: n_scans x N x 3 floats); the point copies are FP64 (widened) */
+int loamx_extract_features_batch_dev_f32(loamx_ctx* ctx, const float* d_xyz, size_t n_scans,
+                                         const loamx_lidar_params* lidar, const loamx_fe_params* fe,
+                                         uint32_t* d_edge_idx, uint32_t* d_n_edge, double* d_edge_xyz,
+                                         uint32_t* d_planar_idx, uint32_t* d_n_planar, double* d_planar_xyz);
+
 /* registerFeatures over n_pairs independent pairs. Feature set f of pair p: points at
  * d_*[p * stride * 3], count d_n_*[p]. d_init: n_pairs x 7 doubles or NULL (identity). */
 int loamx_register_features_batch_dev(loamx_ctx* ctx, size_t n_pairs, const double* d_src_edge,
@@ -188,6 +204,11 @@ int loamx_register_features_batch_dev(loamx_ctx* ctx, size_t n_pairs, const doub
 int loamx_register_scan_pairs_dev(loamx_ctx* ctx, const double* d_xyz, size_t n_pairs,
                                   const loamx_lidar_params* lidar, const loamx_fe_params* fe,
                                   const loamx_reg_params* reg, loamx_reg_result* d_results);
+
+/* the same over float scans */
+int loamx_register_scan_pairs_dev_f32(loamx_ctx* ctx, const float* d_xyz, size_t n_pairs,
+                                      const loamx_lidar_params* lidar, const loamx_fe_params* fe,
+                                      const loamx_reg_params* reg, loamx_reg_result* d_results);
 
 /* ---- per-kernel timing (hipEvents on the context stream), for bench.py's roofline object ------- */
 enum {

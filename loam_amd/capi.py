@@ -81,6 +81,8 @@ EXPORTS = [
     "loamx_ctx_reset_kernel_stats", "loamx_ctx_get_kernel_stats", "loamx_kernel_name", "loamx_synth_pair_pose",
     "loamx_synth_scan_host", "loamx_synth_scan_pairs_dev", "loamx_dev_alloc", "loamx_dev_free",
     "loamx_copy_to_device", "loamx_copy_to_host",
+    "loamx_compute_curvature_f32", "loamx_compute_valid_points_f32", "loamx_extract_features_f32",
+    "loamx_extract_features_batch_dev_f32", "loamx_register_scan_pairs_dev_f32",
 ]
 
 _lib = None
@@ -114,6 +116,14 @@ def load(build_if_missing=True):
     lib.loamx_extract_features.argtypes = [vp, dp, C.c_size_t, C.POINTER(LidarParams),
                                            C.POINTER(FeatureExtractionParams), u32p, C.c_size_t,
                                            C.POINTER(C.c_size_t), u32p, C.c_size_t, C.POINTER(C.c_size_t)]
+    fp = C.POINTER(C.c_float)
+    lib.loamx_compute_curvature_f32.argtypes = [vp, fp, C.c_size_t, C.POINTER(LidarParams),
+                                                C.POINTER(FeatureExtractionParams), dp]
+    lib.loamx_compute_valid_points_f32.argtypes = [vp, fp, C.c_size_t, C.POINTER(LidarParams),
+                                                   C.POINTER(FeatureExtractionParams), C.POINTER(C.c_uint8)]
+    lib.loamx_extract_features_f32.argtypes = [vp, fp, C.c_size_t, C.POINTER(LidarParams),
+                                               C.POINTER(FeatureExtractionParams), u32p, C.c_size_t,
+                                               C.POINTER(C.c_size_t), u32p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.loamx_register_features.argtypes = [vp, dp, C.c_size_t, dp, C.c_size_t, dp, C.c_size_t, dp, C.c_size_t, dp,
                                             C.POINTER(RegistrationParams), C.POINTER(RegResult),
                                             C.POINTER(RegDetail)]
@@ -128,11 +138,13 @@ def load(build_if_missing=True):
     lib.loamx_planar_capacity.argtypes = [C.POINTER(LidarParams), C.POINTER(FeatureExtractionParams)]
     lib.loamx_extract_features_batch_dev.argtypes = [vp, vp, C.c_size_t, C.POINTER(LidarParams),
                                                      C.POINTER(FeatureExtractionParams), vp, vp, vp, vp, vp, vp]
+    lib.loamx_extract_features_batch_dev_f32.argtypes = lib.loamx_extract_features_batch_dev.argtypes
     lib.loamx_register_features_batch_dev.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t,
                                                       C.c_size_t, vp, C.POINTER(RegistrationParams), vp]
     lib.loamx_register_scan_pairs_dev.argtypes = [vp, vp, C.c_size_t, C.POINTER(LidarParams),
                                                   C.POINTER(FeatureExtractionParams), C.POINTER(RegistrationParams),
                                                   vp]
+    lib.loamx_register_scan_pairs_dev_f32.argtypes = lib.loamx_register_scan_pairs_dev.argtypes
     lib.loamx_ctx_enable_kernel_timing.argtypes = [vp, C.c_int]
     lib.loamx_ctx_reset_kernel_stats.argtypes = [vp]
     lib.loamx_ctx_get_kernel_stats.argtypes = [vp, C.POINTER(KernelStat)]
@@ -163,6 +175,16 @@ def _dp(a):
 def _pts(a):
     a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1, 3))
     return a
+
+
+def _scan(a):
+    """A scan as an (N,3) array: float32 input stays float32 (FP32-input entry points), anything else is float64."""
+    a = np.asarray(a)
+    return np.ascontiguousarray(a.reshape(-1, 3)) if a.dtype == np.float32 else _pts(a)
+
+
+def _xyzp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float if a.dtype == np.float32 else C.c_double))
 
 
 def synth_pair_pose(seed, pair_id):
@@ -244,32 +266,33 @@ class Context:
     # ---- host entry points -------------------------------------------------------------------------
     def compute_curvature(self, xyz, lidar, fe=None):
         fe = fe or FeatureExtractionParams()
-        xyz = _pts(xyz)
+        xyz = _scan(xyz)
         out = np.empty(len(xyz))
-        self._check(self.lib.loamx_compute_curvature(self.h, _dp(xyz), len(xyz), C.byref(lidar), C.byref(fe), _dp(out)))
+        fn = self.lib.loamx_compute_curvature_f32 if xyz.dtype == np.float32 else self.lib.loamx_compute_curvature
+        self._check(fn(self.h, _xyzp(xyz), len(xyz), C.byref(lidar), C.byref(fe), _dp(out)))
         return out
 
     def compute_valid_points(self, xyz, lidar, fe=None):
         fe = fe or FeatureExtractionParams()
-        xyz = _pts(xyz)
+        xyz = _scan(xyz)
         out = np.empty(len(xyz), dtype=np.uint8)
-        self._check(self.lib.loamx_compute_valid_points(self.h, _dp(xyz), len(xyz), C.byref(lidar), C.byref(fe),
-                                                        out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        fn = self.lib.loamx_compute_valid_points_f32 if xyz.dtype == np.float32 else self.lib.loamx_compute_valid_points
+        self._check(fn(self.h, _xyzp(xyz), len(xyz), C.byref(lidar), C.byref(fe), out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out.astype(bool)
 
     def extract_features(self, xyz, lidar, fe=None):
-        """Returns (edge_idx, planar_idx) in the reference's output order."""
+        """Returns (edge_idx, planar_idx) in the reference's output order. A float32 array takes the FP32-input path."""
         fe = fe or FeatureExtractionParams()
-        xyz = _pts(xyz)
+        xyz = _scan(xyz)
         ecap = max(1, self.lib.loamx_edge_capacity(C.byref(lidar), C.byref(fe)))
         pcap = max(1, self.lib.loamx_planar_capacity(C.byref(lidar), C.byref(fe)))
         e = np.empty(ecap, dtype=np.uint32)
         p = np.empty(pcap, dtype=np.uint32)
         ne, npl = C.c_size_t(0), C.c_size_t(0)
         u32p = C.POINTER(C.c_uint32)
-        self._check(self.lib.loamx_extract_features(self.h, _dp(xyz), len(xyz), C.byref(lidar), C.byref(fe),
-                                                    e.ctypes.data_as(u32p), ecap, C.byref(ne),
-                                                    p.ctypes.data_as(u32p), pcap, C.byref(npl)))
+        fn = self.lib.loamx_extract_features_f32 if xyz.dtype == np.float32 else self.lib.loamx_extract_features
+        self._check(fn(self.h, _xyzp(xyz), len(xyz), C.byref(lidar), C.byref(fe), e.ctypes.data_as(u32p), ecap, C.byref(ne),
+                       p.ctypes.data_as(u32p), pcap, C.byref(npl)))
         return e[:ne.value].copy(), p[:npl.value].copy()
 
     def register_features(self, src_edge, src_planar, tgt_edge, tgt_planar, init_pose=None, reg=None,
@@ -333,10 +356,10 @@ class Context:
         return self.lib.loamx_planar_capacity(C.byref(lidar), C.byref(fe))
 
     def extract_features_batch_dev(self, d_xyz, n_scans, lidar, fe, d_edge_idx, d_n_edge, d_edge_xyz, d_planar_idx,
-                                   d_n_planar, d_planar_xyz):
-        self._check(self.lib.loamx_extract_features_batch_dev(self.h, d_xyz, n_scans, C.byref(lidar), C.byref(fe),
-                                                              d_edge_idx, d_n_edge, d_edge_xyz, d_planar_idx,
-                                                              d_n_planar, d_planar_xyz))
+                                   d_n_planar, d_planar_xyz, f32=False):
+        fn = self.lib.loamx_extract_features_batch_dev_f32 if f32 else self.lib.loamx_extract_features_batch_dev
+        self._check(fn(self.h, d_xyz, n_scans, C.byref(lidar), C.byref(fe), d_edge_idx, d_n_edge, d_edge_xyz, d_planar_idx,
+                       d_n_planar, d_planar_xyz))
 
     def register_features_batch_dev(self, n_pairs, d_src_edge, d_n_src_edge, d_src_planar, d_n_src_planar,
                                     d_tgt_edge, d_n_tgt_edge, d_tgt_planar, d_n_tgt_planar, edge_stride,
@@ -345,9 +368,9 @@ class Context:
             self.h, n_pairs, d_src_edge, d_n_src_edge, d_src_planar, d_n_src_planar, d_tgt_edge, d_n_tgt_edge,
             d_tgt_planar, d_n_tgt_planar, edge_stride, planar_stride, d_init, C.byref(reg), d_results))
 
-    def register_scan_pairs_dev(self, d_xyz, n_pairs, lidar, fe, reg, d_results):
-        self._check(self.lib.loamx_register_scan_pairs_dev(self.h, d_xyz, n_pairs, C.byref(lidar), C.byref(fe),
-                                                           C.byref(reg), d_results))
+    def register_scan_pairs_dev(self, d_xyz, n_pairs, lidar, fe, reg, d_results, f32=False):
+        fn = self.lib.loamx_register_scan_pairs_dev_f32 if f32 else self.lib.loamx_register_scan_pairs_dev
+        self._check(fn(self.h, d_xyz, n_pairs, C.byref(lidar), C.byref(fe), C.byref(reg), d_results))
 
     def synth_scan_pairs_dev(self, seed, first_pair, n_pairs, scan_lines, points_per_line, sigma, d_xyz):
         self._check(self.lib.loamx_synth_scan_pairs_dev(self.h, seed, first_pair, n_pairs, scan_lines,

@@ -42,8 +42,10 @@ __device__ __forceinline__ bool code_window(const unsigned long long* bits, int 
 // NP: neighbor_points when it is known at compile time (the curvature sum unrolls), 0 = read it from P.
 // The invalidation codes of a tile are kept as four flag words per 64 local columns (wavefront ballots):
 // valid_from_codes (extract_math.h) then is three window tests on them instead of a loop over the neighbours.
-template <int NP>
-__global__ __launch_bounds__(kCurvThreads) void curvature_valid_kernel(const double* __restrict__ xyz, ExtractParams P,
+// T: scalar type of the scan in HBM (double, or float for the FP32-input path: widened on load, which is
+// what the reference's Accessor does for PCL points, so every later bit is the same as for FP64 input).
+template <int NP, typename T>
+__global__ __launch_bounds__(kCurvThreads) void curvature_valid_kernel(const T* __restrict__ xyz, ExtractParams P,
                                                               double* __restrict__ curv_out,
                                                               uint8_t* __restrict__ mask_out) {
   __shared__ double s_xyz[kLocalMax * 3];
@@ -57,11 +59,11 @@ __global__ __launch_bounds__(kCurvThreads) void curvature_valid_kernel(const dou
   const int base = t0 - halo;  // column of local index 0
   const int lo = t0 - halo > 0 ? t0 - halo : 0;
   const int hi = t0 + kTile + halo < W ? t0 + kTile + halo : W;
-  const double* __restrict__ g = xyz + line * (size_t)W * 3;
+  const T* __restrict__ g = xyz + line * (size_t)W * 3;
 
   // coalesced copy of the tile (+halo) of ring-ordered points into LDS
   const int nd = (hi - lo) * 3;
-  for (int k = tid; k < nd; k += kCurvThreads) s_xyz[(lo - base) * 3 + k] = g[(size_t)lo * 3 + k];
+  for (int k = tid; k < nd; k += kCurvThreads) s_xyz[(lo - base) * 3 + k] = (double)g[(size_t)lo * 3 + k];
   __syncthreads();
   for (int c = lo + tid; c < hi; c += kCurvThreads) {
     const int li = c - base;
@@ -423,7 +425,8 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
 // gathered point -> store is a chain of dependent HBM accesses, so the copy is bound by latency, not bytes).
 constexpr uint32_t kCompactSplit = 4, kCompactBatch = 4;
 
-__device__ __forceinline__ void compact_one(const double* __restrict__ scan_xyz, uint32_t groups, uint32_t cap,
+template <typename T>
+__device__ __forceinline__ void compact_one(const T* __restrict__ scan_xyz, uint32_t groups, uint32_t cap,
                                             const uint32_t* __restrict__ stage, const uint32_t* __restrict__ cnt,
                                             uint32_t* __restrict__ out_idx, double* __restrict__ out_xyz,
                                             uint32_t* __restrict__ out_n, uint32_t split, uint32_t* s_scan, uint32_t* s_off,
@@ -460,7 +463,7 @@ __device__ __forceinline__ void compact_one(const double* __restrict__ scan_xyz,
 #pragma unroll
         for (uint32_t b = 0; b < kCompactBatch; b++) {
 #pragma unroll
-          for (int k = 0; k < 3; k++) v[b][k] = ok[b] ? scan_xyz[3 * (size_t)idx[b] + k] : 0.0;
+          for (int k = 0; k < 3; k++) v[b][k] = ok[b] ? (double)scan_xyz[3 * (size_t)idx[b] + k] : 0.0;
         }
 #pragma unroll
         for (uint32_t b = 0; b < kCompactBatch; b++) {
@@ -480,7 +483,8 @@ __device__ __forceinline__ void compact_one(const double* __restrict__ scan_xyz,
   if (tid == 0 && split == 0) *out_n = carry;
 }
 
-__global__ __launch_bounds__(256) void compact_kernel(const double* __restrict__ xyz, ExtractParams P, ExtractStage st,
+template <typename T>
+__global__ __launch_bounds__(256) void compact_kernel(const T* __restrict__ xyz, ExtractParams P, ExtractStage st,
                                                       uint32_t* __restrict__ edge_idx, uint32_t* __restrict__ n_edge,
                                                       double* __restrict__ edge_xyz, size_t edge_stride,
                                                       uint32_t* __restrict__ planar_idx,
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(256) void compact_kernel(const double* __restrict__
   const size_t scan = blockIdx.x / kCompactSplit;
   const uint32_t split = blockIdx.x % kCompactSplit;
   const uint32_t groups = P.H * P.S;
-  const double* scan_xyz = xyz + scan * (size_t)P.H * P.W * 3;
+  const T* scan_xyz = xyz + scan * (size_t)P.H * P.W * 3;
   compact_one(scan_xyz, groups, P.cap_edge, st.edge_stage + scan * (size_t)groups * P.cap_edge,
               st.edge_cnt + scan * (size_t)groups, edge_idx + scan * edge_stride,
               edge_xyz ? edge_xyz + scan * edge_stride * 3 : nullptr, n_edge + scan, split, s_scan, s_off, s_cnt);
@@ -501,15 +505,22 @@ __global__ __launch_bounds__(256) void compact_kernel(const double* __restrict__
 
 }  // namespace
 
-void launch_curvature_valid(const double* d_xyz, size_t n_scans, const ExtractParams& P, double* d_curv,
+template <typename T>
+static void launch_curvature_valid_t(const T* d_xyz, const dim3& grid, const ExtractParams& P, double* d_curv, uint8_t* d_mask,
+                                     hipStream_t s) {
+  if (P.np == 3)  // the reference's default neighbor_points (features.h:40)
+    hipLaunchKernelGGL((curvature_valid_kernel<3, T>), grid, dim3(kCurvThreads), 0, s, d_xyz, P, d_curv, d_mask);
+  else
+    hipLaunchKernelGGL((curvature_valid_kernel<0, T>), grid, dim3(kCurvThreads), 0, s, d_xyz, P, d_curv, d_mask);
+}
+
+void launch_curvature_valid(const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, double* d_curv,
                             uint8_t* d_mask, hipStream_t s) {
   const size_t n_lines = n_scans * P.H;
   if (n_lines == 0 || P.W == 0) return;
   const dim3 grid((unsigned)n_lines, (P.W + kTile - 1) / kTile);
-  if (P.np == 3)  // the reference's default neighbor_points (features.h:40)
-    hipLaunchKernelGGL(curvature_valid_kernel<3>, grid, dim3(kCurvThreads), 0, s, d_xyz, P, d_curv, d_mask);
-  else
-    hipLaunchKernelGGL(curvature_valid_kernel<0>, grid, dim3(kCurvThreads), 0, s, d_xyz, P, d_curv, d_mask);
+  if (f32) launch_curvature_valid_t(static_cast<const float*>(d_xyz), grid, P, d_curv, d_mask, s);
+  else launch_curvature_valid_t(static_cast<const double*>(d_xyz), grid, P, d_curv, d_mask, s);
 }
 
 
@@ -554,13 +565,18 @@ void launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, 
   }
 }
 
-void launch_compact(const double* d_xyz, size_t n_scans, const ExtractParams& P, const ExtractStage& st,
+void launch_compact(const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, const ExtractStage& st,
                     uint32_t* d_edge_idx, uint32_t* d_n_edge, double* d_edge_xyz, size_t edge_stride,
                     uint32_t* d_planar_idx, uint32_t* d_n_planar, double* d_planar_xyz, size_t planar_stride,
                     hipStream_t s) {
   if (n_scans == 0) return;
-  hipLaunchKernelGGL(compact_kernel, dim3((unsigned)(n_scans * kCompactSplit)), dim3(256), 0, s, d_xyz, P, st, d_edge_idx, d_n_edge,
-                     d_edge_xyz, edge_stride, d_planar_idx, d_n_planar, d_planar_xyz, planar_stride);
+  const dim3 grid((unsigned)(n_scans * kCompactSplit));
+  if (f32)
+    hipLaunchKernelGGL(compact_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(d_xyz), P, st, d_edge_idx, d_n_edge,
+                       d_edge_xyz, edge_stride, d_planar_idx, d_n_planar, d_planar_xyz, planar_stride);
+  else
+    hipLaunchKernelGGL(compact_kernel<double>, grid, dim3(256), 0, s, static_cast<const double*>(d_xyz), P, st, d_edge_idx, d_n_edge,
+                       d_edge_xyz, edge_stride, d_planar_idx, d_n_planar, d_planar_xyz, planar_stride);
 }
 
 }  // namespace loamx

@@ -213,7 +213,8 @@ size_t edge_capacity(const ExtractParams& P) { return (size_t)P.H * P.S * P.cap_
 size_t planar_capacity(const ExtractParams& P) { return (size_t)P.H * P.S * P.cap_planar; }
 
 // extraction over device-resident scans ------------------------------------------------------------------
-int extract_dev(loamx_ctx* ctx, const double* d_xyz, size_t n_scans, const ExtractParams& P, uint32_t* d_edge_idx,
+// d_xyz: double, or float when f32 (FP32-input path)
+int extract_dev(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, uint32_t* d_edge_idx,
                 uint32_t* d_n_edge, double* d_edge_xyz, uint32_t* d_planar_idx, uint32_t* d_n_planar,
                 double* d_planar_xyz, bool only_curvature_mask) {
   const size_t N = (size_t)P.H * P.W;
@@ -230,8 +231,8 @@ int extract_dev(loamx_ctx* ctx, const double* d_xyz, size_t n_scans, const Extra
   ENSURE(ctx, WS_CURV, n_scans * N * sizeof(double));
   ENSURE(ctx, WS_MASK, n_scans * N);
   {
-    TimedScope t(ctx, LOAMX_K_CURVATURE, (double)n_scans * (double)N * 33.0);
-    launch_curvature_valid(d_xyz, n_scans, P, wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), ctx->stream);
+    TimedScope t(ctx, LOAMX_K_CURVATURE, (double)n_scans * (double)N * (f32 ? 21.0 : 33.0));
+    launch_curvature_valid(d_xyz, f32, n_scans, P, wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), ctx->stream);
   }
   CHECK_LAUNCH(ctx, "curvature_valid_kernel");
   if (only_curvature_mask) return LOAMX_OK;
@@ -249,7 +250,7 @@ int extract_dev(loamx_ctx* ctx, const double* d_xyz, size_t n_scans, const Extra
   CHECK_LAUNCH(ctx, "select_kernel");
   {
     TimedScope t(ctx, LOAMX_K_COMPACT, 0.0);
-    launch_compact(d_xyz, n_scans, P, st, d_edge_idx, d_n_edge, d_edge_xyz, edge_capacity(P), d_planar_idx,
+    launch_compact(d_xyz, f32, n_scans, P, st, d_edge_idx, d_n_edge, d_edge_xyz, edge_capacity(P), d_planar_idx,
                    d_n_planar, d_planar_xyz, planar_capacity(P), ctx->stream);
   }
   CHECK_LAUNCH(ctx, "compact_kernel");
@@ -543,7 +544,7 @@ size_t loamx_planar_capacity(const loamx_lidar_params* lidar, const loamx_fe_par
 }
 
 /* ---- host entry points ---------------------------------------------------------------------------- */
-static int host_curv_mask(loamx_ctx* ctx, const double* xyz, size_t n_points, const loamx_lidar_params* lidar,
+static int host_curv_mask(loamx_ctx* ctx, const void* xyz, bool f32, size_t n_points, const loamx_lidar_params* lidar,
                           const loamx_fe_params* fe, double* curvature_out, uint8_t* mask_out) {
   if (!ctx) return LOAMX_ERR_BAD_PARAM;
   std::lock_guard<std::mutex> lock(ctx->mu);
@@ -559,9 +560,10 @@ static int host_curv_mask(loamx_ctx* ctx, const double* xyz, size_t n_points, co
   ExtractParams P;
   int rc = make_extract_params(ctx, lidar, fe, P);
   if (rc != LOAMX_OK) return rc;
-  ENSURE(ctx, WS_XYZ, n_points * 3 * sizeof(double));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_XYZ].p, xyz, n_points * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  rc = extract_dev(ctx, wsp<double>(ctx, WS_XYZ), 1, P, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true);
+  const size_t scalar = f32 ? sizeof(float) : sizeof(double);
+  ENSURE(ctx, WS_XYZ, n_points * 3 * scalar);
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_XYZ].p, xyz, n_points * 3 * scalar, hipMemcpyHostToDevice, ctx->stream));
+  rc = extract_dev(ctx, ctx->ws[WS_XYZ].p, f32, 1, P, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true);
   if (rc != LOAMX_OK) return rc;
   if (curvature_out)
     HIP_TRY(ctx, hipMemcpyAsync(curvature_out, ctx->ws[WS_CURV].p, n_points * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -573,17 +575,27 @@ static int host_curv_mask(loamx_ctx* ctx, const double* xyz, size_t n_points, co
 
 int loamx_compute_curvature(loamx_ctx* ctx, const double* xyz, size_t n_points, const loamx_lidar_params* lidar,
                             const loamx_fe_params* fe, double* curvature_out) {
-  return host_curv_mask(ctx, xyz, n_points, lidar, fe, curvature_out, nullptr);
+  return host_curv_mask(ctx, xyz, false, n_points, lidar, fe, curvature_out, nullptr);
 }
 
 int loamx_compute_valid_points(loamx_ctx* ctx, const double* xyz, size_t n_points, const loamx_lidar_params* lidar,
                                const loamx_fe_params* fe, uint8_t* mask_out) {
-  return host_curv_mask(ctx, xyz, n_points, lidar, fe, nullptr, mask_out);
+  return host_curv_mask(ctx, xyz, false, n_points, lidar, fe, nullptr, mask_out);
 }
 
-int loamx_extract_features(loamx_ctx* ctx, const double* xyz, size_t n_points, const loamx_lidar_params* lidar,
-                           const loamx_fe_params* fe, uint32_t* edge_idx, size_t edge_cap, size_t* n_edge,
-                           uint32_t* planar_idx, size_t planar_cap, size_t* n_planar) {
+int loamx_compute_curvature_f32(loamx_ctx* ctx, const float* xyz, size_t n_points, const loamx_lidar_params* lidar,
+                                const loamx_fe_params* fe, double* curvature_out) {
+  return host_curv_mask(ctx, xyz, true, n_points, lidar, fe, curvature_out, nullptr);
+}
+
+int loamx_compute_valid_points_f32(loamx_ctx* ctx, const float* xyz, size_t n_points, const loamx_lidar_params* lidar,
+                                   const loamx_fe_params* fe, uint8_t* mask_out) {
+  return host_curv_mask(ctx, xyz, true, n_points, lidar, fe, nullptr, mask_out);
+}
+
+static int host_extract(loamx_ctx* ctx, const void* xyz, bool f32, size_t n_points, const loamx_lidar_params* lidar,
+                        const loamx_fe_params* fe, uint32_t* edge_idx, size_t edge_cap, size_t* n_edge,
+                        uint32_t* planar_idx, size_t planar_cap, size_t* n_planar) {
   if (!ctx) return LOAMX_ERR_BAD_PARAM;
   std::lock_guard<std::mutex> lock(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -600,13 +612,14 @@ int loamx_extract_features(loamx_ctx* ctx, const double* xyz, size_t n_points, c
   int rc = make_extract_params(ctx, lidar, fe, P);
   if (rc != LOAMX_OK) return rc;
   const size_t ecap = edge_capacity(P), pcap = planar_capacity(P);
-  ENSURE(ctx, WS_XYZ, n_points * 3 * sizeof(double));
+  const size_t scalar = f32 ? sizeof(float) : sizeof(double);
+  ENSURE(ctx, WS_XYZ, n_points * 3 * scalar);
   ENSURE(ctx, WS_EDGE_IDX, ecap * sizeof(uint32_t));
   ENSURE(ctx, WS_PLANAR_IDX, pcap * sizeof(uint32_t));
   ENSURE(ctx, WS_N_EDGE, sizeof(uint32_t));
   ENSURE(ctx, WS_N_PLANAR, sizeof(uint32_t));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_XYZ].p, xyz, n_points * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  rc = extract_dev(ctx, wsp<double>(ctx, WS_XYZ), 1, P, wsp<uint32_t>(ctx, WS_EDGE_IDX), wsp<uint32_t>(ctx, WS_N_EDGE), nullptr,
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_XYZ].p, xyz, n_points * 3 * scalar, hipMemcpyHostToDevice, ctx->stream));
+  rc = extract_dev(ctx, ctx->ws[WS_XYZ].p, f32, 1, P, wsp<uint32_t>(ctx, WS_EDGE_IDX), wsp<uint32_t>(ctx, WS_N_EDGE), nullptr,
                    wsp<uint32_t>(ctx, WS_PLANAR_IDX), wsp<uint32_t>(ctx, WS_N_PLANAR), nullptr, false);
   if (rc != LOAMX_OK) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_pinned[0], ctx->ws[WS_N_EDGE].p, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -618,6 +631,18 @@ int loamx_extract_features(loamx_ctx* ctx, const double* xyz, size_t n_points, c
   if (ne) HIP_TRY(ctx, hipMemcpy(edge_idx, ctx->ws[WS_EDGE_IDX].p, ne * sizeof(uint32_t), hipMemcpyDeviceToHost));
   if (npl) HIP_TRY(ctx, hipMemcpy(planar_idx, ctx->ws[WS_PLANAR_IDX].p, npl * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return LOAMX_OK;
+}
+
+int loamx_extract_features(loamx_ctx* ctx, const double* xyz, size_t n_points, const loamx_lidar_params* lidar,
+                           const loamx_fe_params* fe, uint32_t* edge_idx, size_t edge_cap, size_t* n_edge,
+                           uint32_t* planar_idx, size_t planar_cap, size_t* n_planar) {
+  return host_extract(ctx, xyz, false, n_points, lidar, fe, edge_idx, edge_cap, n_edge, planar_idx, planar_cap, n_planar);
+}
+
+int loamx_extract_features_f32(loamx_ctx* ctx, const float* xyz, size_t n_points, const loamx_lidar_params* lidar,
+                               const loamx_fe_params* fe, uint32_t* edge_idx, size_t edge_cap, size_t* n_edge,
+                               uint32_t* planar_idx, size_t planar_cap, size_t* n_planar) {
+  return host_extract(ctx, xyz, true, n_points, lidar, fe, edge_idx, edge_cap, n_edge, planar_idx, planar_cap, n_planar);
 }
 
 namespace {
@@ -807,17 +832,30 @@ int loamx_target_index_create(loamx_ctx* ctx, const double* tgt_edge, size_t n_t
 }
 
 /* ---- device-resident batch entry points ----------------------------------------------------------- */
-int loamx_extract_features_batch_dev(loamx_ctx* ctx, const double* d_xyz, size_t n_scans, const loamx_lidar_params* lidar,
-                                     const loamx_fe_params* fe, uint32_t* d_edge_idx, uint32_t* d_n_edge,
-                                     double* d_edge_xyz, uint32_t* d_planar_idx, uint32_t* d_n_planar,
-                                     double* d_planar_xyz) {
+static int extract_batch_dev(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_scans, const loamx_lidar_params* lidar,
+                             const loamx_fe_params* fe, uint32_t* d_edge_idx, uint32_t* d_n_edge, double* d_edge_xyz,
+                             uint32_t* d_planar_idx, uint32_t* d_n_planar, double* d_planar_xyz) {
   if (!ctx) return LOAMX_ERR_BAD_PARAM;
   std::lock_guard<std::mutex> lock(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   ExtractParams P;
   int rc = make_extract_params(ctx, lidar, fe, P);
   if (rc != LOAMX_OK) return rc;
-  return extract_dev(ctx, d_xyz, n_scans, P, d_edge_idx, d_n_edge, d_edge_xyz, d_planar_idx, d_n_planar, d_planar_xyz, false);
+  return extract_dev(ctx, d_xyz, f32, n_scans, P, d_edge_idx, d_n_edge, d_edge_xyz, d_planar_idx, d_n_planar, d_planar_xyz, false);
+}
+
+int loamx_extract_features_batch_dev(loamx_ctx* ctx, const double* d_xyz, size_t n_scans, const loamx_lidar_params* lidar,
+                                     const loamx_fe_params* fe, uint32_t* d_edge_idx, uint32_t* d_n_edge,
+                                     double* d_edge_xyz, uint32_t* d_planar_idx, uint32_t* d_n_planar,
+                                     double* d_planar_xyz) {
+  return extract_batch_dev(ctx, d_xyz, false, n_scans, lidar, fe, d_edge_idx, d_n_edge, d_edge_xyz, d_planar_idx, d_n_planar, d_planar_xyz);
+}
+
+int loamx_extract_features_batch_dev_f32(loamx_ctx* ctx, const float* d_xyz, size_t n_scans, const loamx_lidar_params* lidar,
+                                         const loamx_fe_params* fe, uint32_t* d_edge_idx, uint32_t* d_n_edge,
+                                         double* d_edge_xyz, uint32_t* d_planar_idx, uint32_t* d_n_planar,
+                                         double* d_planar_xyz) {
+  return extract_batch_dev(ctx, d_xyz, true, n_scans, lidar, fe, d_edge_idx, d_n_edge, d_edge_xyz, d_planar_idx, d_n_planar, d_planar_xyz);
 }
 
 int loamx_register_features_batch_dev(loamx_ctx* ctx, size_t n_pairs, const double* d_src_edge,
@@ -837,8 +875,8 @@ int loamx_register_features_batch_dev(loamx_ctx* ctx, size_t n_pairs, const doub
   return register_dev(ctx, in, C, d_results, false, nullptr, nullptr);
 }
 
-int loamx_register_scan_pairs_dev(loamx_ctx* ctx, const double* d_xyz, size_t n_pairs, const loamx_lidar_params* lidar,
-                                  const loamx_fe_params* fe, const loamx_reg_params* reg, loamx_reg_result* d_results) {
+static int register_scan_pairs(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_pairs, const loamx_lidar_params* lidar,
+                               const loamx_fe_params* fe, const loamx_reg_params* reg, loamx_reg_result* d_results) {
   if (!ctx) return LOAMX_ERR_BAD_PARAM;
   std::lock_guard<std::mutex> lock(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -856,7 +894,7 @@ int loamx_register_scan_pairs_dev(loamx_ctx* ctx, const double* d_xyz, size_t n_
   ENSURE(ctx, WS_N_PLANAR, n_scans * sizeof(uint32_t));
   ENSURE(ctx, WS_EDGE_XYZ, n_scans * ecap * 3 * sizeof(double));
   ENSURE(ctx, WS_PLANAR_XYZ, n_scans * pcap * 3 * sizeof(double));
-  rc = extract_dev(ctx, d_xyz, n_scans, P, wsp<uint32_t>(ctx, WS_EDGE_IDX), wsp<uint32_t>(ctx, WS_N_EDGE),
+  rc = extract_dev(ctx, d_xyz, f32, n_scans, P, wsp<uint32_t>(ctx, WS_EDGE_IDX), wsp<uint32_t>(ctx, WS_N_EDGE),
                    wsp<double>(ctx, WS_EDGE_XYZ), wsp<uint32_t>(ctx, WS_PLANAR_IDX), wsp<uint32_t>(ctx, WS_N_PLANAR),
                    wsp<double>(ctx, WS_PLANAR_XYZ), false);
   if (rc != LOAMX_OK) return rc;
@@ -869,6 +907,16 @@ int loamx_register_scan_pairs_dev(loamx_ctx* ctx, const double* d_xyz, size_t n_
   in.n_tgt_planar = wsp<uint32_t>(ctx, WS_N_PLANAR), in.n_src_planar = in.n_tgt_planar + 1;
   in.init = nullptr;
   return register_dev(ctx, in, C, d_results, false, nullptr, nullptr);
+}
+
+int loamx_register_scan_pairs_dev(loamx_ctx* ctx, const double* d_xyz, size_t n_pairs, const loamx_lidar_params* lidar,
+                                  const loamx_fe_params* fe, const loamx_reg_params* reg, loamx_reg_result* d_results) {
+  return register_scan_pairs(ctx, d_xyz, false, n_pairs, lidar, fe, reg, d_results);
+}
+
+int loamx_register_scan_pairs_dev_f32(loamx_ctx* ctx, const float* d_xyz, size_t n_pairs, const loamx_lidar_params* lidar,
+                                      const loamx_fe_params* fe, const loamx_reg_params* reg, loamx_reg_result* d_results) {
+  return register_scan_pairs(ctx, d_xyz, true, n_pairs, lidar, fe, reg, d_results);
 }
 
 /* ---- kernel timing ------------------------------------------------------------------------------------ */

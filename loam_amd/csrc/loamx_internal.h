@@ -21,12 +21,13 @@ struct ExtractStage {
   uint32_t* planar_cnt;    // [n_scans][H][S]
 };
 
-void launch_curvature_valid(const double* d_xyz, size_t n_scans, const ExtractParams& P, double* d_curv,
+// d_xyz: n_scans x H x W x 3 scalars, double or (f32) float
+void launch_curvature_valid(const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, double* d_curv,
                             uint8_t* d_mask, hipStream_t s);
 void launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, const ExtractParams& P,
                    const ExtractStage& st, hipStream_t s);
 // edge_stride / planar_stride: entries per scan in the output arrays
-void launch_compact(const double* d_xyz, size_t n_scans, const ExtractParams& P, const ExtractStage& st,
+void launch_compact(const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, const ExtractStage& st,
                     uint32_t* d_edge_idx, uint32_t* d_n_edge, double* d_edge_xyz, size_t edge_stride,
                     uint32_t* d_planar_idx, uint32_t* d_n_planar, double* d_planar_xyz, size_t planar_stride,
                     hipStream_t s);

@@ -14,6 +14,9 @@
 
 namespace py = pybind11;
 using Arr = py::array_t<double, py::array::c_style | py::array::forcecast>;
+// float32 scans (PCL-style sensors data) are taken as they are (no cast: only a C-contiguous float32 array
+// matches) and go through the FP32-input entry points of the C ABI
+using ArrF = py::array_t<float, py::array::c_style>;
 
 namespace {
 
@@ -23,18 +26,43 @@ struct PyFeatures {
   PyFeatures() : edge_points(std::vector<py::ssize_t>{0, 3}), planar_points(std::vector<py::ssize_t>{0, 3}) {}
 };
 
-size_t check_points(const Arr& a, const char* what) {
+template <typename A>
+size_t check_points(const A& a, const char* what) {
   if (a.ndim() == 1 && a.shape(0) == 0) return 0;
   if (a.ndim() != 2 || a.shape(1) != 3) throw std::runtime_error(std::string(what) + ": expected an (N, 3) array of points");
   return (size_t)a.shape(0);
 }
 
-Arr gather_points(const Arr& scan, const std::vector<uint32_t>& idx, size_t n) {
+template <typename A>
+Arr gather_points(const A& scan, const std::vector<uint32_t>& idx, size_t n) {
   Arr out(std::vector<py::ssize_t>{(py::ssize_t)n, 3});
-  const double* src = scan.data();
+  const auto* src = scan.data();
   double* dst = out.mutable_data();
-  for (size_t i = 0; i < n; i++) std::memcpy(dst + 3 * i, src + 3 * (size_t)idx[i], 3 * sizeof(double));
+  for (size_t i = 0; i < n; i++)
+    for (int k = 0; k < 3; k++) dst[3 * i + k] = (double)src[3 * (size_t)idx[i] + k];
   return out;
+}
+
+// one body for float64 and float32 scans: the C ABI entry points differ only in the scalar type
+inline int c_extract(loamx_ctx* c, const double* x, size_t n, const loamx_lidar_params* l, const loamx_fe_params* f, uint32_t* e,
+                     size_t ec, size_t* ne, uint32_t* p, size_t pc, size_t* np) {
+  return loamx_extract_features(c, x, n, l, f, e, ec, ne, p, pc, np);
+}
+inline int c_extract(loamx_ctx* c, const float* x, size_t n, const loamx_lidar_params* l, const loamx_fe_params* f, uint32_t* e,
+                     size_t ec, size_t* ne, uint32_t* p, size_t pc, size_t* np) {
+  return loamx_extract_features_f32(c, x, n, l, f, e, ec, ne, p, pc, np);
+}
+inline int c_curvature(loamx_ctx* c, const double* x, size_t n, const loamx_lidar_params* l, const loamx_fe_params* f, double* o) {
+  return loamx_compute_curvature(c, x, n, l, f, o);
+}
+inline int c_curvature(loamx_ctx* c, const float* x, size_t n, const loamx_lidar_params* l, const loamx_fe_params* f, double* o) {
+  return loamx_compute_curvature_f32(c, x, n, l, f, o);
+}
+inline int c_valid(loamx_ctx* c, const double* x, size_t n, const loamx_lidar_params* l, const loamx_fe_params* f, uint8_t* o) {
+  return loamx_compute_valid_points(c, x, n, l, f, o);
+}
+inline int c_valid(loamx_ctx* c, const float* x, size_t n, const loamx_lidar_params* l, const loamx_fe_params* f, uint8_t* o) {
+  return loamx_compute_valid_points_f32(c, x, n, l, f, o);
 }
 
 loam::Vector3d vec_from(const Arr& a) {
@@ -54,6 +82,53 @@ void scan_size_check(size_t n, const loam::LidarParams& lp) {
         << " x " << lp.points_per_line << ")";
     throw std::runtime_error(msg.str());
   }
+}
+
+template <typename A>
+PyFeatures extract_features(const A& scan, const loam::LidarParams& lp, const loam::FeatureExtractionParams& params) {
+  const size_t n = check_points(scan, "input_scan");
+  scan_size_check(n, lp);
+  PyFeatures out;
+  if (n == 0) return out;
+  loamx_ctx* ctx = loam::gpu::defaultContext();
+  const loamx_lidar_params clp = loam::gpu::toC(lp);
+  const loamx_fe_params cfp = loam::gpu::toC(params);
+  std::vector<uint32_t> e(loamx_edge_capacity(&clp, &cfp) + 1), p(loamx_planar_capacity(&clp, &cfp) + 1);
+  size_t ne = 0, np = 0;
+  {
+    py::gil_scoped_release release;
+    loam::gpu::check(ctx, c_extract(ctx, scan.data(), n, &clp, &cfp, e.data(), e.size(), &ne, p.data(), p.size(), &np));
+  }
+  out.edge_points = gather_points(scan, e, ne);
+  out.planar_points = gather_points(scan, p, np);
+  return out;
+}
+
+template <typename A>
+Arr compute_curvature(const A& scan, const loam::LidarParams& lp, const loam::FeatureExtractionParams& params) {
+  const size_t n = check_points(scan, "input_scan");
+  scan_size_check(n, lp);
+  Arr out((py::ssize_t)n);
+  if (n == 0) return out;
+  loamx_ctx* ctx = loam::gpu::defaultContext();
+  const loamx_lidar_params clp = loam::gpu::toC(lp);
+  const loamx_fe_params cfp = loam::gpu::toC(params);
+  loam::gpu::check(ctx, c_curvature(ctx, scan.data(), n, &clp, &cfp, out.mutable_data()));
+  return out;
+}
+
+template <typename A>
+py::array_t<bool> compute_valid_points(const A& scan, const loam::LidarParams& lp, const loam::FeatureExtractionParams& params) {
+  const size_t n = check_points(scan, "input_scan");
+  scan_size_check(n, lp);
+  py::array_t<bool> out((py::ssize_t)n);
+  if (n == 0) return out;
+  loamx_ctx* ctx = loam::gpu::defaultContext();
+  const loamx_lidar_params clp = loam::gpu::toC(lp);
+  const loamx_fe_params cfp = loam::gpu::toC(params);
+  static_assert(sizeof(bool) == 1, "bool must be one byte");
+  loam::gpu::check(ctx, c_valid(ctx, scan.data(), n, &clp, &cfp, reinterpret_cast<uint8_t*>(out.mutable_data())));
+  return out;
 }
 
 }  // namespace
@@ -112,60 +187,18 @@ PYBIND11_MODULE(loam_python, m) {
       .def_readwrite("edge_points", &PyFeatures::edge_points)
       .def_readwrite("planar_points", &PyFeatures::planar_points);
 
-  m.def(
-      "extractFeatures",
-      [](const Arr& scan, const loam::LidarParams& lp, const loam::FeatureExtractionParams& params) {
-        const size_t n = check_points(scan, "input_scan");
-        scan_size_check(n, lp);
-        PyFeatures out;
-        if (n == 0) return out;
-        loamx_ctx* ctx = loam::gpu::defaultContext();
-        const loamx_lidar_params clp = loam::gpu::toC(lp);
-        const loamx_fe_params cfp = loam::gpu::toC(params);
-        std::vector<uint32_t> e(loamx_edge_capacity(&clp, &cfp) + 1), p(loamx_planar_capacity(&clp, &cfp) + 1);
-        size_t ne = 0, np = 0;
-        {
-          py::gil_scoped_release release;
-          loam::gpu::check(ctx, loamx_extract_features(ctx, scan.data(), n, &clp, &cfp, e.data(), e.size(), &ne, p.data(),
-                                                       p.size(), &np));
-        }
-        out.edge_points = gather_points(scan, e, ne);
-        out.planar_points = gather_points(scan, p, np);
-        return out;
-      },
-      py::arg("input_scan"), py::arg("lidar_params"), py::arg("params") = loam::FeatureExtractionParams());
-
-  m.def(
-      "computeCurvature",
-      [](const Arr& scan, const loam::LidarParams& lp, const loam::FeatureExtractionParams& params) {
-        const size_t n = check_points(scan, "input_scan");
-        scan_size_check(n, lp);
-        Arr out((py::ssize_t)n);
-        if (n == 0) return out;
-        loamx_ctx* ctx = loam::gpu::defaultContext();
-        const loamx_lidar_params clp = loam::gpu::toC(lp);
-        const loamx_fe_params cfp = loam::gpu::toC(params);
-        loam::gpu::check(ctx, loamx_compute_curvature(ctx, scan.data(), n, &clp, &cfp, out.mutable_data()));
-        return out;
-      },
-      py::arg("input_scan"), py::arg("lidar_params"), py::arg("params") = loam::FeatureExtractionParams());
-
-  m.def(
-      "computeValidPoints",
-      [](const Arr& scan, const loam::LidarParams& lp, const loam::FeatureExtractionParams& params) {
-        const size_t n = check_points(scan, "input_scan");
-        scan_size_check(n, lp);
-        py::array_t<bool> out((py::ssize_t)n);
-        if (n == 0) return out;
-        loamx_ctx* ctx = loam::gpu::defaultContext();
-        const loamx_lidar_params clp = loam::gpu::toC(lp);
-        const loamx_fe_params cfp = loam::gpu::toC(params);
-        static_assert(sizeof(bool) == 1, "bool must be one byte");
-        loam::gpu::check(ctx, loamx_compute_valid_points(ctx, scan.data(), n, &clp, &cfp,
-                                                         reinterpret_cast<uint8_t*>(out.mutable_data())));
-        return out;
-      },
-      py::arg("input_scan"), py::arg("lidar_params"), py::arg("params") = loam::FeatureExtractionParams());
+  m.def("extractFeatures", &extract_features<ArrF>, py::arg("input_scan"), py::arg("lidar_params"),
+        py::arg("params") = loam::FeatureExtractionParams());
+  m.def("extractFeatures", &extract_features<Arr>, py::arg("input_scan"), py::arg("lidar_params"),
+        py::arg("params") = loam::FeatureExtractionParams());
+  m.def("computeCurvature", &compute_curvature<ArrF>, py::arg("input_scan"), py::arg("lidar_params"),
+        py::arg("params") = loam::FeatureExtractionParams());
+  m.def("computeCurvature", &compute_curvature<Arr>, py::arg("input_scan"), py::arg("lidar_params"),
+        py::arg("params") = loam::FeatureExtractionParams());
+  m.def("computeValidPoints", &compute_valid_points<ArrF>, py::arg("input_scan"), py::arg("lidar_params"),
+        py::arg("params") = loam::FeatureExtractionParams());
+  m.def("computeValidPoints", &compute_valid_points<Arr>, py::arg("input_scan"), py::arg("lidar_params"),
+        py::arg("params") = loam::FeatureExtractionParams());
 
   py::class_<loam::RegistrationParams>(m, "RegistrationParams")
       .def(py::init<>())

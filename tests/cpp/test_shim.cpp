@@ -98,6 +98,50 @@ static void test_valid_points() {
   }
 }
 
+// PCL-style points (float fields, FieldAccessor) take the FP32-input path; the result must be the
+// one the FP64 path gives on the widened coordinates.
+struct PointF {
+  float x, y, z;
+  float intensity;
+};
+static_assert(gpu::float_scan_v<FieldAccessor, PointF>, "float-field points must select the FP32-input path");
+static_assert(!gpu::float_scan_v<FieldAccessor, Point>, "double-field points must not");
+static_assert(!gpu::float_scan_v<ParenAccessor, PointF>, "only FieldAccessor reads the fields directly");
+
+static void test_float_points() {
+  const size_t H = 8, W = 256;
+  std::vector<PointF> pf;
+  std::vector<Point> pd;
+  for (size_t l = 0; l < H; l++) {
+    for (size_t c = 0; c < W; c++) {
+      const double az = 2.0 * 3.14159265358979323846 * (double)c / (double)W, el = -0.2 + 0.05 * (double)l;
+      // a square room: range jumps at the corners give edges, walls give planar points
+      const double ca = std::cos(az), sa = std::sin(az);
+      const double r = 5.0 / std::fmax(std::fabs(ca), std::fabs(sa)) + ((c * 2654435761u + l * 40503u) % 1000) * 1e-5;
+      PointF p{(float)(r * ca * std::cos(el)), (float)(r * sa * std::cos(el)), (float)(r * std::sin(el)), 1.0f};
+      pf.push_back(p);
+      pd.push_back(Point((double)p.x, (double)p.y, (double)p.z));
+    }
+  }
+  const LidarParams lp(H, W, 0.5, 100.0);
+  const FeatureExtractionParams params{3, 6, 10, 50, 0.01, 1.0, 0.5, 1.0};
+  const auto ff = extractFeatures(pf, lp, params);
+  const auto fd = extractFeatures(pd, lp, params);
+  CHECK(ff.edge_points.size() == fd.edge_points.size());
+  CHECK(ff.planar_points.size() == fd.planar_points.size());
+  CHECK(!ff.planar_points.empty());
+  bool same = ff.edge_points.size() == fd.edge_points.size() && ff.planar_points.size() == fd.planar_points.size();
+  for (size_t i = 0; same && i < ff.edge_points.size(); i++) same = (double)ff.edge_points[i].x == fd.edge_points[i].x && (double)ff.edge_points[i].y == fd.edge_points[i].y;
+  for (size_t i = 0; same && i < ff.planar_points.size(); i++) same = (double)ff.planar_points[i].x == fd.planar_points[i].x && (double)ff.planar_points[i].z == fd.planar_points[i].z;
+  CHECK(same);
+  const auto cf = computeCurvature(pf, lp, params);
+  const auto cd = computeCurvature(pd, lp, params);
+  bool curv_same = cf.size() == cd.size();
+  for (size_t i = 0; curv_same && i < cf.size(); i++) curv_same = cf[i].curvature == cd[i].curvature;
+  CHECK(curv_same);
+  CHECK(computeValidPoints(pf, lp, params) == computeValidPoints(pd, lp, params));
+}
+
 static void test_errors_and_empty() {
   std::vector<Vector3d> empty;
   LoamFeatures<Vector3d> out = extractFeatures<ParenAccessor>(empty, LidarParams(0, 0, 0.1, 100), kKatParams);
@@ -225,6 +269,7 @@ static void test_registration() {
 int main() {
   test_curvature();
   test_valid_points();
+  test_float_points();
   test_errors_and_empty();
   test_pose();
   test_registration();

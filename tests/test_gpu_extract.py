@@ -116,3 +116,48 @@ def test_device_generator_bit_identical_and_batch_extract(oracle):
         assert np.array_equal(ex[s, :ne[s]], dev[s][oe]) and np.array_equal(px[s, :npl[s]], dev[s][op])
     for b in (d_xyz, d_ei, d_pi, d_ne, d_np, d_ex, d_px):
         b.free()
+
+
+@pytest.mark.parametrize("H,W,seed", [(64, 1024, 1), (8, 100, 5), (4, 37, 9)])
+def test_fp32_input_path_equals_oracle_on_widened_scan(oracle, H, W, seed):
+    """float scans (PCL points). The reference's FieldAccessor widens each coordinate to double
+    (common.h:55-60) before any arithmetic, so the oracle on the widened scan is the expected result, bit for bit."""
+    xyz32 = capi.synth_scan_host(seed, 0, 0, H, W, 0.01).astype(np.float32)
+    wide = xyz32.astype(np.float64)
+    lidar = capi.LidarParams(H, W, 1.0, 120.0)
+    for params in PARAM_SETS[:2]:
+        ofe = oracle.FeParams(*params)
+        fe = capi.FeatureExtractionParams(*params)
+        c = ctx().compute_curvature(xyz32, lidar, fe)
+        m = ctx().compute_valid_points(xyz32, lidar, fe)
+        assert np.array_equal(c.view(np.uint64), oracle.compute_curvature(wide, H, W, ofe).view(np.uint64))
+        assert np.array_equal(m, oracle.compute_valid_points(wide, H, W, 1.0, 120.0, ofe))
+        e, p = ctx().extract_features(xyz32, lidar, fe)
+        se, sp, _ = oracle.extract_features(wide, H, W, 1.0, 120.0, ofe, stable=True)
+        assert np.array_equal(e, se) and np.array_equal(p, sp)
+        e64, p64 = ctx().extract_features(wide, lidar, fe)
+        assert np.array_equal(e, e64) and np.array_equal(p, p64)
+
+
+def test_fp32_scan_pairs_equal_fp64_pipeline_on_widened_scans():
+    """Device-resident float scans through extract x2 + register: the same poses, bit for bit, as the FP64
+    pipeline fed with the widened scans."""
+    H, W, n_pairs, seed = 32, 512, 4, 77
+    N = H * W
+    c = ctx()
+    lidar, fe, reg = capi.LidarParams(H, W, 1.0, 120.0), capi.FeatureExtractionParams(), capi.RegistrationParams()
+    scans = np.stack([capi.synth_scan_host(seed, pr, which, H, W, 0.01) for pr in range(n_pairs) for which in (0, 1)])
+    s32 = np.ascontiguousarray(scans.astype(np.float32))
+    s64 = np.ascontiguousarray(s32.astype(np.float64))
+    d32, d64 = c.alloc(s32.nbytes), c.alloc(s64.nbytes)
+    d32.upload(s32)
+    d64.upload(s64)
+    r32, r64 = c.alloc(n_pairs * 64), c.alloc(n_pairs * 64)
+    c.register_scan_pairs_dev(d32.ptr, n_pairs, lidar, fe, reg, r32.ptr, f32=True)
+    c.register_scan_pairs_dev(d64.ptr, n_pairs, lidar, fe, reg, r64.ptr)
+    c.synchronize()
+    a, b = r32.download(np.uint8, n_pairs * 64), r64.download(np.uint8, n_pairs * 64)
+    assert np.array_equal(a, b)
+    assert (a.view(capi.RESULT_DTYPE)["iterations"] > 0).all()
+    for buf in (d32, d64, r32, r64):
+        buf.free()

@@ -65,3 +65,19 @@ def test_readme_scan_to_scan_loop(oracle):
     assert len(detail.iteration_info[0].plane_associations) > 100
     with pytest.raises(RuntimeError):
         loam.extractFeatures(A[:100], lidar_params)
+
+
+@pytest.mark.gpu
+def test_float32_scans_take_the_fp32_input_path(oracle):
+    """a float32 (N,3) array is passed through uncast; results equal the oracle on the widened scan."""
+    loam = _loam()
+    H, W = 16, 256
+    lp = loam.LidarParams(H, W, 1.0, 120.0)
+    A32 = capi.synth_scan_host(13, 0, 0, H, W, 0.01).astype(np.float32)
+    wide = A32.astype(np.float64)
+    f = loam.extractFeatures(A32, lp)
+    oe, op = oracle.extract_features(wide, H, W, 1.0, 120.0)
+    assert f.edge_points.dtype == np.float64
+    assert np.array_equal(f.edge_points, wide[oe]) and np.array_equal(f.planar_points, wide[op])
+    assert np.array_equal(loam.computeCurvature(A32, lp).view(np.uint64), oracle.compute_curvature(wide, H, W).view(np.uint64))
+    assert np.array_equal(loam.computeValidPoints(A32, lp), oracle.compute_valid_points(wide, H, W, 1.0, 120.0))
