@@ -119,6 +119,24 @@ class TargetIndex {
                                               target.planar_points.size(), &rp, &h));
     return TargetIndex(h);
   }
+  /// Appends features to the target (a map that grows scan by scan): afterwards the index is the one `build`
+  /// gives for the concatenated feature sets.
+  template <template <typename> class Accessor = FieldAccessor, typename PointType, template <typename> class Alloc>
+  void insert(const LoamFeatures<PointType, Alloc>& more) {
+    const std::vector<double> e = gpu::pack<Accessor>(more.edge_points), p = gpu::pack<Accessor>(more.planar_points);
+    gpu::check(gpu::defaultContext(), loamx_target_index_insert(gpu::defaultContext(), handle_.get(), e.data(), more.edge_points.size(),
+                                                                p.data(), more.planar_points.size()));
+  }
+  size_t numEdgePoints() const {
+    size_t n = 0;
+    loamx_target_index_size(handle_.get(), &n, nullptr);
+    return n;
+  }
+  size_t numPlanarPoints() const {
+    size_t n = 0;
+    loamx_target_index_size(handle_.get(), nullptr, &n);
+    return n;
+  }
   const loamx_target_index* handle() const { return handle_.get(); }
 
  private:

@@ -160,6 +160,15 @@ typedef struct loamx_target_index loamx_target_index;
 int loamx_target_index_create(loamx_ctx* ctx, const double* tgt_edge, size_t n_tgt_edge, const double* tgt_planar,
                               size_t n_tgt_planar, const loamx_reg_params* reg, loamx_target_index** out);
 void loamx_target_index_destroy(loamx_ctx* ctx, loamx_target_index* index);
+/* Appends points to the index (a map that grows scan by scan). The new points take the indices that follow the
+ * existing ones, and the index afterwards is exactly the one loamx_target_index_create builds over the
+ * concatenated sets: registrations against it return the same bits. The points stay resident on the device
+ * (amortised-doubling buffers); the cell structure is rebuilt over all of them on the device, so an insert
+ * costs one upload of the NEW points plus one index build (4-5 ms per million points on MI355X). */
+int loamx_target_index_insert(loamx_ctx* ctx, loamx_target_index* index, const double* edge, size_t n_edge,
+                              const double* planar, size_t n_planar);
+/* number of edge / planar points in the index (either pointer may be NULL) */
+int loamx_target_index_size(const loamx_target_index* index, size_t* n_edge, size_t* n_planar);
 /* same contract as loamx_register_features, target taken from the index */
 int loamx_register_features_indexed(loamx_ctx* ctx, const loamx_target_index* index, const double* src_edge,
                                     size_t n_src_edge, const double* src_planar, size_t n_src_planar,

@@ -83,6 +83,7 @@ EXPORTS = [
     "loamx_copy_to_device", "loamx_copy_to_host",
     "loamx_compute_curvature_f32", "loamx_compute_valid_points_f32", "loamx_extract_features_f32",
     "loamx_extract_features_batch_dev_f32", "loamx_register_scan_pairs_dev_f32",
+    "loamx_target_index_insert", "loamx_target_index_size",
 ]
 
 _lib = None
@@ -128,6 +129,8 @@ def load(build_if_missing=True):
                                             C.POINTER(RegistrationParams), C.POINTER(RegResult),
                                             C.POINTER(RegDetail)]
     lib.loamx_target_index_create.argtypes = [vp, dp, C.c_size_t, dp, C.c_size_t, C.POINTER(RegistrationParams), C.POINTER(vp)]
+    lib.loamx_target_index_insert.argtypes = [vp, vp, dp, C.c_size_t, dp, C.c_size_t]
+    lib.loamx_target_index_size.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.loamx_target_index_destroy.argtypes = [vp, vp]
     lib.loamx_target_index_destroy.restype = None
     lib.loamx_register_features_indexed.argtypes = [vp, vp, dp, C.c_size_t, dp, C.c_size_t, dp, C.POINTER(RegistrationParams),
@@ -335,6 +338,16 @@ class Context:
         h = C.c_void_p()
         self._check(self.lib.loamx_target_index_create(self.h, _dp(te), len(te), _dp(tp), len(tp), C.byref(reg), C.byref(h)))
         return h
+
+    def target_index_insert(self, index, edge, planar):
+        """Appends points to a target index (same result as an index built over the concatenated sets)."""
+        e, p = _pts(edge), _pts(planar)
+        self._check(self.lib.loamx_target_index_insert(self.h, index, _dp(e), len(e), _dp(p), len(p)))
+
+    def target_index_size(self, index):
+        ne, npl = C.c_size_t(0), C.c_size_t(0)
+        self._check(self.lib.loamx_target_index_size(index, C.byref(ne), C.byref(npl)))
+        return ne.value, npl.value
 
     def target_index_destroy(self, index):
         self.lib.loamx_target_index_destroy(self.h, index)

@@ -63,8 +63,11 @@ struct loamx_target_index {
   uint32_t* cells[2] = {nullptr, nullptr};      // kGridCellsCap + 1 entries each
   GridPoint* sorted[2] = {nullptr, nullptr};    // n + kGridPad entries each
   float* rel[2] = {nullptr, nullptr};           // 3 x (n + kGridPad) single-precision offsets (FP32 pre-selection)
+  double* pts[2] = {nullptr, nullptr};          // the points in insertion order (index = `orig` of the sorted copy)
   size_t n[2] = {0, 0};
+  size_t cap[2] = {0, 0};                       // points the buffers above hold without growing
   double radius[2] = {0, 0};
+  uint32_t* counts = nullptr;                   // device copy of n[] for the build kernels
 };
 
 namespace {
@@ -352,8 +355,8 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   hipStream_t s = ctx->stream;
 
   if (prebuilt) {  // persistent target index: only the source sets are (re)ordered
-    B.grid_edge = GridSet{prebuilt->desc[0], prebuilt->cells[0], prebuilt->sorted[0], prebuilt->n[0] + kGridPad, prebuilt->rel[0]};
-    B.grid_plane = GridSet{prebuilt->desc[1], prebuilt->cells[1], prebuilt->sorted[1], prebuilt->n[1] + kGridPad, prebuilt->rel[1]};
+    B.grid_edge = GridSet{prebuilt->desc[0], prebuilt->cells[0], prebuilt->sorted[0], prebuilt->cap[0] + kGridPad, prebuilt->rel[0]};
+    B.grid_plane = GridSet{prebuilt->desc[1], prebuilt->cells[1], prebuilt->sorted[1], prebuilt->cap[1] + kGridPad, prebuilt->rel[1]};
   }
   {
     TimedScope t(ctx, LOAMX_K_GRID, 0.0);
@@ -753,6 +756,91 @@ int loamx_register_features_indexed(loamx_ctx* ctx, const loamx_target_index* in
 }
 
 /* ---- persistent target index ---------------------------------------------------------------------------- */
+namespace {
+void index_free(loamx_target_index* idx) {
+  for (int k = 0; k < 2; k++) {
+    if (idx->desc[k]) (void)hipFree(idx->desc[k]);
+    if (idx->cells[k]) (void)hipFree(idx->cells[k]);
+    if (idx->sorted[k]) (void)hipFree(idx->sorted[k]);
+    if (idx->rel[k]) (void)hipFree(idx->rel[k]);
+    if (idx->pts[k]) (void)hipFree(idx->pts[k]);
+  }
+  if (idx->counts) (void)hipFree(idx->counts);
+  delete idx;
+}
+
+// Makes room for `extra` more points of kind k (amortised doubling; the old points are copied over on the device).
+int index_reserve(loamx_ctx* ctx, loamx_target_index* idx, int k, size_t extra) {
+  const size_t need = idx->n[k] + extra;
+  if (need <= idx->cap[k] && idx->pts[k]) return LOAMX_OK;
+  size_t cap = idx->cap[k] ? idx->cap[k] : 1;
+  while (cap < need) cap *= 2;
+  if (idx->cap[k] == 0) cap = need ? need : 1;  // the first build is sized exactly
+  double* pts = nullptr;
+  GridPoint* sorted = nullptr;
+  float* rel = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&pts), cap * 24) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&sorted), (cap + kGridPad) * sizeof(GridPoint)) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&rel), 3 * (cap + kGridPad) * sizeof(float)) != hipSuccess) {
+    if (pts) (void)hipFree(pts);
+    if (sorted) (void)hipFree(sorted);
+    if (rel) (void)hipFree(rel);
+    return fail(ctx, LOAMX_ERR_HIP, "hipMalloc failed for the target index");
+  }
+  if (idx->pts[k] && idx->n[k])
+    HIP_TRY(ctx, hipMemcpyAsync(pts, idx->pts[k], idx->n[k] * 24, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (idx->pts[k]) (void)hipFree(idx->pts[k]);
+  if (idx->sorted[k]) (void)hipFree(idx->sorted[k]);
+  if (idx->rel[k]) (void)hipFree(idx->rel[k]);
+  idx->pts[k] = pts, idx->sorted[k] = sorted, idx->rel[k] = rel, idx->cap[k] = cap;
+  return LOAMX_OK;
+}
+
+// (Re)builds both grids from idx->pts: the index of a point set does not depend on how it was grown.
+int index_build(loamx_ctx* ctx, loamx_target_index* idx) {
+  hipStream_t s = ctx->stream;
+  const uint32_t counts[2] = {(uint32_t)idx->n[0], (uint32_t)idx->n[1]};
+  HIP_TRY(ctx, hipMemcpyAsync(idx->counts, counts, sizeof(counts), hipMemcpyHostToDevice, s));
+  RegConfig C{};
+  C.r_edge = idx->radius[0], C.r_plane = idx->radius[1];
+  RegBatch B{};
+  B.n_pairs = 1, B.in_pitch = 1;
+  B.edge_stride = idx->cap[0], B.planar_stride = idx->cap[1];
+  B.tgt_edge = idx->pts[0], B.tgt_planar = idx->pts[1];
+  B.n_tgt_edge = idx->counts, B.n_tgt_planar = idx->counts + 1;
+  B.grid_edge = GridSet{idx->desc[0], idx->cells[0], idx->sorted[0], idx->cap[0] + kGridPad, idx->rel[0]};
+  B.grid_plane = GridSet{idx->desc[1], idx->cells[1], idx->sorted[1], idx->cap[1] + kGridPad, idx->rel[1]};
+  untimed(ctx);
+  {
+    TimedScope t(ctx, LOAMX_K_GRID, 0.0);
+    launch_grid_build_targets(B, C, s);
+  }
+  int rc = check_launch(ctx, "grid_build_kernel");
+  if (rc != LOAMX_OK) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return LOAMX_OK;
+}
+
+int index_append(loamx_ctx* ctx, loamx_target_index* idx, const double* edge, size_t n_e, const double* planar, size_t n_p) {
+  const double* host[2] = {edge, planar};
+  const size_t add[2] = {n_e, n_p};
+  for (int k = 0; k < 2; k++) {
+    if (idx->n[k] + add[k] > 0x0FFFFFFFull) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "feature set too large");
+    if (add[k] && !host[k]) return fail(ctx, LOAMX_ERR_BAD_PARAM, "null point array");
+  }
+  for (int k = 0; k < 2; k++) {  // all the room first: a failed allocation leaves the index as it was
+    int rc = index_reserve(ctx, idx, k, add[k]);
+    if (rc != LOAMX_OK) return rc;
+  }
+  for (int k = 0; k < 2; k++) {
+    if (add[k]) HIP_TRY(ctx, hipMemcpyAsync(idx->pts[k] + idx->n[k] * 3, host[k], add[k] * 24, hipMemcpyHostToDevice, ctx->stream));
+    idx->n[k] += add[k];
+  }
+  return index_build(ctx, idx);
+}
+}  // namespace
+
 void loamx_target_index_destroy(loamx_ctx* ctx, loamx_target_index* index) {
   if (!index) return;
   if (ctx) {
@@ -760,13 +848,7 @@ void loamx_target_index_destroy(loamx_ctx* ctx, loamx_target_index* index) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
   }
-  for (int k = 0; k < 2; k++) {
-    if (index->desc[k]) (void)hipFree(index->desc[k]);
-    if (index->cells[k]) (void)hipFree(index->cells[k]);
-    if (index->sorted[k]) (void)hipFree(index->sorted[k]);
-    if (index->rel[k]) (void)hipFree(index->rel[k]);
-  }
-  delete index;
+  index_free(index);
 }
 
 int loamx_target_index_create(loamx_ctx* ctx, const double* tgt_edge, size_t n_te, const double* tgt_planar, size_t n_tp,
@@ -778,56 +860,34 @@ int loamx_target_index_create(loamx_ctx* ctx, const double* tgt_edge, size_t n_t
   RegConfig C;
   int rc = make_reg_config(ctx, reg, C);
   if (rc != LOAMX_OK) return rc;
-  if (n_te > 0x0FFFFFFFull || n_tp > 0x0FFFFFFFull) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "feature set too large");
-  hipStream_t s = ctx->stream;
   loamx_target_index* idx = new loamx_target_index;
-  idx->n[0] = n_te, idx->n[1] = n_tp;
   idx->radius[0] = C.r_edge, idx->radius[1] = C.r_plane;
-  const double* host[2] = {tgt_edge, tgt_planar};
-  const int ws_pts[2] = {WS_TGT_E, WS_TGT_P};
-  rc = ensure(ctx, WS_FCOUNTS, 4 * sizeof(uint32_t));
-  const uint32_t counts[4] = {0, 0, (uint32_t)n_te, (uint32_t)n_tp};
-  if (rc == LOAMX_OK && hipMemcpyAsync(ctx->ws[WS_FCOUNTS].p, counts, sizeof(counts), hipMemcpyHostToDevice, s) != hipSuccess) rc = LOAMX_ERR_HIP;
-  for (int k = 0; k < 2 && rc == LOAMX_OK; k++) {
-    const size_t n = idx->n[k];
-    rc = ensure(ctx, ws_pts[k], (n ? n : 1) * 24);
-    if (rc != LOAMX_OK) break;
-    if (hipMalloc(reinterpret_cast<void**>(&idx->desc[k]), sizeof(GridDesc)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&idx->cells[k]), (size_t)(kGridCellsCap + 1) * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&idx->sorted[k]), (n + kGridPad) * sizeof(GridPoint)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&idx->rel[k]), 3 * (n + kGridPad) * sizeof(float)) != hipSuccess) {
-      rc = fail(ctx, LOAMX_ERR_HIP, "hipMalloc failed for the target index");
-      break;
-    }
-    if (n && hipMemcpyAsync(ctx->ws[ws_pts[k]].p, host[k], n * 24, hipMemcpyHostToDevice, s) != hipSuccess) rc = LOAMX_ERR_HIP;
-  }
-  if (rc == LOAMX_OK) {
-    RegBatch B{};
-    B.n_pairs = 1, B.in_pitch = 1;
-    B.edge_stride = n_te ? n_te : 1, B.planar_stride = n_tp ? n_tp : 1;
-    B.tgt_edge = wsp<double>(ctx, WS_TGT_E), B.tgt_planar = wsp<double>(ctx, WS_TGT_P);
-    B.n_tgt_edge = wsp<uint32_t>(ctx, WS_FCOUNTS) + 2, B.n_tgt_planar = wsp<uint32_t>(ctx, WS_FCOUNTS) + 3;
-    B.grid_edge = GridSet{idx->desc[0], idx->cells[0], idx->sorted[0], n_te + kGridPad, idx->rel[0]};
-    B.grid_plane = GridSet{idx->desc[1], idx->cells[1], idx->sorted[1], n_tp + kGridPad, idx->rel[1]};
-    untimed(ctx);
-    {
-      TimedScope t(ctx, LOAMX_K_GRID, 0.0);
-      launch_grid_build_targets(B, C, s);
-    }
-    rc = check_launch(ctx, "grid_build_kernel");
-    if (rc == LOAMX_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(ctx, LOAMX_ERR_HIP, "target index build failed");
-  }
+  bool ok = hipMalloc(reinterpret_cast<void**>(&idx->counts), 2 * sizeof(uint32_t)) == hipSuccess;
+  for (int k = 0; k < 2 && ok; k++)
+    ok = hipMalloc(reinterpret_cast<void**>(&idx->desc[k]), sizeof(GridDesc)) == hipSuccess &&
+         hipMalloc(reinterpret_cast<void**>(&idx->cells[k]), (size_t)(kGridCellsCap + 1) * sizeof(uint32_t)) == hipSuccess;
+  rc = ok ? index_append(ctx, idx, tgt_edge, n_te, tgt_planar, n_tp) : fail(ctx, LOAMX_ERR_HIP, "hipMalloc failed for the target index");
   if (rc != LOAMX_OK) {
-    for (int k = 0; k < 2; k++) {
-      if (idx->desc[k]) (void)hipFree(idx->desc[k]);
-      if (idx->cells[k]) (void)hipFree(idx->cells[k]);
-      if (idx->sorted[k]) (void)hipFree(idx->sorted[k]);
-      if (idx->rel[k]) (void)hipFree(idx->rel[k]);
-    }
-    delete idx;
+    index_free(idx);
     return rc;
   }
   *out = idx;
+  return LOAMX_OK;
+}
+
+int loamx_target_index_insert(loamx_ctx* ctx, loamx_target_index* index, const double* edge, size_t n_edge, const double* planar,
+                              size_t n_planar) {
+  if (!ctx || !index) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (n_edge == 0 && n_planar == 0) return LOAMX_OK;
+  return index_append(ctx, index, edge, n_edge, planar, n_planar);
+}
+
+int loamx_target_index_size(const loamx_target_index* index, size_t* n_edge, size_t* n_planar) {
+  if (!index) return LOAMX_ERR_BAD_PARAM;
+  if (n_edge) *n_edge = index->n[0];
+  if (n_planar) *n_planar = index->n[1];
   return LOAMX_OK;
 }
 

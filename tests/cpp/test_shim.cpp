@@ -255,6 +255,16 @@ static void test_registration() {
     const Pose3d viaIndex = registerFeatures<ParenAccessor>(source, index, Pose3d());
     for (int i = 0; i < 3; i++) CHECK(plain.translation(i) == viaIndex.translation(i));
     CHECK(plain.rotation.w() == viaIndex.rotation.w());
+    // ... and so does an index grown in two steps (first half of every feature set, then the rest)
+    LoamFeatures<Vector3d> first, rest;
+    for (size_t i = 0; i < target.edge_points.size(); i++) (i < target.edge_points.size() / 2 ? first : rest).edge_points.push_back(target.edge_points[i]);
+    for (size_t i = 0; i < target.planar_points.size(); i++) (i < target.planar_points.size() / 2 ? first : rest).planar_points.push_back(target.planar_points[i]);
+    TargetIndex grown = TargetIndex::build<ParenAccessor>(first);
+    grown.insert<ParenAccessor>(rest);
+    CHECK(grown.numEdgePoints() == target.edge_points.size() && grown.numPlanarPoints() == target.planar_points.size());
+    const Pose3d viaGrown = registerFeatures<ParenAccessor>(source, grown, Pose3d());
+    for (int i = 0; i < 3; i++) CHECK(plain.translation(i) == viaGrown.translation(i));
+    CHECK(plain.rotation.w() == viaGrown.rotation.w());
   }
   {  // NonStandardAllocator: planar only, self registration
     LoamFeatures<Vector3d> t;

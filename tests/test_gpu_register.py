@@ -195,3 +195,21 @@ def test_scan_to_map_registration(oracle):
     with pytest.raises(capi.LoamxError):
         ctx().register_features_indexed(idx, src[e], src[p], reg=reg2)
     ctx().target_index_destroy(idx)
+    # a map grown scan by scan (insert) is the index of the concatenated sets: the same bits again
+    grown = ctx().target_index(maps_e[0], maps_p[0])
+    for k in (1, 2):
+        ctx().target_index_insert(grown, maps_e[k], maps_p[k])
+    assert ctx().target_index_size(grown) == (len(map_e), len(map_p))
+    pi, ti, ii = ctx().register_features_indexed(grown, src[e], src[p])
+    assert (ti, ii) == (tg, ig) and np.array_equal(pi.view(np.uint64), pg.view(np.uint64))
+    ctx().target_index_insert(grown, np.zeros((0, 3)), np.zeros((0, 3)))  # empty insert: no-op
+    assert ctx().target_index_size(grown) == (len(map_e), len(map_p))
+    ctx().target_index_destroy(grown)
+    # an index that starts empty
+    empty = ctx().target_index(np.zeros((0, 3)), np.zeros((0, 3)))
+    pe, te, ie = ctx().register_features_indexed(empty, src[e], src[p])
+    assert te == capi.INSUFFICIENT_ASSOCIATIONS if hasattr(capi, "INSUFFICIENT_ASSOCIATIONS") else te == 2
+    ctx().target_index_insert(empty, map_e, map_p)
+    pi, ti, ii = ctx().register_features_indexed(empty, src[e], src[p])
+    assert (ti, ii) == (tg, ig) and np.array_equal(pi.view(np.uint64), pg.view(np.uint64))
+    ctx().target_index_destroy(empty)
