@@ -322,10 +322,25 @@ __device__ __forceinline__ uint32_t mis_pass(int lane, int CH, int base, int sta
   return kept;
 }
 
+// Fused compaction (fz.line_tot != nullptr, number_sectors <= 64): the wavefront of a scan line publishes the
+// line's edge / planar totals, sums the totals of the lines before it in the same scan (a chained scan over at
+// most scan_lines - 1 published values, one per lane), and writes its picks — indices and point copies — straight
+// to their final places in the reference's output order. The gather of the picked points (27 % of a scan, but
+// nearly every 128-byte line of it: HBM-bound) then overlaps with the selection of other lines (VALU-bound)
+// instead of running as a kernel of its own. Waiting is safe because workgroups start in index order and a line
+// only waits for lines of lower index; the wait is bounded all the same (kLookbackSpins), and a wavefront that
+// gives up raises fz.error instead of hanging.
+constexpr uint32_t kLookbackSpins = 1u << 20;
+
+template <typename T>
+__device__ __forceinline__ void fused_copy(const T* __restrict__ scan_xyz, uint32_t idx, double* __restrict__ dst) {
+  dst[0] = (double)scan_xyz[3 * (size_t)idx], dst[1] = (double)scan_xyz[3 * (size_t)idx + 1], dst[2] = (double)scan_xyz[3 * (size_t)idx + 2];
+}
+
 template <int R, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __restrict__ curv,
                                                                 const uint8_t* __restrict__ mask, size_t n_lines,
-                                                                ExtractParams P, ExtractStage st) {
+                                                                ExtractParams P, ExtractStage st, ExtractFused fz) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const size_t line = (size_t)blockIdx.x * WAVES + wave;
@@ -387,6 +402,7 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
   }
   const uint32_t line_base = (uint32_t)(line % P.H) * P.W;
   const uint32_t idx_mask = W <= 2 ? 1u : (0xFFFFFFFFu >> __clz(W - 1));  // index-in-line bits of the sort keys
+  uint32_t my_ne = 0, my_np = 0;  // lane s: picks of sector s
   for (uint32_t s = 0; s < P.S; s++) {
     const int start = (int)(s * P.pps);
     const int end = (s == P.S - 1) ? W : start + (int)P.pps;  // features-inl.h:31-35
@@ -399,7 +415,103 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
       st.edge_cnt[group] = ne;
       st.planar_cnt[group] = npl;
     }
+    if ((uint32_t)lane == s) my_ne = ne, my_np = npl;  // (fused path: number_sectors <= 64)
   }
+  if (!fz.line_tot) return;  // uniform
+  // ---- fused compaction -----------------------------------------------------------------------------
+  const uint32_t li = (uint32_t)(line % P.H);
+  const size_t scan = line / P.H;
+  uint32_t e_incl = my_ne, p_incl = my_np;  // inclusive scans over the sectors (lane s = sector s)
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t te = __shfl_up(e_incl, off), tp = __shfl_up(p_incl, off);
+    if (lane >= off) e_incl += te, p_incl += tp;
+  }
+  const uint32_t E_l = __shfl(e_incl, 63), P_l = __shfl(p_incl, 63);
+  if (lane == 0)
+    __hip_atomic_store(fz.line_tot + line, (1ull << 63) | ((unsigned long long)E_l << 32) | (unsigned long long)P_l,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t* __restrict__ oe = fz.edge_idx + scan * fz.edge_stride;
+  uint32_t* __restrict__ op = fz.planar_idx + scan * fz.planar_stride;
+  double* __restrict__ xe = fz.edge_xyz ? fz.edge_xyz + scan * fz.edge_stride * 3 : nullptr;
+  double* __restrict__ xp = fz.planar_xyz ? fz.planar_xyz + scan * fz.planar_stride * 3 : nullptr;
+  const size_t scan_off = scan * (size_t)P.H * P.W * 3;
+  const bool want_xyz = xe != nullptr || xp != nullptr;  // (both or none in practice)
+  uint32_t base_e = 0, base_p = 0;
+  // Sectors in batches: all index loads of a batch, then all point loads, then the stores — the chain stage
+  // index -> point -> store is three dependent memory round trips, so a batch keeps 2 * kFuseBatch of them in
+  // flight per lane. The wait for the preceding lines sits between the loads and the stores of the first batch.
+  constexpr uint32_t kFuseBatch = 3;
+  for (uint32_t s0 = 0; s0 < P.S; s0 += kFuseBatch) {
+    uint32_t idx[2 * kFuseBatch], off[2 * kFuseBatch];
+    bool on[2 * kFuseBatch];
+#pragma unroll
+    for (uint32_t b = 0; b < kFuseBatch; b++) {
+      const uint32_t s = s0 + b;
+      const bool in = s < P.S;
+      const int sl = in ? (int)s : 0;
+      const size_t group = line * P.S + (size_t)sl;
+      const uint32_t ce = __shfl(my_ne, sl), cp = __shfl(my_np, sl);
+      off[2 * b] = __shfl(e_incl, sl) - ce + (uint32_t)lane, off[2 * b + 1] = __shfl(p_incl, sl) - cp + (uint32_t)lane;
+      on[2 * b] = in && (uint32_t)lane < ce, on[2 * b + 1] = in && (uint32_t)lane < cp;
+      // (a lane reads what it wrote itself in mis_pass)
+      idx[2 * b] = on[2 * b] ? st.edge_stage[group * P.cap_edge + lane] : 0u;
+      idx[2 * b + 1] = on[2 * b + 1] ? st.planar_stage[group * P.cap_planar + lane] : 0u;
+    }
+    double v[2 * kFuseBatch][3];
+    if (want_xyz) {
+#pragma unroll
+      for (uint32_t q = 0; q < 2 * kFuseBatch; q++) {
+        if (fz.f32) {
+          const float* __restrict__ src = static_cast<const float*>(fz.xyz) + scan_off + 3 * (size_t)idx[q];
+#pragma unroll
+          for (int k = 0; k < 3; k++) v[q][k] = on[q] ? (double)src[k] : 0.0;
+        } else {
+          const double* __restrict__ src = static_cast<const double*>(fz.xyz) + scan_off + 3 * (size_t)idx[q];
+#pragma unroll
+          for (int k = 0; k < 3; k++) v[q][k] = on[q] ? src[k] : 0.0;
+        }
+      }
+    }
+    if (s0 == 0) {  // uniform: totals of the lines before this one in the scan
+      bool gave_up = false;
+      for (uint32_t c0 = 0; c0 < li; c0 += 64) {
+        const uint32_t j = c0 + (uint32_t)lane;
+        unsigned long long t = 1ull << 63;  // no predecessor on this lane: nothing to wait for, contributes 0
+        if (j < li) {
+          const unsigned long long* src = fz.line_tot + (line - li + j);
+          t = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (uint32_t spins = 0; !(t >> 63) && spins < kLookbackSpins; spins++) {
+            __builtin_amdgcn_s_sleep(4);
+            t = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        gave_up = gave_up || !(t >> 63);
+        uint32_t se = (uint32_t)(t >> 32) & 0x7FFFFFFFu, sp = (uint32_t)t;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) se += __shfl_xor(se, o), sp += __shfl_xor(sp, o);
+        base_e += se, base_p += sp;
+      }
+      if (__ballot(gave_up) != 0) {  // uniform
+        if (lane == 0) atomicOr(fz.error, 1u);
+        return;
+      }
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < 2 * kFuseBatch; q++) {
+      if (on[q]) {
+        const bool edge = (q & 1u) == 0u;
+        const uint32_t o = (edge ? base_e : base_p) + off[q];
+        (edge ? oe : op)[o] = idx[q];
+        double* __restrict__ x = edge ? xe : xp;
+        if (x) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) x[3 * (size_t)o + k] = v[q][k];
+        }
+      }
+    }
+  }
+  if (li == P.H - 1 && lane == 0) fz.n_edge[scan] = base_e + E_l, fz.n_planar[scan] = base_p + P_l;
 }
 
 // block-wide exclusive scan of one value per thread (256 threads); returns the exclusive prefix and
@@ -526,21 +638,25 @@ void launch_curvature_valid(const void* d_xyz, bool f32, size_t n_scans, const E
 
 template <int R>
 static void launch_select_mis(const double* d_curv, const uint8_t* d_mask, size_t n_lines, const ExtractParams& P,
-                              const ExtractStage& st, hipStream_t s) {
+                              const ExtractStage& st, const ExtractFused& fz, hipStream_t s) {
   const size_t per_wave = select_mis_lds_bytes((int)P.W);
   if (per_wave * 4 <= 48 * 1024) {
     hipLaunchKernelGGL((select_mis_kernel<R, 4>), dim3((unsigned)((n_lines + 3) / 4)), dim3(256), per_wave * 4, s, d_curv,
-                       d_mask, n_lines, P, st);
+                       d_mask, n_lines, P, st, fz);
   } else {
     hipLaunchKernelGGL((select_mis_kernel<R, 1>), dim3((unsigned)n_lines), dim3(64), per_wave, s, d_curv, d_mask, n_lines,
-                       P, st);
+                       P, st, fz);
   }
 }
 
-void launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, const ExtractParams& P,
-                   const ExtractStage& st, hipStream_t s) {
+bool launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, const ExtractParams& P,
+                   const ExtractStage& st, const ExtractFused* fused, hipStream_t s) {
   const size_t n_lines = n_scans * P.H;
-  if (n_lines == 0 || P.W == 0) return;
+  if (n_lines == 0 || P.W == 0) return false;
+  // the fused compaction keeps the per-sector counts of a line on the lanes of its wavefront
+  const bool fuse = fused && fused->line_tot && P.S <= 64 && !getenv("LOAMX_NO_FUSED_COMPACT");
+  ExtractFused fz{};
+  if (fuse) fz = *fused;
   // bitmask-MIS fast path: R = np-1 in 1..4, lane chunk wide enough for the halo, at most 64 picks
   // per sector (picks are >= R+1 points apart), the cap itself at most 64
   const int R = (int)P.np - 1, CH = ((int)P.W + 63) / 64;
@@ -548,10 +664,10 @@ void launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, 
   const bool mis_ok = R >= 1 && R <= 4 && CH >= R && CH + 2 * R <= 64 && (longest + R) / (R + 1) <= 64;
   if (mis_ok) {
     switch (R) {
-      case 1: launch_select_mis<1>(d_curv, d_mask, n_lines, P, st, s); return;
-      case 2: launch_select_mis<2>(d_curv, d_mask, n_lines, P, st, s); return;
-      case 3: launch_select_mis<3>(d_curv, d_mask, n_lines, P, st, s); return;
-      default: launch_select_mis<4>(d_curv, d_mask, n_lines, P, st, s); return;
+      case 1: launch_select_mis<1>(d_curv, d_mask, n_lines, P, st, fz, s); return fuse;
+      case 2: launch_select_mis<2>(d_curv, d_mask, n_lines, P, st, fz, s); return fuse;
+      case 3: launch_select_mis<3>(d_curv, d_mask, n_lines, P, st, fz, s); return fuse;
+      default: launch_select_mis<4>(d_curv, d_mask, n_lines, P, st, fz, s); return fuse;
     }
   }
   const size_t per_wave = (size_t)P.W * 8 + (((size_t)P.W + 7) & ~(size_t)7);
@@ -563,6 +679,7 @@ void launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, 
     hipLaunchKernelGGL(select_kernel<1>, dim3((unsigned)n_lines), dim3(64), per_wave, s, d_curv, d_mask, n_lines, P,
                        st);
   }
+  return false;
 }
 
 void launch_compact(const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, const ExtractStage& st,

@@ -21,7 +21,7 @@ enum WsId {
   WS_XYZ = 0, WS_CURV, WS_MASK, WS_EDGE_STAGE, WS_PLANAR_STAGE, WS_EDGE_CNT, WS_PLANAR_CNT,
   WS_EDGE_IDX, WS_PLANAR_IDX, WS_N_EDGE, WS_N_PLANAR, WS_EDGE_XYZ, WS_PLANAR_XYZ,
   WS_GRID_DESC_E, WS_GRID_DESC_P, WS_CELLS_E, WS_CELLS_P, WS_SORTED_E, WS_SORTED_P, WS_REL_E, WS_REL_P,
-  WS_SGRID_DESC_E, WS_SGRID_DESC_P, WS_SCELLS_E, WS_SCELLS_P, WS_SSORTED_E, WS_SSORTED_P, WS_SORT_SCRATCH, WS_ASSOC_E, WS_ASSOC_P, WS_NN_E, WS_NN_P, WS_RNN_E, WS_RNN_P, WS_NEAREST_E, WS_NEAREST_P, WS_REST_E, WS_REST_P, WS_EXACT_E, WS_EXACT_P, WS_NASSOC, WS_STATE, WS_PARTIALS, WS_MOM_PARTIALS, WS_MOMENTS, WS_FLAGGED_LIST, WS_FLAGGED_COUNT,
+  WS_SGRID_DESC_E, WS_SGRID_DESC_P, WS_SCELLS_E, WS_SCELLS_P, WS_SSORTED_E, WS_SSORTED_P, WS_SORT_SCRATCH, WS_ASSOC_E, WS_ASSOC_P, WS_NN_E, WS_NN_P, WS_RNN_E, WS_RNN_P, WS_NEAREST_E, WS_NEAREST_P, WS_REST_E, WS_REST_P, WS_EXACT_E, WS_EXACT_P, WS_NASSOC, WS_STATE, WS_PARTIALS, WS_MOM_PARTIALS, WS_MOMENTS, WS_FLAGGED_LIST, WS_FLAGGED_COUNT, WS_LINE_TOT, WS_EXTRACT_ERR,
   WS_COUNTERS, WS_ITERINFO, WS_SRC_E, WS_SRC_P, WS_TGT_E, WS_TGT_P, WS_FCOUNTS, WS_RESULTS, WS_INIT,
   WS_COUNT
 };
@@ -215,6 +215,12 @@ int make_reg_config(loamx_ctx* ctx, const loamx_reg_params* r, RegConfig& C) {
 size_t edge_capacity(const ExtractParams& P) { return (size_t)P.H * P.S * P.cap_edge; }
 size_t planar_capacity(const ExtractParams& P) { return (size_t)P.H * P.S * P.cap_planar; }
 
+// The fused compaction's give-up flag (see select_mis_kernel): reported once, then cleared.
+int extract_error(loamx_ctx* ctx) {
+  if (ctx->ws[WS_EXTRACT_ERR].p) (void)hipMemsetAsync(ctx->ws[WS_EXTRACT_ERR].p, 0, sizeof(uint32_t), ctx->stream);
+  return fail(ctx, LOAMX_ERR_HIP, "feature extraction: a scan line gave up waiting for the lines before it (select_mis_kernel chained scan)");
+}
+
 // extraction over device-resident scans ------------------------------------------------------------------
 // d_xyz: double, or float when f32 (FP32-input path)
 int extract_dev(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, uint32_t* d_edge_idx,
@@ -246,11 +252,24 @@ int extract_dev(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_scans, con
   ENSURE(ctx, WS_PLANAR_CNT, groups * sizeof(uint32_t));
   ExtractStage st{wsp<uint32_t>(ctx, WS_EDGE_STAGE), wsp<uint32_t>(ctx, WS_PLANAR_STAGE),
                   wsp<uint32_t>(ctx, WS_EDGE_CNT), wsp<uint32_t>(ctx, WS_PLANAR_CNT)};
+  // the selection writes the final feature arrays itself when it can (launch_select); its chained scan over the
+  // lines of a scan needs the per-line slots zeroed
+  ENSURE(ctx, WS_LINE_TOT, n_scans * P.H * sizeof(unsigned long long));
+  const bool had_err = ctx->ws[WS_EXTRACT_ERR].p != nullptr;
+  ENSURE(ctx, WS_EXTRACT_ERR, sizeof(uint32_t));
+  untimed(ctx);
+  if (!had_err) HIP_TRY(ctx, hipMemsetAsync(ctx->ws[WS_EXTRACT_ERR].p, 0, sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->ws[WS_LINE_TOT].p, 0, n_scans * P.H * sizeof(unsigned long long), ctx->stream));
+  const ExtractFused fz{wsp<unsigned long long>(ctx, WS_LINE_TOT), d_xyz, f32 ? 1u : 0u, d_edge_idx, d_n_edge, d_edge_xyz,
+                        edge_capacity(P), d_planar_idx, d_n_planar, d_planar_xyz, planar_capacity(P),
+                        wsp<uint32_t>(ctx, WS_EXTRACT_ERR)};
+  bool fused = false;
   {
     TimedScope t(ctx, LOAMX_K_SELECT, (double)n_scans * (double)N * 9.0);
-    launch_select(wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), n_scans, P, st, ctx->stream);
+    fused = launch_select(wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), n_scans, P, st, &fz, ctx->stream);
   }
   CHECK_LAUNCH(ctx, "select_kernel");
+  if (fused) return LOAMX_OK;
   {
     TimedScope t(ctx, LOAMX_K_COMPACT, 0.0);
     launch_compact(d_xyz, f32, n_scans, P, st, d_edge_idx, d_n_edge, d_edge_xyz, edge_capacity(P), d_planar_idx,
@@ -409,7 +428,10 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
       // one 4-byte readback per outer iteration: stop as soon as every pair has terminated
       untimed(ctx);
       HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, B.n_active, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      const bool chk = it == 0 && ctx->ws[WS_EXTRACT_ERR].p;  // a pipeline call ran the extraction just before
+      if (chk) HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_pinned[2], ctx->ws[WS_EXTRACT_ERR].p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
       HIP_TRY(ctx, hipStreamSynchronize(s));
+      if (chk && ctx->h_pinned[2] != 0) return extract_error(ctx);
       if (ctx->h_pinned[0] == 0) break;
     }
   }
@@ -531,7 +553,10 @@ int loamx_ctx_synchronize(loamx_ctx* ctx) {
   if (!ctx) return LOAMX_ERR_BAD_PARAM;
   std::lock_guard<std::mutex> lock(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->ws[WS_EXTRACT_ERR].p)
+    HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_pinned[2], ctx->ws[WS_EXTRACT_ERR].p, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->ws[WS_EXTRACT_ERR].p && ctx->h_pinned[2] != 0) return extract_error(ctx);
   return LOAMX_OK;
 }
 
@@ -627,7 +652,9 @@ static int host_extract(loamx_ctx* ctx, const void* xyz, bool f32, size_t n_poin
   if (rc != LOAMX_OK) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_pinned[0], ctx->ws[WS_N_EDGE].p, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_pinned[1], ctx->ws[WS_N_PLANAR].p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_pinned[2], ctx->ws[WS_EXTRACT_ERR].p, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->h_pinned[2] != 0) return extract_error(ctx);
   const size_t ne = ctx->h_pinned[0], npl = ctx->h_pinned[1];
   *n_edge = ne, *n_planar = npl;
   if (ne > edge_cap || npl > planar_cap) return fail(ctx, LOAMX_ERR_CAPACITY, "feature index capacity too small");

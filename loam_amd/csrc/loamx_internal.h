@@ -22,10 +22,28 @@ struct ExtractStage {
 };
 
 // d_xyz: n_scans x H x W x 3 scalars, double or (f32) float
+// Outputs select_mis_kernel writes itself when the compaction is fused into the selection (see the kernel).
+struct ExtractFused {
+  unsigned long long* line_tot;  // [n_lines] published totals of every scan line, zeroed before the launch
+  const void* xyz;               // the scans (double, or float when f32)
+  uint32_t f32;
+  uint32_t* edge_idx;            // outputs as launch_compact
+  uint32_t* n_edge;
+  double* edge_xyz;
+  size_t edge_stride;
+  uint32_t* planar_idx;
+  uint32_t* n_planar;
+  double* planar_xyz;
+  size_t planar_stride;
+  uint32_t* error;  // set when a wavefront gave up waiting for the lines before it (never seen; see the kernel)
+};
+
 void launch_curvature_valid(const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, double* d_curv,
                             uint8_t* d_mask, hipStream_t s);
-void launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, const ExtractParams& P,
-                   const ExtractStage& st, hipStream_t s);
+// fz != nullptr: the selection may also write the final feature arrays (returns true if it did: no
+// launch_compact needed); otherwise, or when it returns false, stage + counts only.
+bool launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, const ExtractParams& P,
+                   const ExtractStage& st, const ExtractFused* fz, hipStream_t s);
 // edge_stride / planar_stride: entries per scan in the output arrays
 void launch_compact(const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, const ExtractStage& st,
                     uint32_t* d_edge_idx, uint32_t* d_n_edge, double* d_edge_xyz, size_t edge_stride,

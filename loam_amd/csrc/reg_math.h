@@ -106,7 +106,10 @@ LOAMX_HD uint32_t grid_cell_of_point(const GridDesc& g, Vec3 p) {
   return (uint32_t)((iz * g.ny + iy) * g.nx + ix);
 }
 
-constexpr uint32_t kGridLdsCells = 32768;  // cells counted per pass of grid_build_kernel (LDS table)
+#ifndef LOAMX_GRID_LDS_CELLS
+#define LOAMX_GRID_LDS_CELLS 32768
+#endif
+constexpr uint32_t kGridLdsCells = LOAMX_GRID_LDS_CELLS;  // cells counted per pass of grid_build_kernel (LDS table)
 constexpr uint32_t kGridCellsCap = 65536;  // cells of one target grid (two build passes)
 constexpr uint32_t kGridPad = 4;           // spare GridPoint entries after every sorted set (unclamped 4-wide candidate loads)
 

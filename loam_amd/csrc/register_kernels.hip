@@ -34,7 +34,10 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
-constexpr int kBuildThreads = 1024;
+#ifndef LOAMX_BUILD_THREADS
+#define LOAMX_BUILD_THREADS 1024
+#endif
+constexpr int kBuildThreads = LOAMX_BUILD_THREADS;
 
 // One workgroup builds the whole index of one target set: bounding box, cell size, counting sort by
 // cell with the cell table in LDS (128 KiB), exclusive scan, scatter. Deterministic in everything
