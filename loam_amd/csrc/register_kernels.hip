@@ -42,11 +42,30 @@ constexpr int kBuildThreads = LOAMX_BUILD_THREADS;
 // One workgroup builds the whole index of one target set: bounding box, cell size, counting sort by
 // cell with the cell table in LDS (128 KiB), exclusive scan, scatter. Deterministic in everything
 // but the order of points inside a cell, which the search does not depend on.
-template <bool ORDERED>
+// PACKED (sets of at most kGridSmallCap points: every scan-sized set): two 16-bit cell counters per LDS word (the
+// table is 64 KiB; counts and offsets stay below 65 536, so a half never carries into its neighbour), and the
+// rest of the LDS holds the cell order as a list of 16-bit point indices. The scatter then is an LDS write
+// (s_inv[position] = index) and the points leave the workgroup in one COALESCED pass over the finished order
+// (gather of 24 bytes from the L2-resident input, 32-byte GridPoint + the float copies written in sequence).
+// Measured per workgroup before: the scattered 2 x 16-byte global stores per point took 52-68 us of the
+// build's 110-135 us and the float-copy pass another 14-30 us. ORDERED sets get their reproducible order in LDS
+// as well (rank among the cell mates -> second list), which replaces the scratch copy and grid_rank_kernel.
+constexpr uint32_t kGridSmallCap = 20480;
+template <bool ORDERED, bool PACKED>
 __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double* __restrict__ pts_base,
                                                                    const uint32_t* __restrict__ n_pts, size_t stride,
                                                                    uint32_t in_pitch, double max_dist, GridSet gs, GridPoint* __restrict__ scratch) {
-  __shared__ uint32_t s_cells[kGridLdsCells];
+  __shared__ uint32_t s_cells[PACKED ? kGridLdsCells / 2 : kGridLdsCells];
+  auto cell_get = [&](uint32_t c) -> uint32_t { return PACKED ? (s_cells[c >> 1] >> ((c & 1u) * 16u)) & 0xFFFFu : s_cells[c]; };
+  auto cell_add = [&](uint32_t c) -> uint32_t {  // returns the value before the increment
+    if (PACKED) {
+      const uint32_t sh = (c & 1u) * 16u;
+      return (atomicAdd(&s_cells[c >> 1], 1u << sh) >> sh) & 0xFFFFu;
+    }
+    return atomicAdd(&s_cells[c], 1u);
+  };
+  __shared__ uint16_t s_inv[PACKED ? kGridSmallCap : 1];
+  __shared__ uint16_t s_inv2[(PACKED && ORDERED) ? kGridSmallCap : 1];
   __shared__ double s_red[6][kBuildThreads / 64];
   __shared__ uint32_t s_wave_sum[kBuildThreads / 64];
   __shared__ GridDesc s_g;
@@ -55,6 +74,14 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
   const uint32_t n_raw = n_pts[pair * in_pitch];
   const uint32_t n = n_raw < stride ? n_raw : (uint32_t)stride;
   const double* __restrict__ pts = pts_base + pair * in_pitch * stride * 3;
+#ifdef LOAMX_BUILD_PROFILE
+  unsigned long long stamp[12];
+  int ns = 0;
+#define STAMP() do { __syncthreads(); stamp[ns++] = wall_clock64(); } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+  STAMP();
 
   double lx = kDblMax, ly = kDblMax, lz = kDblMax, hx = -kDblMax, hy = -kDblMax, hz = -kDblMax;
 #pragma unroll 4
@@ -63,6 +90,7 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
     lx = fmin(lx, x), ly = fmin(ly, y), lz = fmin(lz, z);
     hx = fmax(hx, x), hy = fmax(hy, y), hz = fmax(hz, z);
   }
+  STAMP();  // bbox loads
   lx = wave_min(lx), ly = wave_min(ly), lz = wave_min(lz);
   hx = wave_max(hx), hy = wave_max(hy), hz = wave_max(hz);
   if (lane == 0) {
@@ -84,6 +112,7 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
   }
   __syncthreads();
   const GridDesc g = s_g;
+  STAMP();  // grid choice
   const uint32_t ncell = (uint32_t)(g.nx * g.ny * g.nz);
   uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
   GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
@@ -96,22 +125,28 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
   uint32_t carry = 0;
   for (uint32_t c_lo = 0; c_lo < ncell; c_lo += kGridLdsCells) {
     const uint32_t nc = ncell - c_lo < kGridLdsCells ? ncell - c_lo : kGridLdsCells;
-    for (uint32_t c = tid; c < nc; c += kBuildThreads) s_cells[c] = 0;
+    for (uint32_t c = tid; c < (PACKED ? (nc + 1) / 2 : nc); c += kBuildThreads) s_cells[c] = 0;
     __syncthreads();
 #pragma unroll 4
     for (uint32_t i = tid; i < n; i += kBuildThreads) {
       const Vec3 pt = v3(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]);
       const uint32_t cell = (ORDERED ? grid_morton_of_point(g, pt) : grid_cell_of_point(g, pt)) - c_lo;
-      if (cell < nc) atomicAdd(&s_cells[cell], 1u);
+      if (cell < nc) (void)cell_add(cell);
     }
     __syncthreads();
+    STAMP();  // clear + count
     // exclusive scan of s_cells[0..nc): contiguous chunk per thread + block scan of chunk sums.
     // The chunk length is odd, so the 64 lanes of a wavefront walk 64 different LDS banks (an even
     // length such as 32 would put every lane on the same bank).
-    const uint32_t per = ((nc + kBuildThreads - 1) / kBuildThreads) | 1u;
+    // (PACKED: an odd number of WORDS per chunk, i.e. chunks start on word boundaries and never share a word)
+    const uint32_t per = PACKED ? 2u * (((nc + 2 * kBuildThreads - 1) / (2 * kBuildThreads)) | 1u) : ((nc + kBuildThreads - 1) / kBuildThreads) | 1u;
     const uint32_t c0 = tid * per < nc ? tid * per : nc, c1 = c0 + per < nc ? c0 + per : nc;
     uint32_t local = 0;
-    for (uint32_t c = c0; c < c1; c++) local += s_cells[c];
+    if (PACKED) {
+      for (uint32_t w = c0 >> 1; 2 * w < c1; w++) local += (s_cells[w] & 0xFFFFu) + (s_cells[w] >> 16);  // (a half past nc is 0)
+    } else {
+      for (uint32_t c = c0; c < c1; c++) local += s_cells[c];
+    }
     uint32_t incl = local;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -125,29 +160,69 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
     uint32_t pass_total = 0;
     for (int w = 0; w < kBuildThreads / 64; w++) pass_total += s_wave_sum[w];
     uint32_t run = wave_off + incl - local;
-    for (uint32_t c = c0; c < c1; c++) {
-      const uint32_t cnt = s_cells[c];
-      s_cells[c] = run;
-      run += cnt;
+    if (PACKED) {
+      for (uint32_t w = c0 >> 1; 2 * w < c1; w++) {
+        const uint32_t v = s_cells[w], lo = v & 0xFFFFu, hi = v >> 16;
+        s_cells[w] = run | ((run + lo) << 16);
+        run += lo + hi;
+      }
+    } else {
+      for (uint32_t c = c0; c < c1; c++) {
+        const uint32_t cnt = s_cells[c];
+        s_cells[c] = run;
+        run += cnt;
+      }
     }
     __syncthreads();
-    for (uint32_t c = tid; c < nc; c += kBuildThreads) cs[c_lo + c] = s_cells[c];  // coalesced copy of the scan
+    STAMP();  // scan
+    for (uint32_t c = tid; c < nc; c += kBuildThreads) cs[c_lo + c] = cell_get(c);  // coalesced copy of the scan
     __syncthreads();
+    STAMP();  // table write
 #pragma unroll 4
     for (uint32_t i = tid; i < n; i += kBuildThreads) {
       const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
       const uint32_t cell = (ORDERED ? grid_morton_of_point(g, v3(x, y, z)) : grid_cell_of_point(g, v3(x, y, z))) - c_lo;
       if (cell < nc) {
-        const uint32_t pos = atomicAdd(&s_cells[cell], 1u);
-        dst[pos] = GridPoint{x, y, z, i, 0u};
-
+        const uint32_t pos = cell_add(cell);
+        if (PACKED) s_inv[pos] = (uint16_t)i;
+        else dst[pos] = GridPoint{x, y, z, i, 0u};
       }
     }
     carry += pass_total;
     __syncthreads();
+    STAMP();  // scatter
   }
   if (tid == 0) cs[ncell] = n;
-  if (!ORDERED && gs.rel) {
+  if (PACKED) {
+    const uint16_t* order = s_inv;
+    if (ORDERED) {
+      // reproducible order inside a cell: position = cell begin + number of cell mates with a smaller index
+      // (one pass of the LDS table: ncell <= kGridLdsCells for Morton grids; the cursors now hold the cell ends).
+      // The cell of a list entry is recomputed from the point (an L2 hit); keeping the cells in LDS and ranking
+      // in place from registers was measured slower (1.42 vs 1.21 ms per step), and one thread sorting each
+      // cell's segment far slower still (wall cells hold hundreds of points).
+      for (uint32_t p = tid; p < n; p += kBuildThreads) {
+        const uint32_t i = s_inv[p];
+        const Vec3 pt = v3(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]);
+        const uint32_t cell = grid_morton_of_point(g, pt);
+        const uint32_t b = cell ? cell_get(cell - 1) : 0u, en = cell_get(cell);
+        uint32_t rank = 0;
+        for (uint32_t j = b; j < en; j++) rank += s_inv[j] < i ? 1u : 0u;
+        s_inv2[b + rank] = (uint16_t)i;
+      }
+      __syncthreads();
+      order = s_inv2;
+    }
+    STAMP();  // rank
+    float* __restrict__ rel = gs.rel ? gs.rel + pair * 3 * gs.stride : nullptr;
+#pragma unroll 4
+    for (uint32_t p = tid; p < n; p += kBuildThreads) {
+      const uint32_t i = order[p];
+      const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+      sp[p] = GridPoint{x, y, z, i, 0u};
+      if (!ORDERED && rel) rel[p] = (float)(x - g.ox), rel[gs.stride + p] = (float)(y - g.oy), rel[2 * gs.stride + p] = (float)(z - g.oz);
+    }
+  } else if (!ORDERED && gs.rel) {
     // single-precision offsets from the grid origin, SoA (FP32 pre-selection of the k-NN): one coalesced
     // pass over the finished cell order instead of three scattered 4-byte writes per point
     __syncthreads();
@@ -158,6 +233,13 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
       rel[p] = (float)(e.x - g.ox), rel[gs.stride + p] = (float)(e.y - g.oy), rel[2 * gs.stride + p] = (float)(e.z - g.oz);
     }
   }
+#ifdef LOAMX_BUILD_PROFILE
+  STAMP();
+  if (tid == 0 && pair == 700 && n > 2000 && ns >= 8)
+    printf("build ORDERED=%d n=%u ncell=%u ns=%d: bbox %llu choice %llu count %llu scan %llu table %llu scatter %llu rank %llu out %llu (x10 ns)\n", (int)ORDERED, n, ncell, ns,
+           stamp[1] - stamp[0], stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4], stamp[6] - stamp[5], stamp[ns - 2] - stamp[ns - 3], stamp[ns - 1] - stamp[ns - 2]);
+#endif
+#undef STAMP
 }
 
 // Second half of the ORDERED build (source sets): every point of the scratch copy is placed at
@@ -997,26 +1079,35 @@ inline unsigned per_pair_grid(size_t n_pairs) { return (unsigned)((n_pairs + 63)
 
 }  // namespace
 
+// scan-sized sets (the capacity bounds the count) take the packed cell table + LDS lists
+static bool grid_small(size_t stride) { return stride <= kGridSmallCap && !getenv("LOAMX_NO_PACKED_GRID"); }
+template <bool ORDERED>
+static void launch_grid_build(size_t n_pairs, const double* pts, const uint32_t* n_pts, size_t stride, uint32_t in_pitch,
+                              double max_dist, const GridSet& gs, GridPoint* scratch, hipStream_t s) {
+  if (grid_small(stride))
+    hipLaunchKernelGGL((grid_build_kernel<ORDERED, true>), dim3((unsigned)n_pairs), dim3(kBuildThreads), 0, s, pts, n_pts, stride,
+                       in_pitch, max_dist, gs, scratch);
+  else
+    hipLaunchKernelGGL((grid_build_kernel<ORDERED, false>), dim3((unsigned)n_pairs), dim3(kBuildThreads), 0, s, pts, n_pts, stride,
+                       in_pitch, max_dist, gs, scratch);
+}
+
 void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   if (B.n_pairs == 0) return;
-  hipLaunchKernelGGL(grid_build_kernel<false>, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.tgt_edge, B.n_tgt_edge,
-                     B.edge_stride, B.in_pitch, C.r_edge, B.grid_edge, (GridPoint*)nullptr);
-  hipLaunchKernelGGL(grid_build_kernel<false>, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.tgt_planar,
-                     B.n_tgt_planar, B.planar_stride, B.in_pitch, C.r_plane, B.grid_plane, (GridPoint*)nullptr);
+  launch_grid_build<false>(B.n_pairs, B.tgt_edge, B.n_tgt_edge, B.edge_stride, B.in_pitch, C.r_edge, B.grid_edge, nullptr, s);
+  launch_grid_build<false>(B.n_pairs, B.tgt_planar, B.n_tgt_planar, B.planar_stride, B.in_pitch, C.r_plane, B.grid_plane, nullptr, s);
 }
 
 // source sets: only the cell-sorted (Morton) order is used
 void launch_grid_build_sources(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   if (B.n_pairs == 0) return;
   // (the scratch copy is shared: build + rank of one set complete before the next set's build starts)
-  hipLaunchKernelGGL(grid_build_kernel<true>, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.src_edge, B.n_src_edge,
-                     B.edge_stride, B.in_pitch, C.r_edge, B.src_grid_edge, B.sort_scratch);
-  if (B.edge_stride)
+  launch_grid_build<true>(B.n_pairs, B.src_edge, B.n_src_edge, B.edge_stride, B.in_pitch, C.r_edge, B.src_grid_edge, B.sort_scratch, s);
+  if (B.edge_stride && !grid_small(B.edge_stride))
     hipLaunchKernelGGL(grid_rank_kernel, dim3((unsigned)((B.edge_stride + kRankThreads - 1) / kRankThreads), (unsigned)B.n_pairs),
                        dim3(kRankThreads), 0, s, B.n_src_edge, B.edge_stride, B.in_pitch, B.src_grid_edge, B.sort_scratch);
-  hipLaunchKernelGGL(grid_build_kernel<true>, dim3((unsigned)B.n_pairs), dim3(kBuildThreads), 0, s, B.src_planar,
-                     B.n_src_planar, B.planar_stride, B.in_pitch, C.r_plane, B.src_grid_plane, B.sort_scratch);
-  if (B.planar_stride)
+  launch_grid_build<true>(B.n_pairs, B.src_planar, B.n_src_planar, B.planar_stride, B.in_pitch, C.r_plane, B.src_grid_plane, B.sort_scratch, s);
+  if (B.planar_stride && !grid_small(B.planar_stride))
     hipLaunchKernelGGL(grid_rank_kernel, dim3((unsigned)((B.planar_stride + kRankThreads - 1) / kRankThreads), (unsigned)B.n_pairs),
                        dim3(kRankThreads), 0, s, B.n_src_planar, B.planar_stride, B.in_pitch, B.src_grid_plane,
                        B.sort_scratch);
