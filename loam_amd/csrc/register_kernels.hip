@@ -65,7 +65,8 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
     return atomicAdd(&s_cells[c], 1u);
   };
   __shared__ uint16_t s_inv[PACKED ? kGridSmallCap : 1];
-  __shared__ uint16_t s_inv2[(PACKED && ORDERED) ? kGridSmallCap : 1];
+  __shared__ uint16_t s_cellof[PACKED ? kGridSmallCap : 1];  // cell of every point (count + scatter phases) ...
+  uint16_t* s_inv2 = s_cellof;                               // ... then the ranked list of ORDERED sets
   __shared__ double s_red[6][kBuildThreads / 64];
   __shared__ uint32_t s_wave_sum[kBuildThreads / 64];
   __shared__ GridDesc s_g;
@@ -123,15 +124,29 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
   // The LDS table holds kGridLdsCells cells; larger grids are built in passes over cell ranges
   // (every pass re-reads the points; the running total carries the exclusive scan across passes).
   uint32_t carry = 0;
+  if (PACKED) {  // the cell of every point, once (ncell <= 65 536): the count and scatter phases then run from LDS
+#pragma unroll 4
+    for (uint32_t i = tid; i < n; i += kBuildThreads) {
+      const Vec3 pt = v3(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]);
+      s_cellof[i] = (uint16_t)(ORDERED ? grid_morton_of_point(g, pt) : grid_cell_of_point(g, pt));
+    }
+  }
   for (uint32_t c_lo = 0; c_lo < ncell; c_lo += kGridLdsCells) {
     const uint32_t nc = ncell - c_lo < kGridLdsCells ? ncell - c_lo : kGridLdsCells;
     for (uint32_t c = tid; c < (PACKED ? (nc + 1) / 2 : nc); c += kBuildThreads) s_cells[c] = 0;
     __syncthreads();
+    if (PACKED) {
+      for (uint32_t i = tid; i < n; i += kBuildThreads) {
+        const uint32_t cell = (uint32_t)s_cellof[i] - c_lo;
+        if (cell < nc) (void)cell_add(cell);
+      }
+    } else {
 #pragma unroll 4
-    for (uint32_t i = tid; i < n; i += kBuildThreads) {
-      const Vec3 pt = v3(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]);
-      const uint32_t cell = (ORDERED ? grid_morton_of_point(g, pt) : grid_cell_of_point(g, pt)) - c_lo;
-      if (cell < nc) (void)cell_add(cell);
+      for (uint32_t i = tid; i < n; i += kBuildThreads) {
+        const Vec3 pt = v3(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]);
+        const uint32_t cell = (ORDERED ? grid_morton_of_point(g, pt) : grid_cell_of_point(g, pt)) - c_lo;
+        if (cell < nc) (void)cell_add(cell);
+      }
     }
     __syncthreads();
     STAMP();  // clear + count
@@ -178,14 +193,17 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
     for (uint32_t c = tid; c < nc; c += kBuildThreads) cs[c_lo + c] = cell_get(c);  // coalesced copy of the scan
     __syncthreads();
     STAMP();  // table write
+    if (PACKED) {
+      for (uint32_t i = tid; i < n; i += kBuildThreads) {
+        const uint32_t cell = (uint32_t)s_cellof[i] - c_lo;
+        if (cell < nc) s_inv[cell_add(cell)] = (uint16_t)i;
+      }
+    } else {
 #pragma unroll 4
-    for (uint32_t i = tid; i < n; i += kBuildThreads) {
-      const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
-      const uint32_t cell = (ORDERED ? grid_morton_of_point(g, v3(x, y, z)) : grid_cell_of_point(g, v3(x, y, z))) - c_lo;
-      if (cell < nc) {
-        const uint32_t pos = cell_add(cell);
-        if (PACKED) s_inv[pos] = (uint16_t)i;
-        else dst[pos] = GridPoint{x, y, z, i, 0u};
+      for (uint32_t i = tid; i < n; i += kBuildThreads) {
+        const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+        const uint32_t cell = (ORDERED ? grid_morton_of_point(g, v3(x, y, z)) : grid_cell_of_point(g, v3(x, y, z))) - c_lo;
+        if (cell < nc) dst[cell_add(cell)] = GridPoint{x, y, z, i, 0u};
       }
     }
     carry += pass_total;
