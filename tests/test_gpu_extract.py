@@ -161,3 +161,52 @@ def test_fp32_scan_pairs_equal_fp64_pipeline_on_widened_scans():
     assert (a.view(capi.RESULT_DTYPE)["iterations"] > 0).all()
     for buf in (d32, d64, r32, r64):
         buf.free()
+
+
+def test_fused_and_unfused_compaction_agree(oracle, monkeypatch):
+    """The selection kernel writes the final feature arrays itself (chained scan over the lines of a scan) when
+    number_sectors <= 64; otherwise, and with LOAMX_NO_FUSED_COMPACT=1, compact_kernel does. All three routes
+    must give the oracle's sequences."""
+    H, W = 64, 1024
+    xyz = capi.synth_scan_host(31, 0, 0, H, W, 0.01)
+    lidar = capi.LidarParams(H, W, 1.0, 120.0)
+    for params in [(3, 6, 10, 50, 100.0, 1.0, 0.5, 1.0), (3, 80, 2, 3, 100.0, 1.0, 0.5, 1.0), (2, 64, 1, 4, 50.0, 1.0, 0.5, 1.0)]:
+        ofe = oracle.FeParams(*params)
+        fe = capi.FeatureExtractionParams(*params)
+        se, sp, _ = oracle.extract_features(xyz, H, W, 1.0, 120.0, ofe, stable=True)
+        monkeypatch.delenv("LOAMX_NO_FUSED_COMPACT", raising=False)
+        e1, p1 = ctx().extract_features(xyz, lidar, fe)
+        monkeypatch.setenv("LOAMX_NO_FUSED_COMPACT", "1")
+        e2, p2 = ctx().extract_features(xyz, lidar, fe)
+        monkeypatch.delenv("LOAMX_NO_FUSED_COMPACT", raising=False)
+        assert np.array_equal(e1, se) and np.array_equal(p1, sp), params
+        assert np.array_equal(e2, se) and np.array_equal(p2, sp), params
+
+
+def test_batch_extract_many_scans_fused_offsets(oracle):
+    """Many scans in one launch: every scan's chained scan is independent of its neighbours' (counts, indices and
+    point copies of all scans against the oracle)."""
+    H, W, ns = 16, 512, 40
+    N = H * W
+    c = ctx()
+    lidar, fe = capi.LidarParams(H, W, 1.0, 120.0), capi.FeatureExtractionParams()
+    scans = np.stack([capi.synth_scan_host(100 + s, 0, s & 1, H, W, 0.01) for s in range(ns)])
+    d_xyz = c.alloc(scans.nbytes)
+    d_xyz.upload(scans)
+    ecap, pcap = c.edge_capacity(lidar, fe), c.planar_capacity(lidar, fe)
+    d_ei, d_pi = c.alloc(ns * ecap * 4), c.alloc(ns * pcap * 4)
+    d_ne, d_np = c.alloc(ns * 4), c.alloc(ns * 4)
+    d_ex, d_px = c.alloc(ns * ecap * 24), c.alloc(ns * pcap * 24)
+    c.extract_features_batch_dev(d_xyz.ptr, ns, lidar, fe, d_ei.ptr, d_ne.ptr, d_ex.ptr, d_pi.ptr, d_np.ptr, d_px.ptr)
+    c.synchronize()
+    ne, npl = d_ne.download(np.uint32, ns), d_np.download(np.uint32, ns)
+    ei = d_ei.download(np.uint32, ns * ecap).reshape(ns, ecap)
+    pi = d_pi.download(np.uint32, ns * pcap).reshape(ns, pcap)
+    px = d_px.download(np.float64, ns * pcap * 3).reshape(ns, pcap, 3)
+    for s in range(ns):
+        oe, op = oracle.extract_features(scans[s], H, W, 1.0, 120.0)
+        assert ne[s] == len(oe) and npl[s] == len(op)
+        assert np.array_equal(ei[s, :ne[s]], oe) and np.array_equal(pi[s, :npl[s]], op)
+        assert np.array_equal(px[s, :npl[s]], scans[s][op])
+    for b in (d_xyz, d_ei, d_pi, d_ne, d_np, d_ex, d_px):
+        b.free()
