@@ -202,6 +202,51 @@ __device__ __forceinline__ uint64_t shfl_next(uint64_t v, int lane) {
   return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
 }
 
+// v of lane (l ^ J) without the LDS pipe: DPP quad / row operations inside a row of 16 lanes, gfx950's
+// v_permlane16_swap / v_permlane32_swap across rows (patterns checked on the device by tools/probes/dpp_xor.hip).
+template <int J>
+__device__ __forceinline__ int xor_lane_b32(int v, int lane) {
+  if constexpr (J == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+  else if constexpr (J == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+  else if constexpr (J == 4) {
+    const int t = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0x5, false);  // row_shl:4: quads 0, 2 take lane + 4
+    return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xF, 0xA, false);         // row_shr:4: quads 1, 3 take lane - 4
+  } else if constexpr (J == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true);  // row_ror:8
+  else if constexpr (J == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // r[0] = rows [v0 v0 v2 v2], r[1] = [v1 v1 v3 v3]
+    return (lane & 16) ? r[0] : r[1];
+  } else {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // r[0] = halves [lo lo], r[1] = [hi hi]
+    return (lane & 32) ? r[0] : r[1];
+  }
+}
+// inclusive prefix sum over the 64 lanes in six DPP adds: row_shr 1, 2, 4, 8 inside a row, row_bcast15 / row_bcast31
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
+  int v = (int)x;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);  // (lanes without a source add 0)
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);  // row_bcast15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);  // row_bcast31 -> rows 2, 3
+  return (uint32_t)v;
+}
+
+template <int J>
+__device__ __forceinline__ double xor_lane_f64(double v, int lane) {
+  return __hiloint2double(xor_lane_b32<J>(__double2hiint(v), lane), xor_lane_b32<J>(__double2loint(v), lane));
+}
+__device__ __forceinline__ double xor_lane_f64(double v, int j, int lane) {  // j: a constant after unrolling
+  switch (j) {
+    case 1: return xor_lane_f64<1>(v, lane);
+    case 2: return xor_lane_f64<2>(v, lane);
+    case 4: return xor_lane_f64<4>(v, lane);
+    case 8: return xor_lane_f64<8>(v, lane);
+    case 16: return xor_lane_f64<16>(v, lane);
+    default: return xor_lane_f64<32>(v, lane);
+  }
+}
+
 template <bool EDGE>
 __device__ __forceinline__ bool before_or_invalid(double ca, int32_t ia, double cb, int32_t ib) {
   if (ia < 0) return false;  // padding sorts last
@@ -232,13 +277,8 @@ __device__ __forceinline__ uint32_t mis_pass(int lane, int CH, int base, int sta
   } while (__ballot(U != 0) != 0);
   // compact the picks into LDS slots (at most 64 by construction of the launch condition)
   const uint32_t cnt = (uint32_t)__popcll(Pk);
-  uint32_t incl = cnt;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t t = __shfl_up(incl, off);
-    if (lane >= off) incl += t;
-  }
-  const uint32_t total = __shfl(incl, 63);
+  const uint32_t incl = wave_incl_scan_u32(cnt);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   uint32_t slot = incl - cnt;
   for (uint64_t bits = Pk; bits; bits &= bits - 1) {
     const int j = __ffsll((unsigned long long)bits) - 1;
@@ -270,7 +310,7 @@ __device__ __forceinline__ uint32_t mis_pass(int lane, int CH, int base, int sta
         if ((uint32_t)k > n2) break;  // wave-uniform
 #pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
-          const double other = __shfl_xor(key, j);
+          const double other = xor_lane_f64(key, j, lane);
           const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
           double mn, mx;
           asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(key), "v"(other));
@@ -280,7 +320,7 @@ __device__ __forceinline__ uint32_t mis_pass(int lane, int CH, int base, int sta
       }
     }
     // neighbours in the sorted order with the same truncated curvature: undecided by the keys
-    const double nxt = __shfl_down(key, 1);
+    const double nxt = __longlong_as_double((long long)shfl_next((uint64_t)__double_as_longlong(key), lane));  // lane + 1 (DPP)
     const bool both = (uint32_t)lane + 1 < total;
     const bool same = both && __double2hiint(key) == __double2hiint(nxt) &&
                       (((uint32_t)__double2loint(key) ^ (uint32_t)__double2loint(nxt)) & ~idx_mask) == 0u;
@@ -307,8 +347,10 @@ __device__ __forceinline__ uint32_t mis_pass(int lane, int CH, int base, int sta
   // which of my picks survive the cap: those not after the last kept one
   uint64_t K = Pk;
   if (kept < total) {
-    const double tc = __shfl(c, (int)kept - 1);
-    const int32_t ti = __shfl(i, (int)kept - 1);
+    // (kept is wave-uniform: scalar lane reads)
+    const double tc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(c), (int)kept - 1),
+                                       __builtin_amdgcn_readlane(__double2loint(c), (int)kept - 1));
+    const int32_t ti = __builtin_amdgcn_readlane(i, (int)kept - 1);
     K = 0;
     for (uint64_t bits = Pk; bits; bits &= bits - 1) {
       const int j = __ffsll((unsigned long long)bits) - 1;
@@ -421,13 +463,9 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
   // ---- fused compaction -----------------------------------------------------------------------------
   const uint32_t li = (uint32_t)(line % P.H);
   const size_t scan = line / P.H;
-  uint32_t e_incl = my_ne, p_incl = my_np;  // inclusive scans over the sectors (lane s = sector s)
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t te = __shfl_up(e_incl, off), tp = __shfl_up(p_incl, off);
-    if (lane >= off) e_incl += te, p_incl += tp;
-  }
-  const uint32_t E_l = __shfl(e_incl, 63), P_l = __shfl(p_incl, 63);
+  // inclusive scans over the sectors (lane s = sector s)
+  const uint32_t e_incl = wave_incl_scan_u32(my_ne), p_incl = wave_incl_scan_u32(my_np);
+  const uint32_t E_l = (uint32_t)__builtin_amdgcn_readlane((int)e_incl, 63), P_l = (uint32_t)__builtin_amdgcn_readlane((int)p_incl, 63);
   if (lane == 0)
     __hip_atomic_store(fz.line_tot + line, (1ull << 63) | ((unsigned long long)E_l << 32) | (unsigned long long)P_l,
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -451,8 +489,10 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
       const bool in = s < P.S;
       const int sl = in ? (int)s : 0;
       const size_t group = line * P.S + (size_t)sl;
-      const uint32_t ce = __shfl(my_ne, sl), cp = __shfl(my_np, sl);
-      off[2 * b] = __shfl(e_incl, sl) - ce + (uint32_t)lane, off[2 * b + 1] = __shfl(p_incl, sl) - cp + (uint32_t)lane;
+      // (sl is wave-uniform: scalar lane reads)
+      const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)my_ne, sl), cp = (uint32_t)__builtin_amdgcn_readlane((int)my_np, sl);
+      off[2 * b] = (uint32_t)__builtin_amdgcn_readlane((int)e_incl, sl) - ce + (uint32_t)lane;
+      off[2 * b + 1] = (uint32_t)__builtin_amdgcn_readlane((int)p_incl, sl) - cp + (uint32_t)lane;
       on[2 * b] = in && (uint32_t)lane < ce, on[2 * b + 1] = in && (uint32_t)lane < cp;
       // (a lane reads what it wrote itself in mis_pass)
       idx[2 * b] = on[2 * b] ? st.edge_stage[group * P.cap_edge + lane] : 0u;
@@ -487,10 +527,9 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
           }
         }
         gave_up = gave_up || !(t >> 63);
-        uint32_t se = (uint32_t)(t >> 32) & 0x7FFFFFFFu, sp = (uint32_t)t;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) se += __shfl_xor(se, o), sp += __shfl_xor(sp, o);
-        base_e += se, base_p += sp;
+        const uint32_t se = (uint32_t)(t >> 32) & 0x7FFFFFFFu, sp = (uint32_t)t;
+        base_e += (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(se), 63);
+        base_p += (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(sp), 63);
       }
       if (__ballot(gave_up) != 0) {  // uniform
         if (lane == 0) atomicOr(fz.error, 1u);
