@@ -401,7 +401,7 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
       TimedScope t(ctx, LOAMX_K_LM, 0.0);
       launch_lm_begin(B, C, it, s);
     }
-    {
+    if (it > 0) {  // the first ICF iteration streams its records (state_init: stream_planes = 1, use_moments = 0)
       TimedScope t(ctx, LOAMX_K_MOMENT, 0.0);
       launch_moments(B, s);
     }
