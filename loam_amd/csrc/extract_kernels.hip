@@ -98,6 +98,130 @@ __global__ __launch_bounds__(kCurvThreads) void curvature_valid_kernel(const T* 
   }
 }
 
+// The same kernel for a compile-time neighbor_points, restructured around the LDS pipe (PMC on the kernel above:
+// VALU 58 %, LDS 60 % busy, and float input — a third fewer HBM bytes — ran no faster): the tile is kept as three
+// coordinate arrays, every thread owns TWO adjacent columns and reads the 2 NP + 2 values its two sums share as
+// 16-byte pairs (NP = 3: 5 ds_read_b128 per coordinate for two points instead of 2 x 7 ds_read_b64), and writes
+// both results with one 16-byte + one 2-byte store. Arithmetic and its order are those of curvature_at.
+constexpr int kCurvTilesPerGroup = 2;  // tiles one workgroup walks (the next tile's loads fly during this tile's arithmetic)
+
+template <int NP, typename T>
+__global__ __launch_bounds__(kCurvThreads) void curvature_valid2_kernel(const T* __restrict__ xyz, ExtractParams P,
+                                                               double* __restrict__ curv_out,
+                                                               uint8_t* __restrict__ mask_out) {
+  static_assert(kTile == 2 * kCurvThreads, "two columns per thread");
+  constexpr int np = NP, halo = NP + 1;
+  constexpr int hp = (halo + 1) & ~1;        // local index of the tile's first column: even, >= halo
+  constexpr int A = (NP + 1) & ~1;           // the pairs read start A columns before the thread's first column
+  constexpr int kPairs = (A + NP + 3) / 2;   // ... and cover li0 - A .. li0 + NP + 1
+  constexpr int kLoc = kTile + 2 * hp;
+  constexpr int kWords = (kLoc + 63) / 64 + 1;
+  constexpr int kLoads = ((kTile + 2 * halo) * 3 + kCurvThreads - 1) / kCurvThreads;  // elements per thread and tile
+  __shared__ __align__(16) double s_p[3][kLoc];
+  __shared__ double s_r[kLoc];
+  __shared__ unsigned long long s_bits[4][kWords];  // range / occlusion 1 / occlusion 2 / parallel
+  const int tid = threadIdx.x;
+  const size_t line = blockIdx.x;  // scan * H + line
+  const int W = (int)P.W;
+  const T* __restrict__ g = xyz + line * (size_t)W * 3;
+  const int t_first = (int)blockIdx.y * kCurvTilesPerGroup * kTile;
+
+  // the tile (+halo) as registers: element k of the row-major points, coalesced 8-byte loads (16-byte loads of
+  // element pairs were measured slower: 1.03 vs 0.95 ms — the pair straddles two coordinate arrays)
+  T regs[kLoads];
+  auto fetch = [&](int t0) {
+    const int lo = t0 - halo > 0 ? t0 - halo : 0;
+    const int hi = t0 + kTile + halo < W ? t0 + kTile + halo : W;
+    const int nd = (hi - lo) * 3;
+#pragma unroll
+    for (int q = 0; q < kLoads; q++) {
+      const int k = tid + q * kCurvThreads;
+      regs[q] = k < nd ? g[(size_t)lo * 3 + k] : (T)0;
+    }
+  };
+  fetch(t_first);
+#pragma unroll 1
+  for (int tt = 0; tt < kCurvTilesPerGroup; tt++) {
+    const int t0 = t_first + tt * kTile;
+    if (t0 >= W) break;  // uniform
+    const int base = t0 - hp;  // column of local index 0
+    const int lo = t0 - halo > 0 ? t0 - halo : 0;
+    const int hi = t0 + kTile + halo < W ? t0 + kTile + halo : W;
+    {  // element k goes to coordinate k % 3 of point k / 3
+      const int nd = (hi - lo) * 3;
+#pragma unroll
+      for (int q = 0; q < kLoads; q++) {
+        const int k = tid + q * kCurvThreads;
+        if (k < nd) {
+          const uint32_t pt = __umulhi((uint32_t)k, 0x55555556u);  // k / 3
+          s_p[(uint32_t)k - 3u * pt][lo - base + (int)pt] = (double)regs[q];
+        }
+      }
+    }
+    __syncthreads();
+    if (tt + 1 < kCurvTilesPerGroup && t0 + kTile < W) fetch(t0 + kTile);  // in flight until the next trip
+    for (int c = lo + tid; c < hi; c += kCurvThreads) {
+      const int li = c - base;
+      s_r[li] = point_range(s_p[0][li], s_p[1][li], s_p[2][li]);
+    }
+    __syncthreads();
+    {
+      const int clo = t0 - np > 0 ? t0 - np : 0;
+      const int chi = t0 + kTile + np < W ? t0 + kTile + np : W;
+      for (int l0 = 0; l0 < kWords * 64; l0 += kCurvThreads) {  // whole wavefronts: the ballots below need every lane
+        const int li = l0 + tid, c = base + li;
+        uint8_t code = kCodeNone;
+        if (c >= clo && c < chi && !is_line_end((uint32_t)c, P.W, (uint32_t)np)) code = point_code(s_r[li - 1], s_r[li], s_r[li + 1], P);
+        const unsigned long long b1 = __ballot(code == kCodeRange), b2 = __ballot(code == kCodeOcc1);
+        const unsigned long long b3 = __ballot(code == kCodeOcc2), b4 = __ballot(code == kCodeParallel);
+        const int w = li >> 6;
+        if ((tid & 63) == 0 && w < kWords) s_bits[0][w] = b1, s_bits[1][w] = b2, s_bits[2][w] = b3, s_bits[3][w] = b4;
+      }
+    }
+    __syncthreads();
+    const int c0 = t0 + 2 * tid, li0 = hp + 2 * tid;
+    if (c0 < W) {
+      double d[2][3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        double w[2 * kPairs];
+#pragma unroll
+        for (int q = 0; q < kPairs; q++) {
+          const double2 v = *reinterpret_cast<const double2*>(&s_p[a][li0 - A + 2 * q]);
+          w[2 * q] = v.x, w[2 * q + 1] = v.y;
+        }
+#pragma unroll
+        for (int col = 0; col < 2; col++) {  // features-inl.h:73-82, the order of curvature_at
+          double acc = -(2.0 * np) * w[A + col];
+#pragma unroll
+          for (int n = 1; n <= NP; n++) acc = acc + w[A + col - n] + w[A + col + n];
+          d[col][a] = acc;
+        }
+      }
+      double cv[2];
+      bool ok[2];
+#pragma unroll
+      for (int col = 0; col < 2; col++) {
+        const int c = c0 + col, li = li0 + col;
+        const bool end = c >= W || is_line_end((uint32_t)c, P.W, (uint32_t)np);
+        cv[col] = end ? -1.0 : d[col][0] * d[col][0] + d[col][1] * d[col][1] + d[col][2] * d[col][2];
+        // code 1 at j clears j-np..j+np, code 2 j+1..j+np, code 3 j-(np-1)..j, code 4 j (extract_math.h)
+        ok[col] = !end && !code_window(s_bits[0], li - np, 2 * np + 1) && !code_window(s_bits[1], li - np, np) &&
+                  !code_window(s_bits[2], li, np) && !code_window(s_bits[3], li, 1);
+      }
+      const size_t o = line * (size_t)W + c0;
+      if (c0 + 1 < W && (W & 1) == 0) {  // both columns, aligned
+        *reinterpret_cast<double2*>(curv_out + o) = make_double2(cv[0], cv[1]);
+        *reinterpret_cast<uint16_t*>(mask_out + o) = (uint16_t)((ok[0] ? 1u : 0u) | (ok[1] ? 0x100u : 0u));
+      } else {
+        curv_out[o] = cv[0], mask_out[o] = ok[0] ? 1 : 0;
+        if (c0 + 1 < W) curv_out[o + 1] = cv[1], mask_out[o + 1] = ok[1] ? 1 : 0;
+      }
+    }
+    __syncthreads();  // the arrays are rewritten by the next trip
+  }
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
   // LDS operations of one wavefront complete in issue order; this only stops the compiler from
   // moving LDS accesses across the point where lanes exchange data through LDS.
@@ -659,7 +783,12 @@ __global__ __launch_bounds__(256) void compact_kernel(const T* __restrict__ xyz,
 template <typename T>
 static void launch_curvature_valid_t(const T* d_xyz, const dim3& grid, const ExtractParams& P, double* d_curv, uint8_t* d_mask,
                                      hipStream_t s) {
-  if (P.np == 3)  // the reference's default neighbor_points (features.h:40)
+  if (P.np == 3 && !getenv("LOAMX_CURV_V1")) {  // the reference's default neighbor_points (features.h:40)
+    const dim3 grid2(grid.x, (P.W + kCurvTilesPerGroup * kTile - 1) / (kCurvTilesPerGroup * kTile));
+    hipLaunchKernelGGL((curvature_valid2_kernel<3, T>), grid2, dim3(kCurvThreads), 0, s, d_xyz, P, d_curv, d_mask);
+    return;
+  }
+  if (P.np == 3)
     hipLaunchKernelGGL((curvature_valid_kernel<3, T>), grid, dim3(kCurvThreads), 0, s, d_xyz, P, d_curv, d_mask);
   else
     hipLaunchKernelGGL((curvature_valid_kernel<0, T>), grid, dim3(kCurvThreads), 0, s, d_xyz, P, d_curv, d_mask);
