@@ -939,21 +939,22 @@ __global__ __launch_bounds__(64) void lm_step_kernel(RegBatch B) {  // one wavef
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int kMomLdsRow = 65;  // 64 records + 1: the 16 rows of a tile start in different banks
 
-__global__ __launch_bounds__(kSweepThreads) void moment_kernel(RegBatch B) {
-  __shared__ double s_c[kSweepThreads / 64][kMomStride][kMomLdsRow];
-  const size_t pair = blockIdx.x / B.mom_blocks_per_pair;
-  const uint32_t blk = blockIdx.x % B.mom_blocks_per_pair;
+__global__ __launch_bounds__(64) void moment_kernel(RegBatch B) {  // one wavefront per workgroup: wavefronts share nothing
+  __shared__ double s_c[kMomStride][kMomLdsRow];
+  const int wave = (int)(blockIdx.x & 3u), lane = (int)threadIdx.x;  // the wavefront's place in its chunk of kSweepChunk slots
+  const int tix = wave * 64 + lane;
+  const size_t pair = (blockIdx.x >> 2) / B.mom_blocks_per_pair;
+  const uint32_t blk = (blockIdx.x >> 2) % B.mom_blocks_per_pair;
   const PairState& S = B.state[pair];
   if (!S.active || !S.lm.active || !S.use_moments) return;  // uniform per workgroup
   const uint32_t n_sp_raw = B.n_src_planar[pair * B.in_pitch];
   const uint32_t n_sp = n_sp_raw < B.planar_stride ? n_sp_raw : (uint32_t)B.planar_stride;
   const uint32_t base = blk * kSweepChunk;
   if (base >= n_sp) return;  // uniform per workgroup
-  if (blk == 0 && threadIdx.x == 0 && B.sweep_slots) atomicAdd(&B.sweep_slots[4], (unsigned long long)n_sp);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (blk == 0 && tix == 0 && B.sweep_slots) atomicAdd(&B.sweep_slots[4], (unsigned long long)n_sp);
   const size_t pfield = B.n_pairs * B.planar_stride;
   const double* __restrict__ Pl = B.assoc.plane + pair * B.planar_stride;
-  double(*tile)[kMomLdsRow] = s_c[wave];
+  double(*tile)[kMomLdsRow] = s_c;
 #pragma unroll
   for (int j = kMomDim; j < kMomStride; j++) tile[j][lane] = 0.0;  // padding rows
   v4f64 acc = {0.0, 0.0, 0.0, 0.0};
@@ -973,10 +974,10 @@ __global__ __launch_bounds__(kSweepThreads) void moment_kernel(RegBatch B) {
     return R;
   };
   constexpr int kIters = kSweepChunk / kSweepThreads;  // sub-chunks of 256 records (64 per wavefront)
-  Rec cur = load_rec(base + threadIdx.x);
+  Rec cur = load_rec(base + tix);
 #pragma unroll 1
   for (int it = 0; it < kIters; it++) {
-    const Rec nxt = (it + 1 < kIters) ? load_rec(base + (it + 1) * kSweepThreads + threadIdx.x) : Rec{{0, 0, 0, 0, 0, 0, 0}, false};
+    const Rec nxt = (it + 1 < kIters) ? load_rec(base + (it + 1) * kSweepThreads + tix) : Rec{{0, 0, 0, 0, 0, 0, 0}, false};
     double c[kMomDim];
 #pragma unroll
     for (int j = 0; j < kMomDim; j++) c[j] = 0.0;
@@ -999,7 +1000,7 @@ __global__ __launch_bounds__(kSweepThreads) void moment_kernel(RegBatch B) {
     // (the tile and the list are private to the wavefront: no workgroup barrier in this loop, only the ordering
     // of this wavefront's own LDS traffic)
     const unsigned long long fm = __ballot(flagged);
-    if (flagged) flist[n_flagged + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = base + it * kSweepThreads + threadIdx.x;
+    if (flagged) flist[n_flagged + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = base + it * kSweepThreads + tix;
     n_flagged += (uint32_t)__popcll(fm);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1217,7 +1218,7 @@ void launch_sweep_light(const RegBatch& B, hipStream_t s) {
 
 void launch_moments(const RegBatch& B, hipStream_t s) {
   if (B.n_pairs == 0 || B.mom_blocks_per_pair == 0) return;
-  hipLaunchKernelGGL(moment_kernel, dim3((unsigned)(B.n_pairs * B.mom_blocks_per_pair)), dim3(kSweepThreads), 0, s, B);
+  hipLaunchKernelGGL(moment_kernel, dim3((unsigned)(B.n_pairs * B.mom_blocks_per_pair * 4)), dim3(64), 0, s, B);
   hipLaunchKernelGGL(moment_finish_kernel, dim3((unsigned)B.n_pairs), dim3(kMomSize), 0, s, B);
 }
 
