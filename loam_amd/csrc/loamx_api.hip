@@ -45,6 +45,9 @@ struct loamx_ctx {
   hipStream_t own_stream = nullptr, stream = nullptr;
   hipStream_t aux_stream = nullptr;  // edge association chain, forked from / joined into `stream` with the two events
   hipEvent_t ev_fork = nullptr, ev_mid = nullptr, ev_join = nullptr;
+  hipEvent_t ev_counts = nullptr;     // marks the read-back of the largest source set sizes (register_dev)
+  hipStream_t aux2_stream = nullptr;  // the plane queue chain (so that it does not wait behind the edge chain)
+  hipEvent_t ev_join2 = nullptr;
   std::string last_error;
   Buf ws[WS_COUNT];
   uint32_t* h_pinned = nullptr;  // small pinned readback area
@@ -371,7 +374,18 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   B.assoc_slots = B.sweep_slots + 2;
   B.iter_info = want_iter_info ? wsp<loamx_iter_info>(ctx, WS_ITERINFO) : nullptr;
   B.want_nearest = hook ? 1u : 0u;
+  B.max_counts = wsp<uint32_t>(ctx, WS_COUNTERS) + 12;  // bytes 48..56
+  B.assoc_blocks_edge = B.assoc_blocks_plane = 0xFFFFFFFFu;
   hipStream_t s = ctx->stream;
+  // The per-pair state first: its kernel also finds the largest source sets, which come back to the host while
+  // the index builds run (an event right behind the copy: the builds are already queued when the host waits).
+  untimed(ctx);
+  HIP_TRY(ctx, hipMemsetAsync(B.max_counts, 0, 2 * sizeof(uint32_t), s));
+  launch_state_init(B, C, s);
+  CHECK_LAUNCH(ctx, "state_init_kernel");
+  if (!ctx->ev_counts) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_counts, hipEventDisableTiming));
+  HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_pinned[4], B.max_counts, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_counts, s));
 
   if (prebuilt) {  // persistent target index: only the source sets are (re)ordered
     B.grid_edge = GridSet{prebuilt->desc[0], prebuilt->cells[0], prebuilt->sorted[0], prebuilt->cap[0] + kGridPad, prebuilt->rel[0]};
@@ -383,13 +397,13 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
     launch_grid_build_sources(B, C, s);
   }
   CHECK_LAUNCH(ctx, "grid_build_kernel");
-  untimed(ctx);
-  launch_state_init(B, C, s);
-  CHECK_LAUNCH(ctx, "state_init_kernel");
+  HIP_TRY(ctx, hipEventSynchronize(ctx->ev_counts));
+  B.assoc_blocks_edge = (ctx->h_pinned[4] + 255u) / 256u;   // kAssocThreads queries per workgroup
+  B.assoc_blocks_plane = (ctx->h_pinned[5] + 255u) / 256u;
   for (uint32_t it = 0; it < C.max_iterations; it++) {
     {
       TimedScope t(ctx, LOAMX_K_ASSOC, 0.0);
-      launch_associate(B, C, s, ctx->aux_stream, ctx->ev_fork, ctx->ev_mid, ctx->ev_join);
+      launch_associate(B, C, s, ctx->aux_stream, ctx->aux2_stream, ctx->ev_fork, ctx->ev_mid, ctx->ev_join, ctx->ev_join2);
     }
     CHECK_LAUNCH(ctx, "associate_kernel");
     if (hook) {
@@ -512,6 +526,12 @@ int loamx_ctx_create(int device, loamx_ctx** out) {
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
       (void)hipStreamDestroy(ctx->aux_stream);
       ctx->aux_stream = nullptr;
+    } else if (!getenv("LOAMX_NO_AUX2_STREAM") &&
+               hipStreamCreateWithPriority(&ctx->aux2_stream, hipStreamNonBlocking, getenv("LOAMX_AUX_NORMAL_PRIO") ? prio_least : prio_greatest) == hipSuccess) {
+      if (hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming) != hipSuccess) {
+        (void)hipStreamDestroy(ctx->aux2_stream);
+        ctx->aux2_stream = nullptr;
+      }
     }
   }
   *out = ctx;
@@ -534,6 +554,12 @@ void loamx_ctx_destroy(loamx_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->aux_stream);
     (void)hipStreamDestroy(ctx->aux_stream);
   }
+  if (ctx->aux2_stream) {
+    (void)hipStreamSynchronize(ctx->aux2_stream);
+    (void)hipStreamDestroy(ctx->aux2_stream);
+  }
+  if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
+  if (ctx->ev_counts) (void)hipEventDestroy(ctx->ev_counts);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);

@@ -144,14 +144,17 @@ struct RegBatch {
                                     // [2,3] assoc_slots; [4] plane slots streamed by the moment pass
   unsigned long long* assoc_slots;  // [2] edge / plane source features processed by associate_kernel
   loamx_iter_info* iter_info;  // optional [n_pairs][max_iterations]
+  uint32_t* max_counts;   // [2] largest source edge / planar count over the pairs (state_init_kernel; read back by the host)
+  uint32_t assoc_blocks_edge, assoc_blocks_plane;  // workgroups per pair of the association kernels; 0xFFFFFFFF = by capacity
   uint32_t want_nearest;  // 1: a detail hook will read nearest_* (RegistrationDetail pairs); 0: the fit kernels skip that write
 };
 
 void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_grid_build_sources(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_state_init(const RegBatch& B, const RegConfig& C, hipStream_t s);
-void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipStream_t aux, hipEvent_t ev_fork,
-                      hipEvent_t ev_mid, hipEvent_t ev_join);  // aux == nullptr: everything on s
+// aux == nullptr: everything on s; aux2 == nullptr: the plane queue chain follows the edge chain on aux
+void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipStream_t aux, hipStream_t aux2, hipEvent_t ev_fork,
+                      hipEvent_t ev_mid, hipEvent_t ev_join, hipEvent_t ev_join2);
 void launch_lm_begin(const RegBatch& B, const RegConfig& C, uint32_t iteration, hipStream_t s);
 void launch_sweep(const RegBatch& B, hipStream_t s);
 void launch_sweep_light(const RegBatch& B, hipStream_t s);

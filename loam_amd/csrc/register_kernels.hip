@@ -300,6 +300,11 @@ __global__ void state_init_kernel(RegBatch B, RegConfig C) {
   S.use_moments = 0;
   S.lm.active = 0;
   for (int c = 0; c < 6; c++) B.assoc.n_assoc[8 * pair + c] = 0;
+  if (B.max_counts) {  // the host sizes the association grids by the largest set instead of by the capacity
+    const uint32_t ne = B.n_src_edge[pair * B.in_pitch], np = B.n_src_planar[pair * B.in_pitch];
+    atomicMax(&B.max_counts[0], ne < B.edge_stride ? ne : (uint32_t)B.edge_stride);
+    atomicMax(&B.max_counts[1], np < B.planar_stride ? np : (uint32_t)B.planar_stride);
+  }
 }
 
 constexpr int kAssocThreads = 256;
@@ -1148,11 +1153,11 @@ static uint32_t rest_blocks(size_t n_pairs, uint32_t nblk) {
   if (want < LOAMX_REST_BLOCKS) want = LOAMX_REST_BLOCKS;
   return want < cover ? want : cover;
 }
-void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipStream_t aux, hipEvent_t ev_fork,
-                      hipEvent_t ev_mid, hipEvent_t ev_join) {
+void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipStream_t aux, hipStream_t aux2, hipEvent_t ev_fork,
+                      hipEvent_t ev_mid, hipEvent_t ev_join, hipEvent_t ev_join2) {
   if (B.n_pairs == 0) return;
-  const uint32_t be = (uint32_t)((B.edge_stride + kAssocThreads - 1) / kAssocThreads);
-  const uint32_t bp = (uint32_t)((B.planar_stride + kAssocThreads - 1) / kAssocThreads);
+  const uint32_t be = B.assoc_blocks_edge != 0xFFFFFFFFu ? B.assoc_blocks_edge : (uint32_t)((B.edge_stride + kAssocThreads - 1) / kAssocThreads);
+  const uint32_t bp = B.assoc_blocks_plane != 0xFFFFFFFFu ? B.assoc_blocks_plane : (uint32_t)((B.planar_stride + kAssocThreads - 1) / kAssocThreads);
   const size_t pair_groups = (B.n_pairs + 7) / 8;  // grid covers 8 XCD lanes x pair_groups x chunks
   // register-resident neighbour lists are instantiated for K <= 5 (the reference's default) and K <= 8
   // Per feature kind, two chains: A = brute force (small target sets) | round-1 k-NN -> fit of the
@@ -1194,9 +1199,14 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
   }
   if (bp) {
     LOAMX_ASSOC_K(LOAMX_ASSOC_A1, true, bp, s);
-    const bool fork2 = fork && hipEventRecord(ev_mid, s) == hipSuccess && hipStreamWaitEvent(aux, ev_mid, 0) == hipSuccess;
+    // the plane queue chain starts when the plane round-1 kernel is done: on its own stream when there is one
+    // (behind the edge chain on aux it started only after the plane fit: the edge kernels' many empty workgroups
+    // wait for slots next to the plane kernels)
+    hipStream_t sb = aux2 ? aux2 : aux;
+    const bool fork2 = fork && hipEventRecord(ev_mid, s) == hipSuccess && hipStreamWaitEvent(sb, ev_mid, 0) == hipSuccess;
     LOAMX_ASSOC_K(LOAMX_ASSOC_A2, true, bp, s);
-    LOAMX_ASSOC_K(LOAMX_ASSOC_B, true, bp, (fork2 ? aux : s));
+    LOAMX_ASSOC_K(LOAMX_ASSOC_B, true, bp, (fork2 ? sb : s));
+    if (fork2 && aux2 && hipEventRecord(ev_join2, aux2) == hipSuccess) (void)hipStreamWaitEvent(s, ev_join2, 0);
   }
   if (fork && hipEventRecord(ev_join, aux) == hipSuccess) (void)hipStreamWaitEvent(s, ev_join, 0);
 #undef LOAMX_ASSOC_A1
