@@ -406,6 +406,9 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
       launch_associate(B, C, s, ctx->aux_stream, ctx->aux2_stream, ctx->ev_fork, ctx->ev_mid, ctx->ev_join, ctx->ev_join2);
     }
     CHECK_LAUNCH(ctx, "associate_kernel");
+#ifdef LOAMX_NN_SAME_STATS
+    debug_nn_same(B, it, s);
+#endif
     if (hook) {
       untimed(ctx);
       int rc = hook(ctx, B, it, hook_user);

@@ -155,6 +155,9 @@ void launch_state_init(const RegBatch& B, const RegConfig& C, hipStream_t s);
 // aux == nullptr: everything on s; aux2 == nullptr: the plane queue chain follows the edge chain on aux
 void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipStream_t aux, hipStream_t aux2, hipEvent_t ev_fork,
                       hipEvent_t ev_mid, hipEvent_t ev_join, hipEvent_t ev_join2);
+#ifdef LOAMX_NN_SAME_STATS
+void debug_nn_same(const RegBatch& B, uint32_t it, hipStream_t s);
+#endif
 void launch_lm_begin(const RegBatch& B, const RegConfig& C, uint32_t iteration, hipStream_t s);
 void launch_sweep(const RegBatch& B, hipStream_t s);
 void launch_sweep_light(const RegBatch& B, hipStream_t s);

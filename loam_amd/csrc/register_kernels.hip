@@ -1215,6 +1215,39 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
 #undef LOAMX_ASSOC_K
 }
 
+#ifdef LOAMX_NN_SAME_STATS
+// debug aid: how many plane queries keep their neighbour list (count + positions, in order) from one ICF iteration to the next?
+__global__ void nn_same_kernel(RegBatch B, uint32_t* prev, unsigned long long* stats, uint32_t it) {
+  const size_t pair = blockIdx.y;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = B.n_src_planar[pair * B.in_pitch];
+  if (i >= n || i >= B.planar_stride || !B.state[pair].active) return;
+  const size_t field = B.n_pairs * B.planar_stride, slot = pair * B.planar_stride + i;
+  bool same = it > 0, queued = B.assoc.nn_plane[slot] == 0xFFFFFFFFu;
+  for (int f = 0; f < 6; f++) {
+    const uint32_t v = B.assoc.nn_plane[f * field + slot];
+    if (prev[f * field + slot] != v) same = false;
+    prev[f * field + slot] = v;
+  }
+  atomicAdd(&stats[0], 1ull);
+  if (same && !queued) atomicAdd(&stats[1], 1ull);
+  if (queued) atomicAdd(&stats[2], 1ull);
+}
+void debug_nn_same(const RegBatch& B, uint32_t it, hipStream_t s) {
+  static uint32_t* prev = nullptr;
+  static unsigned long long* stats = nullptr;
+  const size_t words = 6 * B.n_pairs * B.planar_stride;
+  if (!prev) { (void)hipMalloc(&prev, words * 4); (void)hipMalloc(&stats, 24); }
+  (void)hipMemsetAsync(stats, 0, 24, s);
+  hipLaunchKernelGGL(nn_same_kernel, dim3((unsigned)((B.planar_stride + 255) / 256), (unsigned)B.n_pairs), dim3(256), 0, s, B, prev, stats, it);
+  unsigned long long h[3];
+  (void)hipMemcpyAsync(h, stats, 24, hipMemcpyDeviceToHost, s);
+  (void)hipStreamSynchronize(s);
+  printf("nn_same it=%u: %llu active plane queries, %llu keep their list (%.1f %%), %llu queued (%.1f %%)\n", it, h[0], h[1],
+         100.0 * (double)h[1] / (double)(h[0] ? h[0] : 1), h[2], 100.0 * (double)h[2] / (double)(h[0] ? h[0] : 1));
+}
+#endif
+
 void launch_sweep(const RegBatch& B, hipStream_t s) {
   if (B.n_pairs == 0 || B.blocks_per_pair == 0) return;
   hipLaunchKernelGGL(sweep_kernel, dim3((unsigned)(B.n_pairs * B.blocks_per_pair)), dim3(kSweepThreads), 0, s, B);
