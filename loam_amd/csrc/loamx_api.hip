@@ -71,6 +71,7 @@ struct loamx_target_index {
   size_t cap[2] = {0, 0};                       // points the buffers above hold without growing
   double radius[2] = {0, 0};
   uint32_t* counts = nullptr;                   // device copy of n[] for the build kernels
+  void* scratch = nullptr;                      // kGridBigScratchBytes for the multi-workgroup build
 };
 
 namespace {
@@ -822,6 +823,7 @@ void index_free(loamx_target_index* idx) {
     if (idx->pts[k]) (void)hipFree(idx->pts[k]);
   }
   if (idx->counts) (void)hipFree(idx->counts);
+  if (idx->scratch) (void)hipFree(idx->scratch);
   delete idx;
 }
 
@@ -865,6 +867,7 @@ int index_build(loamx_ctx* ctx, loamx_target_index* idx) {
   B.edge_stride = idx->cap[0], B.planar_stride = idx->cap[1];
   B.tgt_edge = idx->pts[0], B.tgt_planar = idx->pts[1];
   B.n_tgt_edge = idx->counts, B.n_tgt_planar = idx->counts + 1;
+  B.sort_scratch = static_cast<GridPoint*>(idx->scratch);
   B.grid_edge = GridSet{idx->desc[0], idx->cells[0], idx->sorted[0], idx->cap[0] + kGridPad, idx->rel[0]};
   B.grid_plane = GridSet{idx->desc[1], idx->cells[1], idx->sorted[1], idx->cap[1] + kGridPad, idx->rel[1]};
   untimed(ctx);
@@ -918,7 +921,8 @@ int loamx_target_index_create(loamx_ctx* ctx, const double* tgt_edge, size_t n_t
   if (rc != LOAMX_OK) return rc;
   loamx_target_index* idx = new loamx_target_index;
   idx->radius[0] = C.r_edge, idx->radius[1] = C.r_plane;
-  bool ok = hipMalloc(reinterpret_cast<void**>(&idx->counts), 2 * sizeof(uint32_t)) == hipSuccess;
+  bool ok = hipMalloc(reinterpret_cast<void**>(&idx->counts), 2 * sizeof(uint32_t)) == hipSuccess &&
+            hipMalloc(&idx->scratch, kGridBigScratchBytes) == hipSuccess;
   for (int k = 0; k < 2 && ok; k++)
     ok = hipMalloc(reinterpret_cast<void**>(&idx->desc[k]), sizeof(GridDesc)) == hipSuccess &&
          hipMalloc(reinterpret_cast<void**>(&idx->cells[k]), (size_t)(kGridCellsCap + 1) * sizeof(uint32_t)) == hipSuccess;

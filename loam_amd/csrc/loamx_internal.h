@@ -149,6 +149,8 @@ struct RegBatch {
   uint32_t want_nearest;  // 1: a detail hook will read nearest_* (RegistrationDetail pairs); 0: the fit kernels skip that write
 };
 
+// scratch the multi-workgroup build of a map-sized target set needs per pair (at B.sort_scratch + pair * stride points)
+constexpr size_t kGridBigScratchBytes = 64 + (size_t)kGridCellsCap * sizeof(uint32_t);
 void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_grid_build_sources(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_state_init(const RegBatch& B, const RegConfig& C, hipStream_t s);

@@ -260,6 +260,140 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
 #undef STAMP
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Map-sized target sets (more than kGridSmallCap points: a local map of 10^5 - 10^6 points, BASELINE config 5,
+ * or the planar features of a 128 x 2048 scan): the same counting sort spread over the whole chip — the
+ * single-workgroup kernel above spent 4.4 ms on a 1 M-point map. Bounding box and cell counts go through global
+ * atomics (order-independent integers), the 65 536-entry scan is one workgroup, the scatter takes its position
+ * from a global per-cell cursor. Per pair, the scratch area holds the six box keys and the cursors.
+ * ---------------------------------------------------------------------------------------------- */
+constexpr int kBigThreads = 256, kBigItems = 16, kBigChunk = kBigThreads * kBigItems;
+constexpr size_t kBigScratchBytes = kGridBigScratchBytes;  // per pair: box keys, cursors (loamx_internal.h)
+
+// doubles as unsigned keys with the same order (for atomicMin / atomicMax)
+__device__ __forceinline__ unsigned long long dbl_key(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_dbl(unsigned long long k) {
+  return __longlong_as_double((long long)((k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k));
+}
+__device__ __forceinline__ unsigned char* big_scratch(GridPoint* scratch, size_t pair, size_t stride) {
+  return reinterpret_cast<unsigned char*>(scratch + pair * stride);
+}
+
+__global__ void gridbig_init_kernel(GridPoint* scratch, size_t stride) {
+  unsigned long long* box = reinterpret_cast<unsigned long long*>(big_scratch(scratch, blockIdx.x, stride));
+  if (threadIdx.x < 6) box[threadIdx.x] = threadIdx.x < 3 ? ~0ull : 0ull;  // minima, maxima
+}
+
+__global__ __launch_bounds__(kBigThreads) void gridbig_bbox_kernel(const double* __restrict__ pts_base, const uint32_t* __restrict__ n_pts,
+                                                                   size_t stride, uint32_t in_pitch, GridPoint* scratch) {
+  const size_t pair = blockIdx.y;
+  const uint32_t n_raw = n_pts[pair * in_pitch], n = n_raw < stride ? n_raw : (uint32_t)stride;
+  const uint32_t base = blockIdx.x * kBigChunk;
+  if (base >= n) return;  // uniform
+  const double* __restrict__ pts = pts_base + pair * in_pitch * stride * 3;
+  double lx = kDblMax, ly = kDblMax, lz = kDblMax, hx = -kDblMax, hy = -kDblMax, hz = -kDblMax;
+#pragma unroll 4
+  for (int k = 0; k < kBigItems; k++) {
+    const uint32_t i = base + k * kBigThreads + threadIdx.x;
+    if (i < n) {
+      const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+      lx = fmin(lx, x), ly = fmin(ly, y), lz = fmin(lz, z);
+      hx = fmax(hx, x), hy = fmax(hy, y), hz = fmax(hz, z);
+    }
+  }
+  lx = wave_min(lx), ly = wave_min(ly), lz = wave_min(lz);
+  hx = wave_max(hx), hy = wave_max(hy), hz = wave_max(hz);
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long* box = reinterpret_cast<unsigned long long*>(big_scratch(scratch, pair, stride));
+    atomicMin(&box[0], dbl_key(lx)), atomicMin(&box[1], dbl_key(ly)), atomicMin(&box[2], dbl_key(lz));
+    atomicMax(&box[3], dbl_key(hx)), atomicMax(&box[4], dbl_key(hy)), atomicMax(&box[5], dbl_key(hz));
+  }
+}
+
+__global__ void gridbig_choose_kernel(const uint32_t* __restrict__ n_pts, size_t stride, uint32_t in_pitch, double max_dist,
+                                      GridSet gs, GridPoint* scratch, size_t n_pairs) {
+  const size_t pair = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= n_pairs) return;
+  const uint32_t n_raw = n_pts[pair * in_pitch], n = n_raw < stride ? n_raw : (uint32_t)stride;
+  const unsigned long long* box = reinterpret_cast<const unsigned long long*>(big_scratch(scratch, pair, stride));
+  GridDesc g;
+  grid_choose(g, v3(key_dbl(box[0]), key_dbl(box[1]), key_dbl(box[2])), v3(key_dbl(box[3]), key_dbl(box[4]), key_dbl(box[5])), n, max_dist,
+              kGridCellsCap);
+  gs.desc[pair] = g;
+}
+
+template <bool SCATTER>
+__global__ __launch_bounds__(kBigThreads) void gridbig_pass_kernel(const double* __restrict__ pts_base, const uint32_t* __restrict__ n_pts,
+                                                                   size_t stride, uint32_t in_pitch, GridSet gs, GridPoint* scratch) {
+  const size_t pair = blockIdx.y;
+  const uint32_t n_raw = n_pts[pair * in_pitch], n = n_raw < stride ? n_raw : (uint32_t)stride;
+  const uint32_t base = blockIdx.x * kBigChunk;
+  if (base >= n) return;  // uniform
+  const double* __restrict__ pts = pts_base + pair * in_pitch * stride * 3;
+  const GridDesc g = gs.desc[pair];
+  // count: into the cell table itself; scatter: positions from the cursors (a copy of the scanned table)
+  uint32_t* __restrict__ table = SCATTER ? reinterpret_cast<uint32_t*>(big_scratch(scratch, pair, stride) + 64)
+                                         : gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
+  GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
+#pragma unroll 4
+  for (int k = 0; k < kBigItems; k++) {
+    const uint32_t i = base + k * kBigThreads + threadIdx.x;
+    if (i < n) {
+      const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+      const uint32_t pos = atomicAdd(&table[grid_cell_of_point(g, v3(x, y, z))], 1u);
+      if (SCATTER) sp[pos] = GridPoint{x, y, z, i, 0u};
+    }
+  }
+}
+
+// exclusive scan of the cell counts of one pair (at most 65 536 entries): 64 consecutive entries per thread
+__global__ __launch_bounds__(1024) void gridbig_scan_kernel(const uint32_t* __restrict__ n_pts, size_t stride, uint32_t in_pitch, GridSet gs,
+                                                            GridPoint* scratch) {
+  __shared__ uint32_t s_wave_sum[16];
+  const size_t pair = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t n_raw = n_pts[pair * in_pitch], n = n_raw < stride ? n_raw : (uint32_t)stride;
+  const GridDesc g = gs.desc[pair];
+  const uint32_t ncell = (uint32_t)(g.nx * g.ny * g.nz);
+  uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
+  uint32_t* __restrict__ cursor = reinterpret_cast<uint32_t*>(big_scratch(scratch, pair, stride) + 64);
+  constexpr uint32_t per = kGridCellsCap / 1024;
+  const uint32_t c0 = tid * per;
+  uint32_t local = 0;
+  for (uint32_t c = c0; c < c0 + per && c < ncell; c++) local += cs[c];
+  uint32_t incl = local;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) s_wave_sum[wave] = incl;
+  __syncthreads();
+  uint32_t run = incl - local;
+  for (int w = 0; w < wave; w++) run += s_wave_sum[w];
+  for (uint32_t c = c0; c < c0 + per && c < ncell; c++) {
+    const uint32_t cnt = cs[c];
+    cs[c] = run, cursor[c] = run;
+    run += cnt;
+  }
+  if (tid == 0) cs[ncell] = n;
+}
+
+__global__ __launch_bounds__(kBigThreads) void gridbig_rel_kernel(const uint32_t* __restrict__ n_pts, size_t stride, uint32_t in_pitch,
+                                                                  GridSet gs) {
+  const size_t pair = blockIdx.y;
+  const uint32_t n_raw = n_pts[pair * in_pitch], n = n_raw < stride ? n_raw : (uint32_t)stride;
+  const uint32_t p = blockIdx.x * kBigThreads + threadIdx.x;
+  if (p >= n) return;
+  const GridDesc g = gs.desc[pair];
+  const GridPoint e = gs.sorted[pair * gs.stride + p];
+  float* __restrict__ rel = gs.rel + pair * 3 * gs.stride;
+  rel[p] = (float)(e.x - g.ox), rel[gs.stride + p] = (float)(e.y - g.oy), rel[2 * gs.stride + p] = (float)(e.z - g.oz);
+}
+
 // Second half of the ORDERED build (source sets): every point of the scratch copy is placed at
 // (cell begin + number of cell mates with a smaller original index). A kernel of its own because the
 // pair-wise comparison inside a cell is a latency-bound gather that wants far more waves in flight
@@ -1105,9 +1239,33 @@ inline unsigned per_pair_grid(size_t n_pairs) { return (unsigned)((n_pairs + 63)
 
 // scan-sized sets (the capacity bounds the count) take the packed cell table + LDS lists
 static bool grid_small(size_t stride) { return stride <= kGridSmallCap && !getenv("LOAMX_NO_PACKED_GRID"); }
+// map-sized target sets: the multi-workgroup build (needs kBigScratchBytes of scratch per pair)
+static bool grid_big(size_t stride, const GridPoint* scratch) {
+  return !grid_small(stride) && scratch != nullptr && stride * sizeof(GridPoint) >= kBigScratchBytes && !getenv("LOAMX_NO_BIG_GRID");
+}
+static void launch_grid_build_big(size_t n_pairs, const double* pts, const uint32_t* n_pts, size_t stride, uint32_t in_pitch,
+                                  double max_dist, const GridSet& gs, GridPoint* scratch, hipStream_t s) {
+  const dim3 chunks((unsigned)((stride + kBigChunk - 1) / kBigChunk), (unsigned)n_pairs);
+  hipLaunchKernelGGL(gridbig_init_kernel, dim3((unsigned)n_pairs), dim3(64), 0, s, scratch, stride);
+  hipLaunchKernelGGL(gridbig_bbox_kernel, chunks, dim3(kBigThreads), 0, s, pts, n_pts, stride, in_pitch, scratch);
+  hipLaunchKernelGGL(gridbig_choose_kernel, dim3((unsigned)((n_pairs + 63) / 64)), dim3(64), 0, s, n_pts, stride, in_pitch, max_dist, gs,
+                     scratch, n_pairs);
+  (void)hipMemsetAsync(gs.cell_start, 0, n_pairs * (size_t)(kGridCellsCap + 1) * sizeof(uint32_t), s);
+  hipLaunchKernelGGL(gridbig_pass_kernel<false>, chunks, dim3(kBigThreads), 0, s, pts, n_pts, stride, in_pitch, gs, scratch);
+  hipLaunchKernelGGL(gridbig_scan_kernel, dim3((unsigned)n_pairs), dim3(1024), 0, s, n_pts, stride, in_pitch, gs, scratch);
+  hipLaunchKernelGGL(gridbig_pass_kernel<true>, chunks, dim3(kBigThreads), 0, s, pts, n_pts, stride, in_pitch, gs, scratch);
+  if (gs.rel)
+    hipLaunchKernelGGL(gridbig_rel_kernel, dim3((unsigned)((stride + kBigThreads - 1) / kBigThreads), (unsigned)n_pairs), dim3(kBigThreads), 0,
+                       s, n_pts, stride, in_pitch, gs);
+}
+
 template <bool ORDERED>
 static void launch_grid_build(size_t n_pairs, const double* pts, const uint32_t* n_pts, size_t stride, uint32_t in_pitch,
                               double max_dist, const GridSet& gs, GridPoint* scratch, hipStream_t s) {
+  if (!ORDERED && grid_big(stride, scratch)) {
+    launch_grid_build_big(n_pairs, pts, n_pts, stride, in_pitch, max_dist, gs, scratch, s);
+    return;
+  }
   if (grid_small(stride))
     hipLaunchKernelGGL((grid_build_kernel<ORDERED, true>), dim3((unsigned)n_pairs), dim3(kBuildThreads), 0, s, pts, n_pts, stride,
                        in_pitch, max_dist, gs, scratch);
@@ -1118,8 +1276,8 @@ static void launch_grid_build(size_t n_pairs, const double* pts, const uint32_t*
 
 void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   if (B.n_pairs == 0) return;
-  launch_grid_build<false>(B.n_pairs, B.tgt_edge, B.n_tgt_edge, B.edge_stride, B.in_pitch, C.r_edge, B.grid_edge, nullptr, s);
-  launch_grid_build<false>(B.n_pairs, B.tgt_planar, B.n_tgt_planar, B.planar_stride, B.in_pitch, C.r_plane, B.grid_plane, nullptr, s);
+  launch_grid_build<false>(B.n_pairs, B.tgt_edge, B.n_tgt_edge, B.edge_stride, B.in_pitch, C.r_edge, B.grid_edge, B.sort_scratch, s);
+  launch_grid_build<false>(B.n_pairs, B.tgt_planar, B.n_tgt_planar, B.planar_stride, B.in_pitch, C.r_plane, B.grid_plane, B.sort_scratch, s);
 }
 
 // source sets: only the cell-sorted (Morton) order is used
