@@ -245,3 +245,32 @@ def test_batch_pipeline_is_reproducible_and_batch_size_invariant():
     assert np.array_equal(part, runs[0][first * 64:])
     d_res.free()
     d_xyz.free()
+
+
+def test_scan_pairs_128x2048_use_the_big_set_paths(oracle):
+    """128 x 2048 scans: 39 k planar features per scan, i.e. more than the LDS-list build holds — the target sets
+    go through the multi-workgroup index build (two pairs in one launch), the source sets through the
+    single-workgroup build + rank kernel, and sectors hold more than 64 picks (selection fallback)."""
+    H, W, n_pairs, seed = 128, 2048, 2, 77
+    N = H * W
+    c = ctx()
+    lidar = capi.LidarParams(H, W, 1.0, 120.0)
+    fe, reg = capi.FeatureExtractionParams(), capi.RegistrationParams()
+    d_xyz = c.alloc(n_pairs * 2 * N * 24)
+    d_res = c.alloc(n_pairs * 64)
+    c.synth_scan_pairs_dev(seed, 0, n_pairs, H, W, 0.01, d_xyz.ptr)
+    c.register_scan_pairs_dev(d_xyz.ptr, n_pairs, lidar, fe, reg, d_res.ptr)
+    c.synchronize()
+    res = d_res.download(capi.RESULT_DTYPE, n_pairs)
+    for pr in range(n_pairs):
+        A = capi.synth_scan_host(seed, pr, 0, H, W, 0.01)
+        B = capi.synth_scan_host(seed, pr, 1, H, W, 0.01)
+        ea, pa = oracle.extract_features(A, H, W, 1.0, 120.0)
+        eb, pb = oracle.extract_features(B, H, W, 1.0, 120.0)
+        assert len(pa) > 20480
+        po, to, io = oracle.register_features(B[eb], B[pb], A[ea], A[pa])
+        assert (res[pr]["termination"], res[pr]["iterations"]) == (to, io)
+        rot, trans = pose_diff(oracle, po, res[pr]["pose"])
+        assert rot < SE3_TOL and trans < SE3_TOL, (pr, rot, trans)
+    d_xyz.free()
+    d_res.free()
