@@ -71,7 +71,9 @@ struct loamx_target_index {
   size_t cap[2] = {0, 0};                       // points the buffers above hold without growing
   double radius[2] = {0, 0};
   uint32_t* counts = nullptr;                   // device copy of n[] for the build kernels
-  void* scratch = nullptr;                      // kGridBigScratchBytes for the multi-workgroup build
+  void* scratch = nullptr;                      // box keys + cursors of the multi-workgroup build
+  uint32_t cells_cap[2] = {0, 0};               // 0: kGridCellsCap; map-sized sets own a larger cell table
+  size_t cells_alloc[2] = {0, 0}, scratch_alloc = 0;
 };
 
 namespace {
@@ -389,8 +391,8 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   HIP_TRY(ctx, hipEventRecord(ctx->ev_counts, s));
 
   if (prebuilt) {  // persistent target index: only the source sets are (re)ordered
-    B.grid_edge = GridSet{prebuilt->desc[0], prebuilt->cells[0], prebuilt->sorted[0], prebuilt->cap[0] + kGridPad, prebuilt->rel[0]};
-    B.grid_plane = GridSet{prebuilt->desc[1], prebuilt->cells[1], prebuilt->sorted[1], prebuilt->cap[1] + kGridPad, prebuilt->rel[1]};
+    B.grid_edge = GridSet{prebuilt->desc[0], prebuilt->cells[0], prebuilt->sorted[0], prebuilt->cap[0] + kGridPad, prebuilt->rel[0], prebuilt->cells_cap[0]};
+    B.grid_plane = GridSet{prebuilt->desc[1], prebuilt->cells[1], prebuilt->sorted[1], prebuilt->cap[1] + kGridPad, prebuilt->rel[1], prebuilt->cells_cap[1]};
   }
   {
     TimedScope t(ctx, LOAMX_K_GRID, 0.0);
@@ -867,9 +869,34 @@ int index_build(loamx_ctx* ctx, loamx_target_index* idx) {
   B.edge_stride = idx->cap[0], B.planar_stride = idx->cap[1];
   B.tgt_edge = idx->pts[0], B.tgt_planar = idx->pts[1];
   B.n_tgt_edge = idx->counts, B.n_tgt_planar = idx->counts + 1;
+  // map-sized sets get a cell table of up to kGridMapCellsCap entries (the scan-sized table of 65 536 would put
+  // hundreds of points of a million-point map into every cell); tables and cursors grow with the set
+  size_t scratch_need = kGridBigScratchBytes;
+  for (int k = 0; k < 2; k++) {
+    const char* mc = getenv("LOAMX_MAP_CELLS_LOG2");  // experiment knob (16 = the scan-sized table)
+    idx->cells_cap[k] = idx->n[k] > 200000 ? (mc ? (1u << atoi(mc)) : kGridMapCellsCap) : 0u;
+    if (idx->cells_cap[k] <= kGridCellsCap) idx->cells_cap[k] = 0u;
+    const size_t cap = idx->cells_cap[k] ? idx->cells_cap[k] : kGridCellsCap;
+    const size_t need = (cap + 1) * sizeof(uint32_t);
+    if (idx->cells_alloc[k] < need) {
+      HIP_TRY(ctx, hipStreamSynchronize(s));
+      if (idx->cells[k]) (void)hipFree(idx->cells[k]);
+      idx->cells[k] = nullptr, idx->cells_alloc[k] = 0;
+      HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&idx->cells[k]), need));
+      idx->cells_alloc[k] = need;
+    }
+    if (64 + cap * sizeof(uint32_t) > scratch_need) scratch_need = 64 + cap * sizeof(uint32_t);
+  }
+  if (idx->scratch_alloc < scratch_need) {
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (idx->scratch) (void)hipFree(idx->scratch);
+    idx->scratch = nullptr, idx->scratch_alloc = 0;
+    HIP_TRY(ctx, hipMalloc(&idx->scratch, scratch_need));
+    idx->scratch_alloc = scratch_need;
+  }
   B.sort_scratch = static_cast<GridPoint*>(idx->scratch);
-  B.grid_edge = GridSet{idx->desc[0], idx->cells[0], idx->sorted[0], idx->cap[0] + kGridPad, idx->rel[0]};
-  B.grid_plane = GridSet{idx->desc[1], idx->cells[1], idx->sorted[1], idx->cap[1] + kGridPad, idx->rel[1]};
+  B.grid_edge = GridSet{idx->desc[0], idx->cells[0], idx->sorted[0], idx->cap[0] + kGridPad, idx->rel[0], idx->cells_cap[0]};
+  B.grid_plane = GridSet{idx->desc[1], idx->cells[1], idx->sorted[1], idx->cap[1] + kGridPad, idx->rel[1], idx->cells_cap[1]};
   untimed(ctx);
   {
     TimedScope t(ctx, LOAMX_K_GRID, 0.0);
@@ -921,11 +948,8 @@ int loamx_target_index_create(loamx_ctx* ctx, const double* tgt_edge, size_t n_t
   if (rc != LOAMX_OK) return rc;
   loamx_target_index* idx = new loamx_target_index;
   idx->radius[0] = C.r_edge, idx->radius[1] = C.r_plane;
-  bool ok = hipMalloc(reinterpret_cast<void**>(&idx->counts), 2 * sizeof(uint32_t)) == hipSuccess &&
-            hipMalloc(&idx->scratch, kGridBigScratchBytes) == hipSuccess;
-  for (int k = 0; k < 2 && ok; k++)
-    ok = hipMalloc(reinterpret_cast<void**>(&idx->desc[k]), sizeof(GridDesc)) == hipSuccess &&
-         hipMalloc(reinterpret_cast<void**>(&idx->cells[k]), (size_t)(kGridCellsCap + 1) * sizeof(uint32_t)) == hipSuccess;
+  bool ok = hipMalloc(reinterpret_cast<void**>(&idx->counts), 2 * sizeof(uint32_t)) == hipSuccess;
+  for (int k = 0; k < 2 && ok; k++) ok = hipMalloc(reinterpret_cast<void**>(&idx->desc[k]), sizeof(GridDesc)) == hipSuccess;  // (tables: index_build)
   rc = ok ? index_append(ctx, idx, tgt_edge, n_te, tgt_planar, n_tp) : fail(ctx, LOAMX_ERR_HIP, "hipMalloc failed for the target index");
   if (rc != LOAMX_OK) {
     index_free(idx);

@@ -70,6 +70,8 @@ struct GridSet {
   size_t stride;
   float* rel;            // [n_pairs][3][stride] single-precision offsets of the sorted points from the grid origin
                          // (x plane, y plane, z plane) for the FP32 pre-selection; nullptr for source sets
+  uint32_t cells_cap;    // 0: kGridCellsCap. A persistent index of a map-sized set (one "pair") may own a larger
+                         // cell table: a million-point map at the scan's cell edge puts hundreds of points in a cell
 };
 
 // Association records, structure-of-arrays over the whole batch (field-major) so the residual
@@ -151,6 +153,10 @@ struct RegBatch {
 
 // scratch the multi-workgroup build of a map-sized target set needs per pair (at B.sort_scratch + pair * stride points)
 constexpr size_t kGridBigScratchBytes = 64 + (size_t)kGridCellsCap * sizeof(uint32_t);
+// cell table of a map-sized persistent index. Measured on a 1.02 M-point map (config 5; index build / registration
+// of a 39 k-feature scan): 2^16 cells 1.04 / 6.71 ms, 2^17 1.07 / 5.97, 2^18 1.38 / 5.88, 2^19 1.77 / 5.71,
+// 2^20 2.49 / 5.74, 2^21 4.75 / 8.19 (cells too small for the 5th neighbour: more second rounds)
+constexpr uint32_t kGridMapCellsCap = 1u << 18;
 void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_grid_build_sources(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_state_init(const RegBatch& B, const RegConfig& C, hipStream_t s);

@@ -321,7 +321,7 @@ __global__ void gridbig_choose_kernel(const uint32_t* __restrict__ n_pts, size_t
   const unsigned long long* box = reinterpret_cast<const unsigned long long*>(big_scratch(scratch, pair, stride));
   GridDesc g;
   grid_choose(g, v3(key_dbl(box[0]), key_dbl(box[1]), key_dbl(box[2])), v3(key_dbl(box[3]), key_dbl(box[4]), key_dbl(box[5])), n, max_dist,
-              kGridCellsCap);
+              gs.cells_cap ? gs.cells_cap : kGridCellsCap);
   gs.desc[pair] = g;
 }
 
@@ -335,6 +335,7 @@ __global__ __launch_bounds__(kBigThreads) void gridbig_pass_kernel(const double*
   const double* __restrict__ pts = pts_base + pair * in_pitch * stride * 3;
   const GridDesc g = gs.desc[pair];
   // count: into the cell table itself; scatter: positions from the cursors (a copy of the scanned table)
+  // (a table larger than kGridCellsCap belongs to a single-pair index: the pitch is not used then)
   uint32_t* __restrict__ table = SCATTER ? reinterpret_cast<uint32_t*>(big_scratch(scratch, pair, stride) + 64)
                                          : gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
   GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(kBigThreads) void gridbig_pass_kernel(const double*
   }
 }
 
-// exclusive scan of the cell counts of one pair (at most 65 536 entries): 64 consecutive entries per thread
+// exclusive scan of the cell counts of one pair: tiles of 65 536 entries, 64 consecutive entries per thread
 __global__ __launch_bounds__(1024) void gridbig_scan_kernel(const uint32_t* __restrict__ n_pts, size_t stride, uint32_t in_pitch, GridSet gs,
                                                             GridPoint* scratch) {
   __shared__ uint32_t s_wave_sum[16];
@@ -360,24 +361,32 @@ __global__ __launch_bounds__(1024) void gridbig_scan_kernel(const uint32_t* __re
   const uint32_t ncell = (uint32_t)(g.nx * g.ny * g.nz);
   uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
   uint32_t* __restrict__ cursor = reinterpret_cast<uint32_t*>(big_scratch(scratch, pair, stride) + 64);
-  constexpr uint32_t per = kGridCellsCap / 1024;
-  const uint32_t c0 = tid * per;
-  uint32_t local = 0;
-  for (uint32_t c = c0; c < c0 + per && c < ncell; c++) local += cs[c];
-  uint32_t incl = local;
+  constexpr uint32_t per = 64, tile = per * 1024;
+  uint32_t carry = 0;
+  for (uint32_t t0 = 0; t0 < ncell; t0 += tile) {
+    const uint32_t c0 = t0 + tid * per;
+    uint32_t local = 0;
+    for (uint32_t c = c0; c < c0 + per && c < ncell; c++) local += cs[c];
+    uint32_t incl = local;
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t t = __shfl_up(incl, off);
-    if (lane >= off) incl += t;
-  }
-  if (lane == 63) s_wave_sum[wave] = incl;
-  __syncthreads();
-  uint32_t run = incl - local;
-  for (int w = 0; w < wave; w++) run += s_wave_sum[w];
-  for (uint32_t c = c0; c < c0 + per && c < ncell; c++) {
-    const uint32_t cnt = cs[c];
-    cs[c] = run, cursor[c] = run;
-    run += cnt;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_wave_sum[wave] = incl;
+    __syncthreads();
+    uint32_t run = carry + incl - local, total = 0;
+    for (int w = 0; w < 16; w++) {
+      if (w < wave) run += s_wave_sum[w];
+      total += s_wave_sum[w];
+    }
+    for (uint32_t c = c0; c < c0 + per && c < ncell; c++) {
+      const uint32_t cnt = cs[c];
+      cs[c] = run, cursor[c] = run;
+      run += cnt;
+    }
+    carry += total;
+    __syncthreads();  // s_wave_sum is rewritten by the next tile
   }
   if (tid == 0) cs[ncell] = n;
 }
@@ -1242,7 +1251,7 @@ static bool grid_small(size_t stride) { return stride <= kGridSmallCap && !geten
 // map-sized target sets: the multi-workgroup build (needs kBigScratchBytes of scratch per pair)
 static bool grid_big(size_t stride, const GridPoint* scratch) {
   return !grid_small(stride) && scratch != nullptr && stride * sizeof(GridPoint) >= kBigScratchBytes && !getenv("LOAMX_NO_BIG_GRID");
-}
+}  // (a caller that sets GridSet::cells_cap provides 64 + 4 * cells_cap bytes of scratch and one pair)
 static void launch_grid_build_big(size_t n_pairs, const double* pts, const uint32_t* n_pts, size_t stride, uint32_t in_pitch,
                                   double max_dist, const GridSet& gs, GridPoint* scratch, hipStream_t s) {
   const dim3 chunks((unsigned)((stride + kBigChunk - 1) / kBigChunk), (unsigned)n_pairs);
@@ -1250,7 +1259,7 @@ static void launch_grid_build_big(size_t n_pairs, const double* pts, const uint3
   hipLaunchKernelGGL(gridbig_bbox_kernel, chunks, dim3(kBigThreads), 0, s, pts, n_pts, stride, in_pitch, scratch);
   hipLaunchKernelGGL(gridbig_choose_kernel, dim3((unsigned)((n_pairs + 63) / 64)), dim3(64), 0, s, n_pts, stride, in_pitch, max_dist, gs,
                      scratch, n_pairs);
-  (void)hipMemsetAsync(gs.cell_start, 0, n_pairs * (size_t)(kGridCellsCap + 1) * sizeof(uint32_t), s);
+  (void)hipMemsetAsync(gs.cell_start, 0, (gs.cells_cap ? (size_t)gs.cells_cap + 1 : n_pairs * (size_t)(kGridCellsCap + 1)) * sizeof(uint32_t), s);
   hipLaunchKernelGGL(gridbig_pass_kernel<false>, chunks, dim3(kBigThreads), 0, s, pts, n_pts, stride, in_pitch, gs, scratch);
   hipLaunchKernelGGL(gridbig_scan_kernel, dim3((unsigned)n_pairs), dim3(1024), 0, s, n_pts, stride, in_pitch, gs, scratch);
   hipLaunchKernelGGL(gridbig_pass_kernel<true>, chunks, dim3(kBigThreads), 0, s, pts, n_pts, stride, in_pitch, gs, scratch);
