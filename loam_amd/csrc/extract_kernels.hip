@@ -307,9 +307,15 @@ __global__ __launch_bounds__(WAVES * 64) void select_kernel(const double* __rest
  * shuffle pair for the suppression. Used when np-1 = R in 1..4, R <= CH, CH + 2R <= 64 and a sector
  * can hold at most 64 picks; select_kernel remains the general fallback (identical results).
  * ---------------------------------------------------------------------------------------------- */
-// LDS bytes per wavefront: padded curvature (W + 64 doubles), 64 pick slots (double + int), padded mask
-__host__ __device__ inline size_t select_mis_lds_bytes(int W) {
-  return ((size_t)W + 64) * 8 + 64 * 8 + 64 * 4 + (((size_t)W + 256 + 7) & ~(size_t)7);
+// LDS bytes per wavefront: padded curvature (W + 64 doubles), 64 or 128 pick slots (double + int), padded mask
+__host__ __device__ inline size_t select_mis_lds_bytes(int W, int slots) {
+  return ((size_t)W + 64) * 8 + (size_t)slots * 12 + (((size_t)W + 256 + 7) & ~(size_t)7);
+}
+// picks a sector can yield (they are at least R + 1 points apart): 64 slots, or 128 for the long sectors of
+// 2048-column scans (then only with caps <= 64: the lanes hold the first 64 picks of the order)
+__host__ __device__ inline int select_mis_slots(const ExtractParams& P, int R) {
+  const uint32_t longest = P.W - (P.S - 1) * P.pps;
+  return (longest + (uint32_t)R) / (uint32_t)(R + 1) <= 64u ? 64 : 128;
 }
 // value of the previous / next lane (0 at the wave's ends): one DPP move per dword
 // (wave_shr:1 / wave_shl:1 with bound_ctrl zero fill) instead of an LDS-crossbar ds_bpermute
@@ -378,11 +384,11 @@ __device__ __forceinline__ bool before_or_invalid(double ca, int32_t ia, double 
   return EDGE ? edge_before(ca, ia, cb, ib) : planar_before(ca, ia, cb, ib);
 }
 
-template <int R, bool EDGE>
+template <int R, bool EDGE, bool TWO>
 __device__ __forceinline__ uint32_t mis_pass(int lane, int CH, int base, int start, int end, uint64_t& V, uint64_t T,
                                              const uint64_t gt[R], const double* s_c, double* m_c, int32_t* m_i,
                                              uint32_t cap, uint32_t line_base, uint32_t* __restrict__ stage,
-                                             uint32_t idx_mask, uint32_t ch_magic) {
+                                             uint32_t idx_mask, uint32_t ch_magic, uint32_t slots) {
   const uint64_t cm = low_mask(CH);
   const int pbase = lane * (CH + 1);  // s_c is stored with one spare slot per lane chunk (see select_mis_kernel)
   int lo = start - base, hi = end - base;
@@ -399,71 +405,132 @@ __device__ __forceinline__ uint32_t mis_pass(int lane, int CH, int base, int sta
     Pk |= win;
     U &= ~((mis_spread<R>(Ww) >> R) & cm);
   } while (__ballot(U != 0) != 0);
-  // compact the picks into LDS slots (at most 64 by construction of the launch condition)
+  // compact the picks into LDS slots (at most `slots` = 64 or 128 by construction of the launch condition)
   const uint32_t cnt = (uint32_t)__popcll(Pk);
   const uint32_t incl = wave_incl_scan_u32(cnt);
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   uint32_t slot = incl - cnt;
   for (uint64_t bits = Pk; bits; bits &= bits - 1) {
     const int j = __ffsll((unsigned long long)bits) - 1;
-    if (slot < 64) {
+    if (slot < slots) {
       m_c[slot] = s_c[pbase + j];
       m_i[slot] = base + j;
     }
     slot++;
   }
   wave_lds_sync();
-  double c = (uint32_t)lane < total ? m_c[lane] : 0.0;
-  int32_t i = (uint32_t)lane < total ? m_i[lane] : -1;
+  // lane l holds pick l and, when a long sector yields more than 64 picks (2048-column scans), pick 64 + l
+  const bool two = TWO && total > 64u;  // wave-uniform (TWO: the kernel variant for sectors that can yield more than 64 picks)
+  double c = (uint32_t)lane < total ? m_c[lane] : 0.0, c1 = 0.0;
+  int32_t i = (uint32_t)lane < total ? m_i[lane] : -1, i1 = -1;
+  if (two && 64u + (uint32_t)lane < total) c1 = m_c[64 + lane], i1 = m_i[64 + lane];
   wave_lds_sync();
   // Sort the picks into the walk order of the reference (edge: descending, planar: ascending by
   // (curvature, index)) with a bitonic network over the next power of two >= total lanes.
   // Fast path: curvature and index folded into one double (low index bits replace low mantissa
   // bits; edge keys negated, padding = +inf), so a compare-exchange is v_min_f64 / v_max_f64 on one
-  // shuffled value. Exact unless two picks share a truncated curvature (or a curvature is not
+  // exchanged value. Exact unless two picks share a truncated curvature (or a curvature is not
   // finite): then the network is re-run on the exact (curvature, index) pairs.
+  // More than 64 picks: only the first `cap` <= 64 of the order are ever used, so the first 64 picks are sorted
+  // ascending and the rest descending by the same exchanges; the lane-wise minimum of the two is then the set of
+  // the 64 first picks as a bitonic sequence, which one more merge (6 layers) puts in order.
   if (total > 1) {
-    const uint32_t n2 = total <= 2 ? 2u : (1u << (32 - __clz((int)total - 1)));
-    const bool finite = i < 0 || c <= 1.7976931348623157e308;
-    double key = __hiloint2double(__double2hiint(c), (int)(((uint32_t)__double2loint(c) & ~idx_mask) | (uint32_t)i));
-    key = EDGE ? -key : key;
-    key = i < 0 ? __builtin_huge_val() : key;
-    if (__ballot(!finite) == 0) {
+    const uint32_t n2 = two ? 64u : (total <= 2 ? 2u : (1u << (32 - __clz((int)total - 1))));
+    auto fold = [&](double cc, int32_t ii) {
+      double k = __hiloint2double(__double2hiint(cc), (int)(((uint32_t)__double2loint(cc) & ~idx_mask) | (uint32_t)ii));
+      k = EDGE ? -k : k;
+      return ii < 0 ? __builtin_huge_val() : k;
+    };
+    const bool finite = (i < 0 || c <= 1.7976931348623157e308) && (i1 < 0 || c1 <= 1.7976931348623157e308);
+    double key = fold(c, i), key1 = two ? fold(c1, i1) : __builtin_huge_val();
+    bool undecided = __ballot(!finite) != 0;
+    if (!undecided) {
 #pragma unroll
       for (int k = 2; k <= 64; k <<= 1) {
         if ((uint32_t)k > n2) break;  // wave-uniform
 #pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
-          const double other = xor_lane_f64(key, j, lane);
           const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+          const double other = xor_lane_f64(key, j, lane);
           double mn, mx;
           asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(key), "v"(other));
           asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(key), "v"(other));
           key = keep_min ? mn : mx;
+          if (two) {  // the second half, descending
+            const double o1 = xor_lane_f64(key1, j, lane);
+            asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(key1), "v"(o1));
+            asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(key1), "v"(o1));
+            key1 = keep_min ? mx : mn;
+          }
         }
       }
+      if (two) {
+        double lo, hi;
+        asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(key), "v"(key1));
+        asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(key), "v"(key1));
+        key = lo;
+#pragma unroll
+        for (int j = 32; j > 0; j >>= 1) {  // bitonic -> ascending
+          const double other = xor_lane_f64(key, j, lane);
+          double mn, mx;
+          asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(key), "v"(other));
+          asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(key), "v"(other));
+          key = (lane & j) == 0 ? mn : mx;
+        }
+        // the best of the set-aside picks must be decided against the last kept one too
+#pragma unroll
+        for (int j = 32; j > 0; j >>= 1) {
+          const double other = xor_lane_f64(hi, j, lane);
+          asm("v_min_f64 %0, %1, %2" : "=v"(hi) : "v"(hi), "v"(other));
+        }
+        const double last = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(key), 63), __builtin_amdgcn_readlane(__double2loint(key), 63));
+        if (__double2hiint(last) == __double2hiint(hi) && (((uint32_t)__double2loint(last) ^ (uint32_t)__double2loint(hi)) & ~idx_mask) == 0u)
+          undecided = true;  // (uniform: hi is the same on every lane)
+      }
+      // neighbours in the sorted order with the same truncated curvature: undecided by the keys
+      const double nxt = __longlong_as_double((long long)shfl_next((uint64_t)__double_as_longlong(key), lane));  // lane + 1 (DPP)
+      const bool both = (uint32_t)lane + 1 < (two ? 64u : total);
+      const bool same = both && __double2hiint(key) == __double2hiint(nxt) &&
+                        (((uint32_t)__double2loint(key) ^ (uint32_t)__double2loint(nxt)) & ~idx_mask) == 0u;
+      if (__ballot(same) != 0) undecided = true;
     }
-    // neighbours in the sorted order with the same truncated curvature: undecided by the keys
-    const double nxt = __longlong_as_double((long long)shfl_next((uint64_t)__double_as_longlong(key), lane));  // lane + 1 (DPP)
-    const bool both = (uint32_t)lane + 1 < total;
-    const bool same = both && __double2hiint(key) == __double2hiint(nxt) &&
-                      (((uint32_t)__double2loint(key) ^ (uint32_t)__double2loint(nxt)) & ~idx_mask) == 0u;
-    if (__ballot(!finite) != 0 || __ballot(same) != 0) {
+    if (undecided) {
 #pragma unroll 1
       for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll 1
         for (int j = k >> 1; j > 0; j >>= 1) {
+          const bool keep_first = ((lane & j) == 0) == ((lane & k) == 0);
+          {
+            const double oc = __shfl_xor(c, j);
+            const int32_t oi = __shfl_xor(i, j);
+            const bool other_first = before_or_invalid<EDGE>(oc, oi, c, i);
+            const bool me_first = before_or_invalid<EDGE>(c, i, oc, oi);
+            if (keep_first ? other_first : me_first) c = oc, i = oi;
+          }
+          if (two) {  // the second half in the opposite direction
+            const double oc = __shfl_xor(c1, j);
+            const int32_t oi = __shfl_xor(i1, j);
+            const bool other_first = before_or_invalid<EDGE>(oc, oi, c1, i1);
+            const bool me_first = before_or_invalid<EDGE>(c1, i1, oc, oi);
+            if (keep_first ? me_first : other_first) c1 = oc, i1 = oi;
+          }
+        }
+      }
+      if (two) {
+        if (before_or_invalid<EDGE>(c1, i1, c, i)) c = c1, i = i1;
+#pragma unroll 1
+        for (int j = 32; j > 0; j >>= 1) {
           const double oc = __shfl_xor(c, j);
           const int32_t oi = __shfl_xor(i, j);
-          const bool keep_first = ((lane & j) == 0) == ((lane & k) == 0);
           const bool other_first = before_or_invalid<EDGE>(oc, oi, c, i);
           const bool me_first = before_or_invalid<EDGE>(c, i, oc, oi);
-          if (keep_first ? other_first : me_first) c = oc, i = oi;
+          if ((lane & j) == 0 ? other_first : me_first) c = oc, i = oi;
         }
       }
     } else {
-      i = (uint32_t)lane < total ? (int32_t)((uint32_t)__double2loint(key) & idx_mask) : -1;
-      c = (uint32_t)lane < total ? s_c[i < 0 ? 0 : i + (ch_magic ? (int32_t)__umulhi((uint32_t)i, ch_magic) : i)] : 0.0;
+      const uint32_t have = two ? 64u : total;
+      i = (uint32_t)lane < have ? (int32_t)((uint32_t)__double2loint(key) & idx_mask) : -1;
+      c = (uint32_t)lane < have ? s_c[i < 0 ? 0 : i + (ch_magic ? (int32_t)__umulhi((uint32_t)i, ch_magic) : i)] : 0.0;
     }
   }
   const uint32_t kept = total < cap ? total : cap;  // features-inl.h:155/:177: at most max+1 picks
@@ -503,7 +570,7 @@ __device__ __forceinline__ void fused_copy(const T* __restrict__ scan_xyz, uint3
   dst[0] = (double)scan_xyz[3 * (size_t)idx], dst[1] = (double)scan_xyz[3 * (size_t)idx + 1], dst[2] = (double)scan_xyz[3 * (size_t)idx + 2];
 }
 
-template <int R, int WAVES>
+template <int R, int WAVES, bool TWO>
 __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __restrict__ curv,
                                                                 const uint8_t* __restrict__ mask, size_t n_lines,
                                                                 ExtractParams P, ExtractStage st, ExtractFused fz) {
@@ -515,11 +582,12 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
   // LDS layout: every lane's chunk of CH points is followed by one spare double (4 spare bytes in
   // the mask): with the chunk stride CH (16 for W = 1024) the lanes of a wavefront would all read the
   // same LDS bank when each walks its own chunk; CH + 1 spreads them over all banks.
-  const size_t per_wave = select_mis_lds_bytes(W);
+  constexpr int slots = TWO ? 128 : 64;
+  const size_t per_wave = select_mis_lds_bytes(W, slots);
   double* s_c = reinterpret_cast<double*>(smem + wave * per_wave);
   double* m_c = s_c + W + 64;
-  int32_t* m_i = reinterpret_cast<int32_t*>(m_c + 64);
-  uint8_t* s_v = reinterpret_cast<uint8_t*>(m_i + 64);
+  int32_t* m_i = reinterpret_cast<int32_t*>(m_c + slots);
+  uint8_t* s_v = reinterpret_cast<uint8_t*>(m_i + slots);
   // i / CH == umulhi(i, ch_magic) for i < 2^16 when CH >= 2; ch_magic == 0 stands for CH == 1 (i / CH == i)
   const uint32_t ch_magic = CH > 1 ? 0xFFFFFFFFu / (uint32_t)CH + 1u : 0u;
   for (int i = lane; i < W; i += 64) {
@@ -573,10 +641,10 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
     const int start = (int)(s * P.pps);
     const int end = (s == P.S - 1) ? W : start + (int)P.pps;  // features-inl.h:31-35
     const size_t group = line * P.S + s;
-    const uint32_t ne = mis_pass<R, true>(lane, CH, base, start, end, V, ET, gt, s_c, m_c, m_i, P.cap_edge, line_base,
-                                          st.edge_stage + group * P.cap_edge, idx_mask, ch_magic);
-    const uint32_t npl = mis_pass<R, false>(lane, CH, base, start, end, V, PT, gt, s_c, m_c, m_i, P.cap_planar,
-                                            line_base, st.planar_stage + group * P.cap_planar, idx_mask, ch_magic);
+    const uint32_t ne = mis_pass<R, true, TWO>(lane, CH, base, start, end, V, ET, gt, s_c, m_c, m_i, P.cap_edge, line_base,
+                                          st.edge_stage + group * P.cap_edge, idx_mask, ch_magic, (uint32_t)slots);
+    const uint32_t npl = mis_pass<R, false, TWO>(lane, CH, base, start, end, V, PT, gt, s_c, m_c, m_i, P.cap_planar,
+                                            line_base, st.planar_stage + group * P.cap_planar, idx_mask, ch_magic, (uint32_t)slots);
     if (lane == 0) {
       st.edge_cnt[group] = ne;
       st.planar_cnt[group] = npl;
@@ -804,17 +872,23 @@ void launch_curvature_valid(const void* d_xyz, bool f32, size_t n_scans, const E
 }
 
 
+template <int R, bool TWO>
+static void launch_select_mis2(const double* d_curv, const uint8_t* d_mask, size_t n_lines, const ExtractParams& P,
+                               const ExtractStage& st, const ExtractFused& fz, hipStream_t s) {
+  const size_t per_wave = select_mis_lds_bytes((int)P.W, TWO ? 128 : 64);
+  if (per_wave * 4 <= 48 * 1024) {
+    hipLaunchKernelGGL((select_mis_kernel<R, 4, TWO>), dim3((unsigned)((n_lines + 3) / 4)), dim3(256), per_wave * 4, s, d_curv,
+                       d_mask, n_lines, P, st, fz);
+  } else {
+    hipLaunchKernelGGL((select_mis_kernel<R, 1, TWO>), dim3((unsigned)n_lines), dim3(64), per_wave, s, d_curv, d_mask, n_lines,
+                       P, st, fz);
+  }
+}
 template <int R>
 static void launch_select_mis(const double* d_curv, const uint8_t* d_mask, size_t n_lines, const ExtractParams& P,
                               const ExtractStage& st, const ExtractFused& fz, hipStream_t s) {
-  const size_t per_wave = select_mis_lds_bytes((int)P.W);
-  if (per_wave * 4 <= 48 * 1024) {
-    hipLaunchKernelGGL((select_mis_kernel<R, 4>), dim3((unsigned)((n_lines + 3) / 4)), dim3(256), per_wave * 4, s, d_curv,
-                       d_mask, n_lines, P, st, fz);
-  } else {
-    hipLaunchKernelGGL((select_mis_kernel<R, 1>), dim3((unsigned)n_lines), dim3(64), per_wave, s, d_curv, d_mask, n_lines,
-                       P, st, fz);
-  }
+  if (select_mis_slots(P, R) > 64) launch_select_mis2<R, true>(d_curv, d_mask, n_lines, P, st, fz, s);
+  else launch_select_mis2<R, false>(d_curv, d_mask, n_lines, P, st, fz, s);
 }
 
 bool launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, const ExtractParams& P,
@@ -829,8 +903,10 @@ bool launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, 
   // per sector (picks are >= R+1 points apart), the cap itself at most 64
   const int R = (int)P.np - 1, CH = ((int)P.W + 63) / 64;
   const uint32_t longest = P.W - (P.S - 1) * P.pps;
-  const bool mis_ok = R >= 1 && R <= 4 && CH >= R && CH + 2 * R <= 64 && (longest + R) / (R + 1) <= 64;
-  if (mis_ok) {
+  const uint32_t picks = (longest + R) / (R + 1);  // most picks a sector can yield
+  const bool mis_ok = R >= 1 && R <= 4 && CH >= R && CH + 2 * R <= 64 &&
+                      (picks <= 64 || (picks <= 128 && P.cap_edge <= 64 && P.cap_planar <= 64));
+  if (mis_ok && !getenv("LOAMX_NO_MIS_SELECT")) {
     switch (R) {
       case 1: launch_select_mis<1>(d_curv, d_mask, n_lines, P, st, fz, s); return fuse;
       case 2: launch_select_mis<2>(d_curv, d_mask, n_lines, P, st, fz, s); return fuse;
