@@ -77,11 +77,20 @@ def test_dropouts_and_out_of_range(oracle):
     assert np.array_equal(e, se) and np.array_equal(p, sp)
 
 
-def test_tie_policy_noise_free(oracle):
-    xyz = capi.synth_scan_host(2, 0, 0, 32, 512, 0.0)
-    e, p = ctx().extract_features(xyz, capi.LidarParams(32, 512, 1.0, 120.0))
-    se, sp, ties = oracle.extract_features(xyz, 32, 512, 1.0, 120.0, stable=True)
+@pytest.mark.parametrize("H,W", [(32, 512), (8, 2048)])  # 2048 columns: more than 64 picks per sector, two per lane
+def test_tie_policy_noise_free(oracle, H, W):
+    xyz = capi.synth_scan_host(2, 0, 0, H, W, 0.0)
+    e, p = ctx().extract_features(xyz, capi.LidarParams(H, W, 1.0, 120.0))
+    se, sp, ties = oracle.extract_features(xyz, H, W, 1.0, 120.0, stable=True)
     assert np.array_equal(e, se) and np.array_equal(p, sp)
+    if W == 2048:  # ... and the arg-max fallback agrees
+        import os
+        os.environ["LOAMX_NO_MIS_SELECT"] = "1"
+        try:
+            e2, p2 = ctx().extract_features(xyz, capi.LidarParams(H, W, 1.0, 120.0))
+        finally:
+            del os.environ["LOAMX_NO_MIS_SELECT"]
+        assert np.array_equal(e2, se) and np.array_equal(p2, sp)
 
 
 def test_device_generator_bit_identical_and_batch_extract(oracle):

@@ -250,7 +250,7 @@ def test_batch_pipeline_is_reproducible_and_batch_size_invariant():
 def test_scan_pairs_128x2048_use_the_big_set_paths(oracle):
     """128 x 2048 scans: 39 k planar features per scan, i.e. more than the LDS-list build holds — the target sets
     go through the multi-workgroup index build (two pairs in one launch), the source sets through the
-    single-workgroup build + rank kernel, and sectors hold more than 64 picks (selection fallback)."""
+    single-workgroup build + rank kernel, and sectors yield more than 64 picks (two picks per lane in the selection)."""
     H, W, n_pairs, seed = 128, 2048, 2, 77
     N = H * W
     c = ctx()
