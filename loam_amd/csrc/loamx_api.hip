@@ -347,9 +347,9 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   ENSURE(ctx, WS_FLAGGED_COUNT, np * (size_t)B.mom_blocks_per_pair * 4 * sizeof(uint32_t));
   {
     const bool fresh = ctx->ws[WS_COUNTERS].cap == 0;
-    ENSURE(ctx, WS_COUNTERS, 64);
+    ENSURE(ctx, WS_COUNTERS, 128);
     untimed(ctx);
-    if (fresh) HIP_TRY(ctx, hipMemsetAsync(ctx->ws[WS_COUNTERS].p, 0, 64, ctx->stream));
+    if (fresh) HIP_TRY(ctx, hipMemsetAsync(ctx->ws[WS_COUNTERS].p, 0, 128, ctx->stream));
   }
   if (want_iter_info) ENSURE(ctx, WS_ITERINFO, np * (size_t)(C.max_iterations ? C.max_iterations : 1) * sizeof(loamx_iter_info));
   B.grid_edge = GridSet{wsp<GridDesc>(ctx, WS_GRID_DESC_E), wsp<uint32_t>(ctx, WS_CELLS_E), wsp<GridPoint>(ctx, WS_SORTED_E), es + kGridPad,
@@ -377,17 +377,22 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   B.assoc_slots = B.sweep_slots + 2;
   B.iter_info = want_iter_info ? wsp<loamx_iter_info>(ctx, WS_ITERINFO) : nullptr;
   B.want_nearest = hook ? 1u : 0u;
-  B.max_counts = wsp<uint32_t>(ctx, WS_COUNTERS) + 12;  // bytes 48..56
+  B.max_counts = wsp<uint32_t>(ctx, WS_COUNTERS) + 16;  // bytes 64..88
   B.assoc_blocks_edge = B.assoc_blocks_plane = 0xFFFFFFFFu;
+  B.knn_mode_edge = B.knn_mode_plane = 0u;
   hipStream_t s = ctx->stream;
   // The per-pair state first: its kernel also finds the largest source sets, which come back to the host while
   // the index builds run (an event right behind the copy: the builds are already queued when the host waits).
   untimed(ctx);
-  HIP_TRY(ctx, hipMemsetAsync(B.max_counts, 0, 2 * sizeof(uint32_t), s));
+  {
+    const uint32_t init[6] = {0u, 0u, 0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    memcpy(&ctx->h_pinned[8], init, sizeof(init));
+    HIP_TRY(ctx, hipMemcpyAsync(B.max_counts, &ctx->h_pinned[8], sizeof(init), hipMemcpyHostToDevice, s));
+  }
   launch_state_init(B, C, s);
   CHECK_LAUNCH(ctx, "state_init_kernel");
   if (!ctx->ev_counts) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_counts, hipEventDisableTiming));
-  HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_pinned[4], B.max_counts, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_pinned[16], B.max_counts, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipEventRecord(ctx->ev_counts, s));
 
   if (prebuilt) {  // persistent target index: only the source sets are (re)ordered
@@ -401,8 +406,14 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   }
   CHECK_LAUNCH(ctx, "grid_build_kernel");
   HIP_TRY(ctx, hipEventSynchronize(ctx->ev_counts));
-  B.assoc_blocks_edge = (ctx->h_pinned[4] + 255u) / 256u;   // kAssocThreads queries per workgroup
-  B.assoc_blocks_plane = (ctx->h_pinned[5] + 255u) / 256u;
+  B.assoc_blocks_edge = (ctx->h_pinned[16] + 255u) / 256u;   // kAssocThreads queries per workgroup
+  B.assoc_blocks_plane = (ctx->h_pinned[17] + 255u) / 256u;
+  {  // which of the two k-NN kernels of a feature kind has work at all (target sizes relative to kBruteMax)
+    uint32_t tmax[2] = {ctx->h_pinned[18], ctx->h_pinned[19]}, tmin[2] = {ctx->h_pinned[20], ctx->h_pinned[21]};
+    if (prebuilt) tmax[0] = tmin[0] = (uint32_t)prebuilt->n[0], tmax[1] = tmin[1] = (uint32_t)prebuilt->n[1];
+    uint32_t* mode[2] = {&B.knn_mode_edge, &B.knn_mode_plane};
+    for (int k = 0; k < 2; k++) *mode[k] = tmin[k] > tmax[k] ? 0u : (tmin[k] > kBruteMax ? 1u : (tmax[k] <= kBruteMax ? 2u : 0u));
+  }
   for (uint32_t it = 0; it < C.max_iterations; it++) {
     {
       TimedScope t(ctx, LOAMX_K_ASSOC, 0.0);
@@ -432,7 +443,7 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
       }
       {
         TimedScope t(ctx, LOAMX_K_LM, 0.0);
-        launch_sweep_light(B, s);
+        if (it > 0) launch_sweep_light(B, s);  // (no pair is on moments in the first ICF iteration)
         launch_lm_step(B, s);
       }
     }

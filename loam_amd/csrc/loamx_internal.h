@@ -146,7 +146,10 @@ struct RegBatch {
                                     // [2,3] assoc_slots; [4] plane slots streamed by the moment pass
   unsigned long long* assoc_slots;  // [2] edge / plane source features processed by associate_kernel
   loamx_iter_info* iter_info;  // optional [n_pairs][max_iterations]
-  uint32_t* max_counts;   // [2] largest source edge / planar count over the pairs (state_init_kernel; read back by the host)
+  uint32_t* max_counts;   // [6] over the active pairs (state_init_kernel; read back by the host): largest source edge / planar
+                          // count, largest target edge / planar count, smallest target edge / planar count
+  uint32_t knn_mode_edge, knn_mode_plane;  // 0: grid and brute-force k-NN kernels both launched (target sizes on both
+                                           // sides of kBruteMax, or unknown); 1: grid only; 2: brute force only
   uint32_t assoc_blocks_edge, assoc_blocks_plane;  // workgroups per pair of the association kernels; 0xFFFFFFFF = by capacity
   uint32_t want_nearest;  // 1: a detail hook will read nearest_* (RegistrationDetail pairs); 0: the fit kernels skip that write
 };
@@ -156,6 +159,7 @@ constexpr size_t kGridBigScratchBytes = 64 + (size_t)kGridCellsCap * sizeof(uint
 // cell table of a map-sized persistent index. Measured on a 1.02 M-point map (config 5; index build / registration
 // of a 39 k-feature scan): 2^16 cells 1.04 / 6.71 ms, 2^17 1.07 / 5.97, 2^18 1.38 / 5.88, 2^19 1.77 / 5.71,
 // 2^20 2.49 / 5.74, 2^21 4.75 / 8.19 (cells too small for the 5th neighbour: more second rounds)
+constexpr uint32_t kBruteMax = 512;  // target sets up to this size are searched by associate_knn_brute_kernel
 constexpr uint32_t kGridMapCellsCap = 1u << 18;
 void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_grid_build_sources(const RegBatch& B, const RegConfig& C, hipStream_t s);

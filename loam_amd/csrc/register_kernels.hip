@@ -447,6 +447,12 @@ __global__ void state_init_kernel(RegBatch B, RegConfig C) {
     const uint32_t ne = B.n_src_edge[pair * B.in_pitch], np = B.n_src_planar[pair * B.in_pitch];
     atomicMax(&B.max_counts[0], ne < B.edge_stride ? ne : (uint32_t)B.edge_stride);
     atomicMax(&B.max_counts[1], np < B.planar_stride ? np : (uint32_t)B.planar_stride);
+    if (B.n_tgt_edge && B.n_tgt_planar) {  // (a persistent index has its sizes on the host)
+      uint32_t te = B.n_tgt_edge[pair * B.in_pitch], tp = B.n_tgt_planar[pair * B.in_pitch];
+      te = te < B.edge_stride ? te : (uint32_t)B.edge_stride, tp = tp < B.planar_stride ? tp : (uint32_t)B.planar_stride;
+      atomicMax(&B.max_counts[2], te), atomicMax(&B.max_counts[3], tp);
+      atomicMin(&B.max_counts[4], te), atomicMin(&B.max_counts[5], tp);
+    }
   }
 }
 
@@ -476,7 +482,6 @@ __device__ __forceinline__ bool xcd_pair_map(uint32_t block, uint32_t blocks_per
 // Small target sets (a few hundred edge features per scan) are searched exhaustively: the whole set
 // streams through LDS in tiles and every lane scans all of it — no divergence, no dependent loads,
 // and none of the empty-cell rounds a grid search spends on sparse sets. Same collectors, same result.
-constexpr uint32_t kBruteMax = 512;
 constexpr int kBruteTile = 256;
 
 template <class Coll>
@@ -508,6 +513,8 @@ __global__ __launch_bounds__(kAssocThreads) void associate_knn_brute_kernel(RegB
   if (n_tgt > kBruteMax) return;  // uniform: the grid kernels take this pair
   const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
   const uint32_t n_src = PLANE ? B.n_src_planar[pair * B.in_pitch] : B.n_src_edge[pair * B.in_pitch];
+  if ((PLANE ? B.knn_mode_plane : B.knn_mode_edge) == 2u && chunk == 0 && threadIdx.x == 0 && B.assoc_slots)  // (the grid kernel was not launched)
+    atomicAdd(&B.assoc_slots[PLANE ? 1 : 0], (unsigned long long)(n_src < stride ? n_src : stride));
   if (chunk * kAssocThreads >= n_src || chunk * kAssocThreads >= stride) return;  // uniform: no query here
   const uint32_t i = chunk * kAssocThreads + threadIdx.x;
   const bool has = i < n_src && i < stride;
@@ -1335,8 +1342,11 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
 #define LOAMX_ASSOC_A1(PL, KMV, nblk, st)                                                                         \
   do {                                                                                                            \
     const dim3 grid_((unsigned)(pair_groups * 8 * (nblk)));                                                       \
-    hipLaunchKernelGGL((associate_knn_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, (st), B, C, (nblk));       \
-    hipLaunchKernelGGL((associate_knn_brute_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, (st), B, C, (nblk)); \
+    const uint32_t mode_ = (PL) ? B.knn_mode_plane : B.knn_mode_edge; /* a kernel no pair needs is not launched */   \
+    if (mode_ != 2u)                                                                                              \
+      hipLaunchKernelGGL((associate_knn_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, (st), B, C, (nblk));     \
+    if (mode_ != 1u)                                                                                              \
+      hipLaunchKernelGGL((associate_knn_brute_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, (st), B, C, (nblk)); \
   } while (0)
 #define LOAMX_ASSOC_A2(PL, KMV, nblk, st)                                                                         \
   hipLaunchKernelGGL((associate_fit_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * (nblk))), dim3(kAssocThreads), 0, \
