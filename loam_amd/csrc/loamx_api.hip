@@ -393,6 +393,8 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   CHECK_LAUNCH(ctx, "state_init_kernel");
   if (!ctx->ev_counts) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_counts, hipEventDisableTiming));
   HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_pinned[16], B.max_counts, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  const bool chk_extract = ctx->ws[WS_EXTRACT_ERR].p != nullptr;  // a pipeline call ran the extraction just before
+  if (chk_extract) HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_pinned[2], ctx->ws[WS_EXTRACT_ERR].p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipEventRecord(ctx->ev_counts, s));
 
   if (prebuilt) {  // persistent target index: only the source sets are (re)ordered
@@ -406,6 +408,7 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   }
   CHECK_LAUNCH(ctx, "grid_build_kernel");
   HIP_TRY(ctx, hipEventSynchronize(ctx->ev_counts));
+  if (chk_extract && ctx->h_pinned[2] != 0) return extract_error(ctx);
   B.assoc_blocks_edge = (ctx->h_pinned[16] + 255u) / 256u;   // kAssocThreads queries per workgroup
   B.assoc_blocks_plane = (ctx->h_pinned[17] + 255u) / 256u;
   {  // which of the two k-NN kernels of a feature kind has work at all (target sizes relative to kBruteMax)
@@ -455,14 +458,14 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
       launch_outer_update(B, C, it, s);
     }
     CHECK_LAUNCH(ctx, "outer_update_kernel");
-    if (it + 1 < C.max_iterations) {
-      // one 4-byte readback per outer iteration: stop as soon as every pair has terminated
+    if (it + 1 < C.max_iterations && it > 0) {
+      // one 4-byte readback per outer iteration: stop as soon as every pair has terminated. Not after the first
+      // iteration: a registration that starts more than the convergence thresholds away from its answer cannot
+      // converge there, so the second iteration is enqueued without waiting (if every pair did stop — too few
+      // associations everywhere — its kernels find no active pair and return)
       untimed(ctx);
       HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, B.n_active, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-      const bool chk = it == 0 && ctx->ws[WS_EXTRACT_ERR].p;  // a pipeline call ran the extraction just before
-      if (chk) HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_pinned[2], ctx->ws[WS_EXTRACT_ERR].p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
       HIP_TRY(ctx, hipStreamSynchronize(s));
-      if (chk && ctx->h_pinned[2] != 0) return extract_error(ctx);
       if (ctx->h_pinned[0] == 0) break;
     }
   }
