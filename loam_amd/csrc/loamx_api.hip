@@ -420,7 +420,12 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   for (uint32_t it = 0; it < C.max_iterations; it++) {
     {
       TimedScope t(ctx, LOAMX_K_ASSOC, 0.0);
-      launch_associate(B, C, s, ctx->aux_stream, ctx->aux2_stream, ctx->ev_fork, ctx->ev_mid, ctx->ev_join, ctx->ev_join2);
+      // (a single scan-sized pair cannot fill the chip twice over: the forks and joins only add latency there —
+      // one 64 x 1024 pair 1.15 ms with the auxiliary streams, 1.10 ms without; one 128 x 2048 scan against a
+      // 1 M-point map the other way round: 5.9 vs 6.8 ms)
+      const bool side = (size_t)B.n_pairs * B.assoc_blocks_plane >= 128;
+      launch_associate(B, C, s, side ? ctx->aux_stream : nullptr, side ? ctx->aux2_stream : nullptr, ctx->ev_fork, ctx->ev_mid, ctx->ev_join,
+                       ctx->ev_join2);
     }
     CHECK_LAUNCH(ctx, "associate_kernel");
 #ifdef LOAMX_NN_SAME_STATS
