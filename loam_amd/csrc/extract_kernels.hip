@@ -853,13 +853,13 @@ static void launch_curvature_valid_t(const T* d_xyz, const dim3& grid, const Ext
                                      hipStream_t s) {
   if (P.np == 3 && !getenv("LOAMX_CURV_V1")) {  // the reference's default neighbor_points (features.h:40)
     const dim3 grid2(grid.x, (P.W + kCurvTilesPerGroup * kTile - 1) / (kCurvTilesPerGroup * kTile));
-    hipLaunchKernelGGL((curvature_valid2_kernel<3, T>), grid2, dim3(kCurvThreads), 0, s, d_xyz, P, d_curv, d_mask);
+    launch_kernel((curvature_valid2_kernel<3, T>), grid2, dim3(kCurvThreads), 0, s, d_xyz, P, d_curv, d_mask);
     return;
   }
   if (P.np == 3)
-    hipLaunchKernelGGL((curvature_valid_kernel<3, T>), grid, dim3(kCurvThreads), 0, s, d_xyz, P, d_curv, d_mask);
+    launch_kernel((curvature_valid_kernel<3, T>), grid, dim3(kCurvThreads), 0, s, d_xyz, P, d_curv, d_mask);
   else
-    hipLaunchKernelGGL((curvature_valid_kernel<0, T>), grid, dim3(kCurvThreads), 0, s, d_xyz, P, d_curv, d_mask);
+    launch_kernel((curvature_valid_kernel<0, T>), grid, dim3(kCurvThreads), 0, s, d_xyz, P, d_curv, d_mask);
 }
 
 void launch_curvature_valid(const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, double* d_curv,
@@ -877,10 +877,10 @@ static void launch_select_mis2(const double* d_curv, const uint8_t* d_mask, size
                                const ExtractStage& st, const ExtractFused& fz, hipStream_t s) {
   const size_t per_wave = select_mis_lds_bytes((int)P.W, TWO ? 128 : 64);
   if (per_wave * 4 <= 48 * 1024) {
-    hipLaunchKernelGGL((select_mis_kernel<R, 4, TWO>), dim3((unsigned)((n_lines + 3) / 4)), dim3(256), per_wave * 4, s, d_curv,
+    launch_kernel((select_mis_kernel<R, 4, TWO>), dim3((unsigned)((n_lines + 3) / 4)), dim3(256), per_wave * 4, s, d_curv,
                        d_mask, n_lines, P, st, fz);
   } else {
-    hipLaunchKernelGGL((select_mis_kernel<R, 1, TWO>), dim3((unsigned)n_lines), dim3(64), per_wave, s, d_curv, d_mask, n_lines,
+    launch_kernel((select_mis_kernel<R, 1, TWO>), dim3((unsigned)n_lines), dim3(64), per_wave, s, d_curv, d_mask, n_lines,
                        P, st, fz);
   }
 }
@@ -917,10 +917,10 @@ bool launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, 
   const size_t per_wave = (size_t)P.W * 8 + (((size_t)P.W + 7) & ~(size_t)7);
   if (P.W <= 1024) {
     constexpr int WAVES = 4;
-    hipLaunchKernelGGL(select_kernel<WAVES>, dim3((unsigned)((n_lines + WAVES - 1) / WAVES)), dim3(WAVES * 64),
+    launch_kernel(select_kernel<WAVES>, dim3((unsigned)((n_lines + WAVES - 1) / WAVES)), dim3(WAVES * 64),
                        per_wave * WAVES, s, d_curv, d_mask, n_lines, P, st);
   } else {
-    hipLaunchKernelGGL(select_kernel<1>, dim3((unsigned)n_lines), dim3(64), per_wave, s, d_curv, d_mask, n_lines, P,
+    launch_kernel(select_kernel<1>, dim3((unsigned)n_lines), dim3(64), per_wave, s, d_curv, d_mask, n_lines, P,
                        st);
   }
   return false;
@@ -933,10 +933,10 @@ void launch_compact(const void* d_xyz, bool f32, size_t n_scans, const ExtractPa
   if (n_scans == 0) return;
   const dim3 grid((unsigned)(n_scans * kCompactSplit));
   if (f32)
-    hipLaunchKernelGGL(compact_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(d_xyz), P, st, d_edge_idx, d_n_edge,
+    launch_kernel(compact_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(d_xyz), P, st, d_edge_idx, d_n_edge,
                        d_edge_xyz, edge_stride, d_planar_idx, d_n_planar, d_planar_xyz, planar_stride);
   else
-    hipLaunchKernelGGL(compact_kernel<double>, grid, dim3(256), 0, s, static_cast<const double*>(d_xyz), P, st, d_edge_idx, d_n_edge,
+    launch_kernel(compact_kernel<double>, grid, dim3(256), 0, s, static_cast<const double*>(d_xyz), P, st, d_edge_idx, d_n_edge,
                        d_edge_xyz, edge_stride, d_planar_idx, d_n_planar, d_planar_xyz, planar_stride);
 }
 

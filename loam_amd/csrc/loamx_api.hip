@@ -76,6 +76,10 @@ struct loamx_target_index {
   size_t cells_alloc[2] = {0, 0}, scratch_alloc = 0;
 };
 
+namespace loamx {
+thread_local LaunchScope* g_launch_scope = nullptr;
+}
+
 namespace {
 
 const char* kKernelNames[LOAMX_K_COUNT] = {"curvature_valid_kernel", "select_kernel", "compact_kernel",
@@ -133,10 +137,19 @@ hipEvent_t take_event(loamx_ctx* ctx) {
 struct TimedScope {
   loamx_ctx* ctx;
   PendingEvent pe;
-  bool on;
-  TimedScope(loamx_ctx* c, int kernel, double bytes) : ctx(c), on(c->timing) {
+  bool on, attach;
+  LaunchScope ls;
+  // attach: the events ride on the scope's own kernels (single-stream scopes); otherwise marker events around it
+  TimedScope(loamx_ctx* c, int kernel, double bytes, bool attach_ = false) : ctx(c), on(c->timing), attach(attach_) {
     if (on) {
       pe.kernel = kernel, pe.bytes = bytes;
+      if (attach) {
+        pe.own_e0 = true;
+        pe.e0 = take_event(ctx), pe.e1 = take_event(ctx);
+        ls = LaunchScope{pe.e0, pe.e1, true};
+        g_launch_scope = &ls;
+        return;
+      }
       // back-to-back scopes share one event: half the event packets between the kernels
       pe.own_e0 = !(ctx->tail_fresh && ctx->tail_event);
       pe.e0 = pe.own_e0 ? take_event(ctx) : ctx->tail_event;
@@ -146,6 +159,16 @@ struct TimedScope {
   }
   ~TimedScope() {
     if (on) {
+      if (attach) {
+        g_launch_scope = nullptr;
+        if (ls.first) {  // no kernel was launched inside: nothing to time
+          ctx->event_pool.push_back(pe.e0), ctx->event_pool.push_back(pe.e1);
+        } else {
+          ctx->pending.push_back(pe);
+        }
+        ctx->tail_fresh = false;
+        return;
+      }
       (void)hipEventRecord(pe.e1, ctx->stream);
       ctx->pending.push_back(pe);
       ctx->tail_event = pe.e1, ctx->tail_fresh = true;
@@ -246,7 +269,7 @@ int extract_dev(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_scans, con
   ENSURE(ctx, WS_CURV, n_scans * N * sizeof(double));
   ENSURE(ctx, WS_MASK, n_scans * N);
   {
-    TimedScope t(ctx, LOAMX_K_CURVATURE, (double)n_scans * (double)N * (f32 ? 21.0 : 33.0));
+    TimedScope t(ctx, LOAMX_K_CURVATURE, (double)n_scans * (double)N * (f32 ? 21.0 : 33.0), true);
     launch_curvature_valid(d_xyz, f32, n_scans, P, wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), ctx->stream);
   }
   CHECK_LAUNCH(ctx, "curvature_valid_kernel");
@@ -271,13 +294,13 @@ int extract_dev(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_scans, con
                         wsp<uint32_t>(ctx, WS_EXTRACT_ERR)};
   bool fused = false;
   {
-    TimedScope t(ctx, LOAMX_K_SELECT, (double)n_scans * (double)N * 9.0);
+    TimedScope t(ctx, LOAMX_K_SELECT, (double)n_scans * (double)N * 9.0, true);
     fused = launch_select(wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), n_scans, P, st, &fz, ctx->stream);
   }
   CHECK_LAUNCH(ctx, "select_kernel");
   if (fused) return LOAMX_OK;
   {
-    TimedScope t(ctx, LOAMX_K_COMPACT, 0.0);
+    TimedScope t(ctx, LOAMX_K_COMPACT, 0.0, true);
     launch_compact(d_xyz, f32, n_scans, P, st, d_edge_idx, d_n_edge, d_edge_xyz, edge_capacity(P), d_planar_idx,
                    d_n_planar, d_planar_xyz, planar_capacity(P), ctx->stream);
   }
@@ -443,20 +466,20 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
       if (rc != LOAMX_OK) return rc;
     }
     {
-      TimedScope t(ctx, LOAMX_K_LM, 0.0);
+      TimedScope t(ctx, LOAMX_K_LM, 0.0, true);
       launch_lm_begin(B, C, it, s);
     }
     if (it > 0) {  // the first ICF iteration streams its records (state_init: stream_planes = 1, use_moments = 0)
-      TimedScope t(ctx, LOAMX_K_MOMENT, 0.0);
+      TimedScope t(ctx, LOAMX_K_MOMENT, 0.0, true);
       launch_moments(B, s);
     }
     for (int k = 0; k < 5; k++) {  // iteration-0 evaluation + max_num_iterations = 4 candidates
       {
-        TimedScope t(ctx, LOAMX_K_SWEEP, 0.0);
+        TimedScope t(ctx, LOAMX_K_SWEEP, 0.0, true);
         launch_sweep(B, s);
       }
       {
-        TimedScope t(ctx, LOAMX_K_LM, 0.0);
+        TimedScope t(ctx, LOAMX_K_LM, 0.0, true);
         if (it > 0) launch_sweep_light(B, s);  // (no pair is on moments in the first ICF iteration)
         launch_lm_step(B, s);
       }
@@ -465,7 +488,7 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
     untimed(ctx);
     HIP_TRY(ctx, hipMemsetAsync(B.n_active, 0, sizeof(uint32_t), s));
     {
-      TimedScope t(ctx, LOAMX_K_LM, 0.0);
+      TimedScope t(ctx, LOAMX_K_LM, 0.0, true);
       launch_outer_update(B, C, it, s);
     }
     CHECK_LAUNCH(ctx, "outer_update_kernel");

@@ -1,6 +1,7 @@
 // loamx_internal.h — declarations shared by the .hip translation units of libloamx.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/loamx.h"
@@ -8,6 +9,27 @@
 #include "reg_math.h"
 
 namespace loamx {
+
+/* ---- kernel launches with timing attached (loamx_api.hip: TimedScope) ------------------------------------
+ * While a timing scope of the calling thread is in "attach" mode, the first kernel launched records the scope's
+ * start event with its own begin and every kernel re-records the stop event with its end (the last one
+ * stands): hipExtLaunchKernelGGL takes the timestamps from the dispatch itself, so no marker packets sit between
+ * the kernels of the timed region (barrier-style hipEventRecord cost 2.5 % of the step). */
+struct LaunchScope {
+  hipEvent_t start, stop;
+  bool first;
+};
+extern thread_local LaunchScope* g_launch_scope;
+template <typename F, typename... Args>
+inline void launch_kernel(F kernel, const dim3& grid, const dim3& block, size_t shmem, hipStream_t s, Args... args) {
+  LaunchScope* sc = g_launch_scope;
+  if (sc) {
+    hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)shmem, s, sc->first ? sc->start : nullptr, sc->stop, 0, args...);
+    sc->first = false;
+  } else {
+    hipLaunchKernelGGL(kernel, grid, block, shmem, s, args...);
+  }
+}
 
 /* ---- extraction (extract_kernels.hip) ---------------------------------------------------------- */
 constexpr int kMaxNeighborPoints = 16;  // LDS halo bound of curvature_valid_kernel

@@ -1262,16 +1262,16 @@ static bool grid_big(size_t stride, const GridPoint* scratch) {
 static void launch_grid_build_big(size_t n_pairs, const double* pts, const uint32_t* n_pts, size_t stride, uint32_t in_pitch,
                                   double max_dist, const GridSet& gs, GridPoint* scratch, hipStream_t s) {
   const dim3 chunks((unsigned)((stride + kBigChunk - 1) / kBigChunk), (unsigned)n_pairs);
-  hipLaunchKernelGGL(gridbig_init_kernel, dim3((unsigned)n_pairs), dim3(64), 0, s, scratch, stride);
-  hipLaunchKernelGGL(gridbig_bbox_kernel, chunks, dim3(kBigThreads), 0, s, pts, n_pts, stride, in_pitch, scratch);
-  hipLaunchKernelGGL(gridbig_choose_kernel, dim3((unsigned)((n_pairs + 63) / 64)), dim3(64), 0, s, n_pts, stride, in_pitch, max_dist, gs,
+  launch_kernel(gridbig_init_kernel, dim3((unsigned)n_pairs), dim3(64), 0, s, scratch, stride);
+  launch_kernel(gridbig_bbox_kernel, chunks, dim3(kBigThreads), 0, s, pts, n_pts, stride, in_pitch, scratch);
+  launch_kernel(gridbig_choose_kernel, dim3((unsigned)((n_pairs + 63) / 64)), dim3(64), 0, s, n_pts, stride, in_pitch, max_dist, gs,
                      scratch, n_pairs);
   (void)hipMemsetAsync(gs.cell_start, 0, (gs.cells_cap ? (size_t)gs.cells_cap + 1 : n_pairs * (size_t)(kGridCellsCap + 1)) * sizeof(uint32_t), s);
-  hipLaunchKernelGGL(gridbig_pass_kernel<false>, chunks, dim3(kBigThreads), 0, s, pts, n_pts, stride, in_pitch, gs, scratch);
-  hipLaunchKernelGGL(gridbig_scan_kernel, dim3((unsigned)n_pairs), dim3(1024), 0, s, n_pts, stride, in_pitch, gs, scratch);
-  hipLaunchKernelGGL(gridbig_pass_kernel<true>, chunks, dim3(kBigThreads), 0, s, pts, n_pts, stride, in_pitch, gs, scratch);
+  launch_kernel(gridbig_pass_kernel<false>, chunks, dim3(kBigThreads), 0, s, pts, n_pts, stride, in_pitch, gs, scratch);
+  launch_kernel(gridbig_scan_kernel, dim3((unsigned)n_pairs), dim3(1024), 0, s, n_pts, stride, in_pitch, gs, scratch);
+  launch_kernel(gridbig_pass_kernel<true>, chunks, dim3(kBigThreads), 0, s, pts, n_pts, stride, in_pitch, gs, scratch);
   if (gs.rel)
-    hipLaunchKernelGGL(gridbig_rel_kernel, dim3((unsigned)((stride + kBigThreads - 1) / kBigThreads), (unsigned)n_pairs), dim3(kBigThreads), 0,
+    launch_kernel(gridbig_rel_kernel, dim3((unsigned)((stride + kBigThreads - 1) / kBigThreads), (unsigned)n_pairs), dim3(kBigThreads), 0,
                        s, n_pts, stride, in_pitch, gs);
 }
 
@@ -1283,10 +1283,10 @@ static void launch_grid_build(size_t n_pairs, const double* pts, const uint32_t*
     return;
   }
   if (grid_small(stride))
-    hipLaunchKernelGGL((grid_build_kernel<ORDERED, true>), dim3((unsigned)n_pairs), dim3(kBuildThreads), 0, s, pts, n_pts, stride,
+    launch_kernel((grid_build_kernel<ORDERED, true>), dim3((unsigned)n_pairs), dim3(kBuildThreads), 0, s, pts, n_pts, stride,
                        in_pitch, max_dist, gs, scratch);
   else
-    hipLaunchKernelGGL((grid_build_kernel<ORDERED, false>), dim3((unsigned)n_pairs), dim3(kBuildThreads), 0, s, pts, n_pts, stride,
+    launch_kernel((grid_build_kernel<ORDERED, false>), dim3((unsigned)n_pairs), dim3(kBuildThreads), 0, s, pts, n_pts, stride,
                        in_pitch, max_dist, gs, scratch);
 }
 
@@ -1302,18 +1302,18 @@ void launch_grid_build_sources(const RegBatch& B, const RegConfig& C, hipStream_
   // (the scratch copy is shared: build + rank of one set complete before the next set's build starts)
   launch_grid_build<true>(B.n_pairs, B.src_edge, B.n_src_edge, B.edge_stride, B.in_pitch, C.r_edge, B.src_grid_edge, B.sort_scratch, s);
   if (B.edge_stride && !grid_small(B.edge_stride))
-    hipLaunchKernelGGL(grid_rank_kernel, dim3((unsigned)((B.edge_stride + kRankThreads - 1) / kRankThreads), (unsigned)B.n_pairs),
+    launch_kernel(grid_rank_kernel, dim3((unsigned)((B.edge_stride + kRankThreads - 1) / kRankThreads), (unsigned)B.n_pairs),
                        dim3(kRankThreads), 0, s, B.n_src_edge, B.edge_stride, B.in_pitch, B.src_grid_edge, B.sort_scratch);
   launch_grid_build<true>(B.n_pairs, B.src_planar, B.n_src_planar, B.planar_stride, B.in_pitch, C.r_plane, B.src_grid_plane, B.sort_scratch, s);
   if (B.planar_stride && !grid_small(B.planar_stride))
-    hipLaunchKernelGGL(grid_rank_kernel, dim3((unsigned)((B.planar_stride + kRankThreads - 1) / kRankThreads), (unsigned)B.n_pairs),
+    launch_kernel(grid_rank_kernel, dim3((unsigned)((B.planar_stride + kRankThreads - 1) / kRankThreads), (unsigned)B.n_pairs),
                        dim3(kRankThreads), 0, s, B.n_src_planar, B.planar_stride, B.in_pitch, B.src_grid_plane,
                        B.sort_scratch);
 }
 
 void launch_state_init(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   if (B.n_pairs == 0) return;
-  hipLaunchKernelGGL(state_init_kernel, dim3(per_pair_grid(B.n_pairs)), dim3(64), 0, s, B, C);
+  launch_kernel(state_init_kernel, dim3(per_pair_grid(B.n_pairs)), dim3(64), 0, s, B, C);
 }
 
 #ifndef LOAMX_REST_BLOCKS
@@ -1344,21 +1344,21 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
     const dim3 grid_((unsigned)(pair_groups * 8 * (nblk)));                                                       \
     const uint32_t mode_ = (PL) ? B.knn_mode_plane : B.knn_mode_edge; /* a kernel no pair needs is not launched */   \
     if (mode_ != 2u)                                                                                              \
-      hipLaunchKernelGGL((associate_knn_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, (st), B, C, (nblk));     \
+      launch_kernel((associate_knn_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, (st), B, C, (nblk));     \
     if (mode_ != 1u)                                                                                              \
-      hipLaunchKernelGGL((associate_knn_brute_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, (st), B, C, (nblk)); \
+      launch_kernel((associate_knn_brute_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, (st), B, C, (nblk)); \
   } while (0)
 #define LOAMX_ASSOC_A2(PL, KMV, nblk, st)                                                                         \
-  hipLaunchKernelGGL((associate_fit_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * (nblk))), dim3(kAssocThreads), 0, \
+  launch_kernel((associate_fit_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * (nblk))), dim3(kAssocThreads), 0, \
                      (st), B, C, (nblk))
 #define LOAMX_ASSOC_B(PL, KMV, nblk, st)                                                                          \
   do {                                                                                                            \
     const uint32_t rblk_ = rest_blocks(B.n_pairs, (nblk)), xblk_ = (nblk) < 2u ? (nblk) : 2u;                      \
-    hipLaunchKernelGGL((associate_knn_rest_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * rblk_)),           \
+    launch_kernel((associate_knn_rest_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * rblk_)),           \
                        dim3(kRestThreads), 0, (st), B, C, rblk_);                                                 \
-    hipLaunchKernelGGL((associate_knn_exact_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * xblk_)),          \
+    launch_kernel((associate_knn_exact_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * xblk_)),          \
                        dim3(kAssocThreads), 0, (st), B, C, xblk_);                                                \
-    hipLaunchKernelGGL((associate_fit_queued_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * rblk_)),         \
+    launch_kernel((associate_fit_queued_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * rblk_)),         \
                        dim3(kRestThreads), 0, (st), B, C, rblk_);                                                 \
   } while (0)
 #define LOAMX_ASSOC_K(STEP, PL, nblk, st)                \
@@ -1416,7 +1416,7 @@ void debug_nn_same(const RegBatch& B, uint32_t it, hipStream_t s) {
   const size_t words = 6 * B.n_pairs * B.planar_stride;
   if (!prev) { (void)hipMalloc(&prev, words * 4); (void)hipMalloc(&stats, 24); }
   (void)hipMemsetAsync(stats, 0, 24, s);
-  hipLaunchKernelGGL(nn_same_kernel, dim3((unsigned)((B.planar_stride + 255) / 256), (unsigned)B.n_pairs), dim3(256), 0, s, B, prev, stats, it);
+  launch_kernel(nn_same_kernel, dim3((unsigned)((B.planar_stride + 255) / 256), (unsigned)B.n_pairs), dim3(256), 0, s, B, prev, stats, it);
   unsigned long long h[3];
   (void)hipMemcpyAsync(h, stats, 24, hipMemcpyDeviceToHost, s);
   (void)hipStreamSynchronize(s);
@@ -1427,39 +1427,39 @@ void debug_nn_same(const RegBatch& B, uint32_t it, hipStream_t s) {
 
 void launch_sweep(const RegBatch& B, hipStream_t s) {
   if (B.n_pairs == 0 || B.blocks_per_pair == 0) return;
-  hipLaunchKernelGGL(sweep_kernel, dim3((unsigned)(B.n_pairs * B.blocks_per_pair)), dim3(kSweepThreads), 0, s, B);
+  launch_kernel(sweep_kernel, dim3((unsigned)(B.n_pairs * B.blocks_per_pair)), dim3(kSweepThreads), 0, s, B);
 }
 
 // the same evaluation for the pairs that are on moments (timed with the LM kernels: it streams next to nothing)
 void launch_sweep_light(const RegBatch& B, hipStream_t s) {
   if (B.n_pairs == 0 || B.blocks_per_pair == 0) return;
-  hipLaunchKernelGGL(sweep_light_kernel, dim3((unsigned)B.n_pairs), dim3(kSweepThreads), 0, s, B);
+  launch_kernel(sweep_light_kernel, dim3((unsigned)B.n_pairs), dim3(kSweepThreads), 0, s, B);
 }
 
 void launch_moments(const RegBatch& B, hipStream_t s) {
   if (B.n_pairs == 0 || B.mom_blocks_per_pair == 0) return;
-  hipLaunchKernelGGL(moment_kernel, dim3((unsigned)(B.n_pairs * B.mom_blocks_per_pair * 4)), dim3(64), 0, s, B);
-  hipLaunchKernelGGL(moment_finish_kernel, dim3((unsigned)B.n_pairs), dim3(kMomSize), 0, s, B);
+  launch_kernel(moment_kernel, dim3((unsigned)(B.n_pairs * B.mom_blocks_per_pair * 4)), dim3(64), 0, s, B);
+  launch_kernel(moment_finish_kernel, dim3((unsigned)B.n_pairs), dim3(kMomSize), 0, s, B);
 }
 
 void launch_lm_step(const RegBatch& B, hipStream_t s) {
   if (B.n_pairs == 0) return;
-  hipLaunchKernelGGL(lm_step_kernel, dim3(per_pair_grid(B.n_pairs)), dim3(64), 0, s, B);
+  launch_kernel(lm_step_kernel, dim3(per_pair_grid(B.n_pairs)), dim3(64), 0, s, B);
 }
 
 void launch_lm_begin(const RegBatch& B, const RegConfig& C, uint32_t iteration, hipStream_t s) {
   if (B.n_pairs == 0) return;
-  hipLaunchKernelGGL(lm_begin_kernel, dim3(per_pair_grid(B.n_pairs)), dim3(64), 0, s, B, C, iteration);
+  launch_kernel(lm_begin_kernel, dim3(per_pair_grid(B.n_pairs)), dim3(64), 0, s, B, C, iteration);
 }
 
 void launch_outer_update(const RegBatch& B, const RegConfig& C, uint32_t iteration, hipStream_t s) {
   if (B.n_pairs == 0) return;
-  hipLaunchKernelGGL(outer_update_kernel, dim3(per_pair_grid(B.n_pairs)), dim3(64), 0, s, B, C, iteration);
+  launch_kernel(outer_update_kernel, dim3(per_pair_grid(B.n_pairs)), dim3(64), 0, s, B, C, iteration);
 }
 
 void launch_write_results(const RegBatch& B, loamx_reg_result* d_results, hipStream_t s) {
   if (B.n_pairs == 0) return;
-  hipLaunchKernelGGL(write_results_kernel, dim3(per_pair_grid(B.n_pairs)), dim3(64), 0, s, B, d_results);
+  launch_kernel(write_results_kernel, dim3(per_pair_grid(B.n_pairs)), dim3(64), 0, s, B, d_results);
 }
 
 }  // namespace loamx
