@@ -34,7 +34,8 @@ enum {
   LOAMX_ERR_HIP = 3,
   LOAMX_ERR_CAPACITY = 4,    /* caller-provided output capacity too small */
   LOAMX_ERR_UNSUPPORTED = 5, /* parameter combination outside what the kernels implement */
-  LOAMX_ERR_NO_DEVICE = 6
+  LOAMX_ERR_NO_DEVICE = 6,
+  LOAMX_ERR_COMM = 7         /* RCCL error in the multi-GPU gather (loamx_last_error has ncclGetErrorString) */
 };
 
 /* loam::LidarParams (loam/include/loam/common.h:29-41) */
@@ -116,7 +117,10 @@ const char* loamx_last_error(const loamx_ctx* ctx);
 /* Context = one device + one stream + grow-on-demand device workspace. Thread-safe per context. */
 int loamx_ctx_create(int device, loamx_ctx** out);
 void loamx_ctx_destroy(loamx_ctx* ctx);
-/* Use an external hipStream_t (e.g. torch's current stream); NULL restores the context's own. */
+/* Use an external hipStream_t; NULL (handle 0) selects the context's OWN private hipStreamNonBlocking stream.
+ * Careful with frameworks: torch's default stream has handle 0, i.e. it is NOT adopted — work enqueued by a "_dev"
+ * entry point is then ordered only against this context's stream; call loamx_ctx_synchronize (or pass the
+ * non-zero handle of an explicit side stream) before another stream or library reads the results. */
 int loamx_ctx_set_stream(loamx_ctx* ctx, void* hip_stream);
 int loamx_ctx_synchronize(loamx_ctx* ctx);
 
@@ -219,6 +223,34 @@ int loamx_register_scan_pairs_dev_f32(loamx_ctx* ctx, const float* d_xyz, size_t
                                       const loamx_lidar_params* lidar, const loamx_fe_params* fe,
                                       const loamx_reg_params* reg, loamx_reg_result* d_results);
 
+/* ---- multi-GPU batch mode (BASELINE configs[3]) ------------------------------------------------
+ * The reference has no counterpart (registration-inl.h:11-78 takes everything by value / const-ref: scan pairs are
+ * independent units). One process per GPU owns a contiguous block of pair ids and runs the single-GPU entry points
+ * on it; the only communication is the gather of the 64-byte loamx_reg_result records, done here with RCCL
+ * (ncclAllGather, or grouped ncclBroadcast when the shards are uneven) on the context's stream, asynchronously —
+ * it is ordered after the registration kernels that produce the records by the stream itself. */
+#define LOAMX_COMM_ID_BYTES 128 /* = NCCL_UNIQUE_ID_BYTES */
+typedef struct loamx_comm loamx_comm;
+/* contiguous block [first, first + count) of rank `rank`; block sizes differ by at most one */
+void loamx_shard_range(size_t total_pairs, int world_size, int rank, size_t* first, size_t* count);
+/* rank 0 calls this once and hands the 128 bytes to every rank out of band (file, socket, launcher) */
+int loamx_comm_get_unique_id(unsigned char id_out[LOAMX_COMM_ID_BYTES]);
+/* collective over all ranks: ncclCommInitRank on the context's device */
+int loamx_comm_create(loamx_ctx* ctx, const unsigned char id[LOAMX_COMM_ID_BYTES], int world_size, int rank,
+                      loamx_comm** out);
+/* adopts a communicator the host already owns (an ncclComm_t); loamx_comm_destroy then leaves it alone */
+int loamx_comm_wrap(loamx_ctx* ctx, void* nccl_comm, loamx_comm** out);
+void loamx_comm_destroy(loamx_comm* comm);
+/* what RCCL reports for the communicator: ncclCommCount / ncclCommUserRank / ncclCommCuDevice */
+int loamx_comm_info(const loamx_comm* comm, int* world_size, int* rank, int* device);
+/* d_local: this rank's n_local records (device); d_all: total_pairs records (device), filled in pair-id order on
+ * every rank. n_local must equal this rank's loamx_shard_range count. Asynchronous on the context's stream. */
+int loamx_gather_results_dev(loamx_ctx* ctx, loamx_comm* comm, const loamx_reg_result* d_local, size_t n_local,
+                             size_t total_pairs, loamx_reg_result* d_all);
+/* all ranks wait for each other (1-element all-reduce + stream synchronisation); *max_value, if given, is replaced by
+ * the maximum over ranks (the bench's max-over-ranks timing without a second communication library) */
+int loamx_comm_barrier(loamx_ctx* ctx, loamx_comm* comm, double* max_value);
+
 /* ---- per-kernel timing (hipEvents on the context stream), for bench.py's roofline object ------- */
 enum {
   LOAMX_K_CURVATURE = 0, /* curvature + validity, 33 B/point algorithmic */
@@ -229,7 +261,9 @@ enum {
   LOAMX_K_SWEEP = 5,     /* residual / Jacobian / normal equations, 56 B per plane + 72 B per edge slot streamed */
   LOAMX_K_LM = 6,        /* per-pair trust-region bookkeeping */
   LOAMX_K_MOMENT = 7,    /* plane moment pass (Gram matrix of the plane coefficients), 56 B per plane slot */
-  LOAMX_K_COUNT = 8
+  LOAMX_K_KNN_PLANE = 8, /* sub-scope of LOAMX_K_ASSOC: the round-1 k-NN kernel of the plane features alone
+                            (instruction-bound: bench.py prices it against the vector-issue roofline) */
+  LOAMX_K_COUNT = 9
 };
 typedef struct {
   uint64_t launches;

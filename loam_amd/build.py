@@ -25,6 +25,17 @@ def _hipcc():
     raise RuntimeError("hipcc not found: libloamx.so cannot be built (there is no CPU fallback)")
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources + the C ABI header: profiles/ files are stamped with it and
+    bench.py only quotes PMC numbers that were measured on the sources it runs."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        h.update(os.path.basename(f).encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
@@ -33,12 +44,39 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _obj_path(src):
+    return os.path.join(LIB_DIR, "obj", os.path.splitext(src)[0] + ".o")
+
+
 def build(force=False, verbose=False):
+    """One object per .hip source (compiled in parallel, only when the source or a header is newer), then the link."""
     if not force and not needs_build():
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(os.path.join(LIB_DIR, "obj"), exist_ok=True)
     extra = os.environ.get("LOAMX_EXTRA_FLAGS", "").split()  # experiments only, e.g. -DLOAMX_ASSOC_WAVES=6
-    cmd = [_hipcc()] + FLAGS + extra + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    flags_tag = os.path.join(LIB_DIR, "obj", "flags.txt")
+    flags_now = " ".join(FLAGS + extra)
+    same_flags = os.path.exists(flags_tag) and open(flags_tag).read() == flags_now
+    hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    hdr_time = max(hdr_time, os.path.getmtime(os.path.abspath(__file__)))
+
+    def compile_one(src):
+        obj, path = _obj_path(src), os.path.join(CSRC, src)
+        if not force and same_flags and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), hdr_time):
+            return
+        cmd = [_hipcc()] + [f for f in FLAGS if f != "-shared"] + extra + ["-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        list(ex.map(compile_one, SOURCES))
+    open(flags_tag, "w").write(flags_now)
+    # librccl: the gather of the result records in multi-GPU batch mode (loamx_gather_results_dev)
+    rocm_lib = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
+    cmd = ([_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + [_obj_path(s) for s in SOURCES] +
+           ["-L" + rocm_lib, "-lrccl", "-Wl,-rpath," + rocm_lib])
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

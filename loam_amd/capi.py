@@ -10,9 +10,9 @@ import numpy as np
 
 from . import build as _build
 
-OK, ERR_SCAN_SIZE, ERR_BAD_PARAM, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_NO_DEVICE = range(7)
+OK, ERR_SCAN_SIZE, ERR_BAD_PARAM, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_COMM = range(8)
 CONVERGED, MAX_ITER, INSUFFICIENT_ASSOCIATIONS = 0, 1, 2
-K_CURVATURE, K_SELECT, K_COMPACT, K_GRID, K_ASSOC, K_SWEEP, K_LM, K_MOMENT, K_COUNT = range(9)
+K_CURVATURE, K_SELECT, K_COMPACT, K_GRID, K_ASSOC, K_SWEEP, K_LM, K_MOMENT, K_KNN_PLANE, K_COUNT = range(10)
 
 
 class LidarParams(C.Structure):
@@ -84,6 +84,8 @@ EXPORTS = [
     "loamx_compute_curvature_f32", "loamx_compute_valid_points_f32", "loamx_extract_features_f32",
     "loamx_extract_features_batch_dev_f32", "loamx_register_scan_pairs_dev_f32",
     "loamx_target_index_insert", "loamx_target_index_size",
+    "loamx_shard_range", "loamx_comm_get_unique_id", "loamx_comm_create", "loamx_comm_wrap", "loamx_comm_destroy",
+    "loamx_comm_info", "loamx_gather_results_dev", "loamx_comm_barrier",
 ]
 
 _lib = None
@@ -161,6 +163,17 @@ def load(build_if_missing=True):
     lib.loamx_dev_free.argtypes = [vp, vp]
     lib.loamx_copy_to_device.argtypes = [vp, vp, vp, C.c_size_t]
     lib.loamx_copy_to_host.argtypes = [vp, vp, vp, C.c_size_t]
+    szp = C.POINTER(C.c_size_t)
+    lib.loamx_shard_range.argtypes = [C.c_size_t, C.c_int, C.c_int, szp, szp]
+    lib.loamx_shard_range.restype = None
+    lib.loamx_comm_get_unique_id.argtypes = [C.c_char_p]
+    lib.loamx_comm_create.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.loamx_comm_wrap.argtypes = [vp, vp, C.POINTER(vp)]
+    lib.loamx_comm_destroy.argtypes = [vp]
+    lib.loamx_comm_destroy.restype = None
+    lib.loamx_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.loamx_gather_results_dev.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, vp]
+    lib.loamx_comm_barrier.argtypes = [vp, vp, dp]
     _lib = lib
     return lib
 
@@ -200,6 +213,55 @@ def synth_scan_host(seed, pair_id, which, scan_lines, points_per_line, sigma=0.0
     out = np.empty((scan_lines * points_per_line, 3))
     load().loamx_synth_scan_host(seed, pair_id, which, scan_lines, points_per_line, sigma, _dp(out))
     return out
+
+
+COMM_ID_BYTES = 128
+
+
+def shard_range(total_pairs, world_size, rank):
+    """[first, first + count) of `rank`: the partition loamx_gather_results_dev expects (pure host arithmetic)."""
+    f, n = C.c_size_t(0), C.c_size_t(0)
+    load().loamx_shard_range(total_pairs, world_size, rank, C.byref(f), C.byref(n))
+    return f.value, n.value
+
+
+def comm_unique_id():
+    """128-byte RCCL unique id; rank 0 creates it and hands it to every rank (loamx_comm_get_unique_id)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = load().loamx_comm_get_unique_id(buf)
+    if rc != OK:
+        raise LoamxError(rc, "loamx_comm_get_unique_id: " + load().loamx_status_string(rc).decode())
+    return buf.raw
+
+
+class Comm:
+    """RCCL communicator of the multi-GPU batch mode (loamx_comm): one rank per process and GPU."""
+
+    def __init__(self, ctx, unique_id, world_size, rank):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._check(ctx.lib.loamx_comm_create(ctx.h, bytes(unique_id), world_size, rank, C.byref(h)))
+        self.h = h
+
+    def info(self):
+        w, r, d = C.c_int(0), C.c_int(0), C.c_int(0)
+        self.ctx._check(self.ctx.lib.loamx_comm_info(self.h, C.byref(w), C.byref(r), C.byref(d)))
+        return dict(world_size=w.value, rank=r.value, device=d.value)
+
+    def gather_results_dev(self, d_local, n_local, total_pairs, d_all):
+        """all ranks: d_all[total_pairs] <- every rank's records in pair-id order (asynchronous on the context stream)"""
+        self.ctx._check(self.ctx.lib.loamx_gather_results_dev(self.ctx.h, self.h, d_local, n_local, total_pairs, d_all))
+
+    def barrier(self, value=0.0):
+        """waits for all ranks; returns the maximum of `value` over the ranks"""
+        v = C.c_double(value)
+        self.ctx._check(self.ctx.lib.loamx_comm_barrier(self.ctx.h, self.h, C.byref(v)))
+        return v.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.loamx_comm_destroy(self.h)
+            self.h = None
 
 
 class DeviceBuffer:

@@ -10,6 +10,8 @@
 #include <string>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "loamx_internal.h"
 #include "synth.h"
 
@@ -84,7 +86,7 @@ namespace {
 
 const char* kKernelNames[LOAMX_K_COUNT] = {"curvature_valid_kernel", "select_kernel", "compact_kernel",
                                            "grid_build_kernel",      "associate_kernel", "sweep_kernel",
-                                           "lm_kernels",             "moment_kernel"};
+                                           "lm_kernels",             "moment_kernel",    "knn_plane_kernel"};
 
 int fail(loamx_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->last_error = msg;
@@ -453,8 +455,20 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
       // one 64 x 1024 pair 1.15 ms with the auxiliary streams, 1.10 ms without; one 128 x 2048 scan against a
       // 1 M-point map the other way round: 5.9 vs 6.8 ms)
       const bool side = (size_t)B.n_pairs * B.assoc_blocks_plane >= 128;
+      // sub-scope: the plane round-1 k-NN kernel alone (events attached to its own dispatch)
+      PendingEvent knn{};
+      LaunchScope knn_ls{nullptr, nullptr, true};
+      if (ctx->timing) {
+        knn.kernel = LOAMX_K_KNN_PLANE, knn.bytes = 0.0, knn.own_e0 = true;
+        knn.e0 = take_event(ctx), knn.e1 = take_event(ctx);
+        knn_ls = LaunchScope{knn.e0, knn.e1, true};
+      }
       launch_associate(B, C, s, side ? ctx->aux_stream : nullptr, side ? ctx->aux2_stream : nullptr, ctx->ev_fork, ctx->ev_mid, ctx->ev_join,
-                       ctx->ev_join2);
+                       ctx->ev_join2, ctx->timing ? &knn_ls : nullptr);
+      if (ctx->timing) {
+        if (knn_ls.first) ctx->event_pool.push_back(knn.e0), ctx->event_pool.push_back(knn.e1);  // (kernel not launched)
+        else ctx->pending.push_back(knn);
+      }
     }
     CHECK_LAUNCH(ctx, "associate_kernel");
 #ifdef LOAMX_NN_SAME_STATS
@@ -546,6 +560,7 @@ const char* loamx_status_string(int status) {
     case LOAMX_ERR_CAPACITY: return "output capacity too small";
     case LOAMX_ERR_UNSUPPORTED: return "unsupported parameter combination";
     case LOAMX_ERR_NO_DEVICE: return "no usable HIP device";
+    case LOAMX_ERR_COMM: return "RCCL error";
     default: return "unknown status";
   }
 }
@@ -1212,6 +1227,161 @@ int loamx_copy_to_host(loamx_ctx* ctx, void* h_dst, const void* d_src, size_t by
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return LOAMX_OK;
+}
+
+/* ---- multi-GPU batch mode: RCCL gather of the result records ---------------------------------------------- */
+}  // extern "C"
+
+struct loamx_comm {
+  ncclComm_t comm = nullptr;
+  bool owned = false;
+  int world = 1, rank = 0, device = 0;
+  double* d_scalar = nullptr;  // barrier / max-reduce scratch (device)
+};
+
+namespace {
+#define NCCL_TRY(ctx, expr)                                                                        \
+  do {                                                                                             \
+    ncclResult_t r_ = (expr);                                                                      \
+    if (r_ != ncclSuccess) return fail(ctx, LOAMX_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(r_)); \
+  } while (0)
+
+int comm_finish_init(loamx_ctx* ctx, loamx_comm* c) {
+  NCCL_TRY(ctx, ncclCommCount(c->comm, &c->world));
+  NCCL_TRY(ctx, ncclCommUserRank(c->comm, &c->rank));
+  NCCL_TRY(ctx, ncclCommCuDevice(c->comm, &c->device));
+  if (c->device != ctx->device) return fail(ctx, LOAMX_ERR_BAD_PARAM, "communicator and context live on different devices");
+  HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&c->d_scalar), 2 * sizeof(double)));
+  return LOAMX_OK;
+}
+}  // namespace
+
+extern "C" {
+
+void loamx_shard_range(size_t total_pairs, int world_size, int rank, size_t* first, size_t* count) {
+  const size_t w = world_size > 0 ? (size_t)world_size : 1, r = rank > 0 ? (size_t)rank : 0;
+  const size_t base = total_pairs / w, rem = total_pairs % w;
+  if (first) *first = r * base + (r < rem ? r : rem);
+  if (count) *count = r < w ? base + (r < rem ? 1 : 0) : 0;
+}
+
+int loamx_comm_get_unique_id(unsigned char id_out[LOAMX_COMM_ID_BYTES]) {
+  static_assert(LOAMX_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+  if (!id_out) return LOAMX_ERR_BAD_PARAM;
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return LOAMX_ERR_COMM;
+  memcpy(id_out, id.internal, NCCL_UNIQUE_ID_BYTES);
+  return LOAMX_OK;
+}
+
+int loamx_comm_create(loamx_ctx* ctx, const unsigned char id[LOAMX_COMM_ID_BYTES], int world_size, int rank, loamx_comm** out) {
+  if (!ctx || !id || !out) return LOAMX_ERR_BAD_PARAM;
+  *out = nullptr;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (world_size < 1 || rank < 0 || rank >= world_size) return fail(ctx, LOAMX_ERR_BAD_PARAM, "bad world size / rank");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ncclUniqueId uid;
+  memcpy(uid.internal, id, NCCL_UNIQUE_ID_BYTES);
+  loamx_comm* c = new loamx_comm;
+  c->owned = true;
+  ncclResult_t r = ncclCommInitRank(&c->comm, world_size, uid, rank);
+  if (r != ncclSuccess) {
+    delete c;
+    return fail(ctx, LOAMX_ERR_COMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+  }
+  int rc = comm_finish_init(ctx, c);
+  if (rc != LOAMX_OK) {
+    loamx_comm_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return LOAMX_OK;
+}
+
+int loamx_comm_wrap(loamx_ctx* ctx, void* nccl_comm, loamx_comm** out) {
+  if (!ctx || !nccl_comm || !out) return LOAMX_ERR_BAD_PARAM;
+  *out = nullptr;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  loamx_comm* c = new loamx_comm;
+  c->comm = static_cast<ncclComm_t>(nccl_comm), c->owned = false;
+  int rc = comm_finish_init(ctx, c);
+  if (rc != LOAMX_OK) {
+    loamx_comm_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return LOAMX_OK;
+}
+
+void loamx_comm_destroy(loamx_comm* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->d_scalar) (void)hipFree(c->d_scalar);
+  if (c->owned && c->comm) (void)ncclCommDestroy(c->comm);
+  delete c;
+}
+
+int loamx_comm_info(const loamx_comm* c, int* world_size, int* rank, int* device) {
+  if (!c) return LOAMX_ERR_BAD_PARAM;
+  if (world_size) *world_size = c->world;
+  if (rank) *rank = c->rank;
+  if (device) *device = c->device;
+  return LOAMX_OK;
+}
+
+int loamx_gather_results_dev(loamx_ctx* ctx, loamx_comm* c, const loamx_reg_result* d_local, size_t n_local, size_t total_pairs,
+                             loamx_reg_result* d_all) {
+  if (!ctx || !c || !d_all || (n_local && !d_local)) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  size_t first = 0, count = 0;
+  loamx_shard_range(total_pairs, c->world, c->rank, &first, &count);
+  if (count != n_local) return fail(ctx, LOAMX_ERR_BAD_PARAM, "n_local is not this rank's shard of total_pairs (loamx_shard_range)");
+  if (total_pairs == 0) return LOAMX_OK;
+  untimed(ctx);
+  hipStream_t s = ctx->stream;
+  static_assert(sizeof(loamx_reg_result) == 64, "record size");
+  if (c->world == 1) {
+    if (d_all != d_local) HIP_TRY(ctx, hipMemcpyAsync(d_all, d_local, n_local * sizeof(loamx_reg_result), hipMemcpyDeviceToDevice, s));
+    return LOAMX_OK;
+  }
+  if (total_pairs % (size_t)c->world == 0) {  // equal shards: one all-gather of n_local * 64 bytes per rank
+    NCCL_TRY(ctx, ncclAllGather(d_local, d_all, n_local * sizeof(loamx_reg_result), ncclChar, c->comm, s));
+    return LOAMX_OK;
+  }
+  // uneven shards (sizes differ by one): every rank broadcasts its block to its place, as one grouped operation
+  NCCL_TRY(ctx, ncclGroupStart());
+  for (int r = 0; r < c->world; r++) {
+    size_t f = 0, n = 0;
+    loamx_shard_range(total_pairs, c->world, r, &f, &n);
+    if (n == 0) continue;
+    ncclResult_t rr = ncclBroadcast(r == c->rank ? static_cast<const void*>(d_local) : static_cast<const void*>(d_all + f), d_all + f,
+                                    n * sizeof(loamx_reg_result), ncclChar, r, c->comm, s);
+    if (rr != ncclSuccess) {
+      (void)ncclGroupEnd();
+      return fail(ctx, LOAMX_ERR_COMM, std::string("ncclBroadcast: ") + ncclGetErrorString(rr));
+    }
+  }
+  NCCL_TRY(ctx, ncclGroupEnd());
+  return LOAMX_OK;
+}
+
+int loamx_comm_barrier(loamx_ctx* ctx, loamx_comm* c, double* max_value) {
+  if (!ctx || !c) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  untimed(ctx);
+  hipStream_t s = ctx->stream;
+  const double v = max_value ? *max_value : 0.0;
+  HIP_TRY(ctx, hipMemcpyAsync(c->d_scalar, &v, sizeof(double), hipMemcpyHostToDevice, s));
+  if (c->world > 1) NCCL_TRY(ctx, ncclAllReduce(c->d_scalar, c->d_scalar + 1, 1, ncclDouble, ncclMax, c->comm, s));
+  else HIP_TRY(ctx, hipMemcpyAsync(c->d_scalar + 1, c->d_scalar, sizeof(double), hipMemcpyDeviceToDevice, s));
+  double o = 0.0;
+  HIP_TRY(ctx, hipMemcpyAsync(&o, c->d_scalar + 1, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  if (max_value) *max_value = o;
   return LOAMX_OK;
 }
 

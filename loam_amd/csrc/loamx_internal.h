@@ -187,8 +187,9 @@ void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_
 void launch_grid_build_sources(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_state_init(const RegBatch& B, const RegConfig& C, hipStream_t s);
 // aux == nullptr: everything on s; aux2 == nullptr: the plane queue chain follows the edge chain on aux
+// knn_scope != nullptr: the plane round-1 k-NN kernel is launched with that timing scope attached
 void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipStream_t aux, hipStream_t aux2, hipEvent_t ev_fork,
-                      hipEvent_t ev_mid, hipEvent_t ev_join, hipEvent_t ev_join2);
+                      hipEvent_t ev_mid, hipEvent_t ev_join, hipEvent_t ev_join2, LaunchScope* knn_scope = nullptr);
 #ifdef LOAMX_NN_SAME_STATS
 void debug_nn_same(const RegBatch& B, uint32_t it, hipStream_t s);
 #endif

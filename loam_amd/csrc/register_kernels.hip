@@ -1328,7 +1328,7 @@ static uint32_t rest_blocks(size_t n_pairs, uint32_t nblk) {
   return want < cover ? want : cover;
 }
 void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipStream_t aux, hipStream_t aux2, hipEvent_t ev_fork,
-                      hipEvent_t ev_mid, hipEvent_t ev_join, hipEvent_t ev_join2) {
+                      hipEvent_t ev_mid, hipEvent_t ev_join, hipEvent_t ev_join2, LaunchScope* knn_scope) {
   if (B.n_pairs == 0) return;
   const uint32_t be = B.assoc_blocks_edge != 0xFFFFFFFFu ? B.assoc_blocks_edge : (uint32_t)((B.edge_stride + kAssocThreads - 1) / kAssocThreads);
   const uint32_t bp = B.assoc_blocks_plane != 0xFFFFFFFFu ? B.assoc_blocks_plane : (uint32_t)((B.planar_stride + kAssocThreads - 1) / kAssocThreads);
@@ -1343,8 +1343,12 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
   do {                                                                                                            \
     const dim3 grid_((unsigned)(pair_groups * 8 * (nblk)));                                                       \
     const uint32_t mode_ = (PL) ? B.knn_mode_plane : B.knn_mode_edge; /* a kernel no pair needs is not launched */   \
-    if (mode_ != 2u)                                                                                              \
+    if (mode_ != 2u) {                                                                                            \
+      LaunchScope* outer_ = g_launch_scope;                                                                       \
+      if ((PL) && knn_scope) g_launch_scope = knn_scope;                                                          \
       launch_kernel((associate_knn_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, (st), B, C, (nblk));     \
+      g_launch_scope = outer_;                                                                                    \
+    }                                                                                                             \
     if (mode_ != 1u)                                                                                              \
       launch_kernel((associate_knn_brute_kernel<PL, KMV>), grid_, dim3(kAssocThreads), 0, (st), B, C, (nblk)); \
   } while (0)

@@ -1,0 +1,96 @@
+"""GPU: BASELINE configs[2]/[3] at full size on one card.
+  * the RCCL gather behind the C ABI (loamx_comm_*, loamx_gather_results_dev), exercised with a 1-rank communicator;
+  * the 8-shard x 1 024-pair plan of configs[3] run shard by shard on this GPU: the concatenation equals ONE
+    8 192-pair call bit for bit (pairs are independent units: the sharding can not change a result);
+  * the 1 024-pair batch of configs[2] against the CPU oracle on a 64-pair sample."""
+import os
+
+import numpy as np
+import pytest
+
+from gpu_common import ctx, pose_diff
+from loam_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+H, W, SEED = 64, 1024, 20240311  # the bench workload (bench.py)
+N = H * W
+
+
+def _run(c, d_xyz_ptr, n_pairs, d_res):
+    lidar = capi.LidarParams(H, W, 1.0, 120.0)
+    c.register_scan_pairs_dev(d_xyz_ptr, n_pairs, lidar, capi.FeatureExtractionParams(), capi.RegistrationParams(), d_res.ptr)
+    c.synchronize()
+    return d_res.download(np.uint8, n_pairs * 64).copy()
+
+
+def test_rccl_gather_behind_the_c_abi_one_rank():
+    c = ctx()
+    comm = capi.Comm(c, capi.comm_unique_id(), 1, 0)
+    info = comm.info()
+    assert info["world_size"] == 1 and info["rank"] == 0
+    rec = np.zeros(5, dtype=capi.RESULT_DTYPE)
+    rec["pose"] = np.arange(35, dtype=np.float64).reshape(5, 7)
+    rec["termination"], rec["iterations"] = np.arange(5), 7 - np.arange(5)
+    d_local, d_all = c.alloc(5 * 64).upload(rec.view(np.uint8)), c.alloc(5 * 64)
+    comm.gather_results_dev(d_local.ptr, 5, 5, d_all.ptr)
+    assert comm.barrier(3.5) == 3.5
+    assert np.array_equal(d_all.download(np.uint8, 5 * 64), rec.view(np.uint8))
+    with pytest.raises(capi.LoamxError):  # not this rank's shard
+        comm.gather_results_dev(d_local.ptr, 4, 5, d_all.ptr)
+    comm.close()
+    d_local.free()
+    d_all.free()
+
+
+def test_1024_pair_batch_against_the_oracle_sample(oracle):
+    """configs[2]: the bench's own batch; 64 pairs spread over it are checked against the CPU oracle"""
+    c = ctx()
+    P = 1024
+    d_xyz, d_res = c.alloc(P * 2 * N * 24), c.alloc(P * 64)
+    c.synth_scan_pairs_dev(SEED, 0, P, H, W, 0.01, d_xyz.ptr)
+    res = _run(c, d_xyz.ptr, P, d_res).view(capi.RESULT_DTYPE)
+    d_xyz.free()
+    d_res.free()
+    assert (res["termination"] == capi.CONVERGED).all()
+    worst = (0.0, 0.0)
+    for pr in range(5, P, 16):  # 64 pairs
+        A = capi.synth_scan_host(SEED, pr, 0, H, W, 0.01)
+        B = capi.synth_scan_host(SEED, pr, 1, H, W, 0.01)
+        ea, pa = oracle.extract_features(A, H, W, 1.0, 120.0)
+        eb, pb = oracle.extract_features(B, H, W, 1.0, 120.0)
+        po, to, io = oracle.register_features(B[eb], B[pb], A[ea], A[pa])
+        assert (res[pr]["termination"], res[pr]["iterations"]) == (to, io), pr
+        rot, trans = pose_diff(oracle, po, res[pr]["pose"])
+        assert rot < 1e-5 and trans < 1e-5, (pr, rot, trans)
+        worst = (max(worst[0], rot), max(worst[1], trans))
+        rot, trans = pose_diff(oracle, capi.synth_pair_pose(SEED, pr), res[pr]["pose"])  # and the known SE(3)
+        assert rot < 5e-3 and trans < 3e-2, (pr, rot, trans)
+    print("1024-pair batch, 64-pair oracle sample: worst SE(3) difference", worst)
+
+
+def test_eight_shard_plan_equals_one_8192_pair_call():
+    """configs[3] on one GPU: rank r of 8 owns pairs [1024 r, 1024 (r + 1)) (loamx_shard_range); the eight shard
+    results, concatenated in rank order as the gather does, are the bits of one 8 192-pair call."""
+    c = ctx()
+    world, P = 8, int(os.environ.get("LOAMX_TEST_SHARD_PAIRS", "1024"))
+    total = world * P
+    d_xyz, d_res = c.alloc(total * 2 * N * 24), c.alloc(total * 64)  # 25.8 GB of scans
+    c.synth_scan_pairs_dev(SEED, 0, total, H, W, 0.01, d_xyz.ptr)
+    whole = _run(c, d_xyz.ptr, total, d_res)
+    parts = []
+    for r in range(world):
+        first, count = capi.shard_range(total, world, r)
+        assert (first, count) == (r * P, P)
+        parts.append(_run(c, d_xyz.ptr + first * 2 * N * 24, count, d_res))
+    d_xyz.free()
+    d_res.free()
+    assert np.array_equal(np.concatenate(parts), whole)
+    rec = whole.view(capi.RESULT_DTYPE)
+    assert (rec["termination"] == capi.CONVERGED).all()
+    # a rank that generates its own shard (first_pair = its offset), as bench.py does, gets the same scans
+    d_xyz, d_res = c.alloc(P * 2 * N * 24), c.alloc(P * 64)
+    c.synth_scan_pairs_dev(SEED, 5 * P, P, H, W, 0.01, d_xyz.ptr)
+    assert np.array_equal(_run(c, d_xyz.ptr, P, d_res), parts[5])
+    d_xyz.free()
+    d_res.free()

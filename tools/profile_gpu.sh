@@ -7,6 +7,7 @@ tag=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 D=$ROOT/gpurun_out/prof_$tag
 rm -rf "$D"; mkdir -p "$D"
+(cd "$ROOT" && python3 -c "from loam_amd import build; print(build.source_hash())" > "$D/source_sha256.txt")
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$D/trace" --output-format csv -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$D/bench_under_rocprof.log" 2> "$D/trace.err"
 echo "trace done"

@@ -18,6 +18,12 @@ import re
 import sys
 
 
+def source_hash():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from loam_amd import build
+    return build.source_hash()
+
+
 def short(name):
     m = re.search(r"(\w+_kernel(?:<[\w, ]+>)?)", name)
     return m.group(1) if m else name[:48]
@@ -108,8 +114,8 @@ def main():
                       f"{'' if algo is None else f'{algo/1e6:.2f}'} | {'' if ratio is None else f'{ratio:.3f}'} |")
         cfg = bj.get("config", {})
         scopes = {k: v["launches"] for k, v in kern.items()}  # HIP-event scopes of that run (associate = kNN + fit, edge + plane)
-        json.dump({"source": os.path.basename(src), "bench_config": cfg, "event_scopes": scopes, "kernels": out},
-                  open(dst + "_pmc.json", "w"), indent=1)
+        pmc_json = {"source": os.path.basename(src), "source_sha256": (open(os.path.join(src, "source_sha256.txt")).read().strip() if os.path.exists(os.path.join(src, "source_sha256.txt")) else source_hash()), "bench_config": cfg, "event_scopes": scopes, "kernels": out}
+        json.dump(pmc_json, open(dst + "_pmc.json", "w"), indent=1)
     # any further counter passes (pmc_x*): per-kernel average per dispatch
     extra = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
     for f in sorted(glob.glob(os.path.join(src, "pmc_x*", "*", "*_counter_collection.csv"))):
@@ -117,6 +123,10 @@ def main():
             a = extra[short(r["Kernel_Name"])][r["Counter_Name"]]
             a[0] += 1
             a[1] += float(r["Counter_Value"])
+    if extra and os.path.exists(dst + "_pmc.json"):  # averages per dispatch, for bench.py's compute roofline
+        pj = json.load(open(dst + "_pmc.json"))
+        pj["counters"] = {k: {c: v[1] / v[0] for c, v in extra[k].items()} for k in extra}
+        json.dump(pj, open(dst + "_pmc.json", "w"), indent=1)
     if extra:
         ctrs = sorted({c for k in extra for c in extra[k]})
         md += ["", "## Other counters (average per dispatch, one `--pmc` pass per set)", "",
