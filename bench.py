@@ -83,6 +83,21 @@ def source_hash():
     return B.source_hash()
 
 
+def cgroup_cpu_quota():
+    """CPUs this process may use at once according to its cgroup (cpu.max / cfs quota), or None if unlimited."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / per if q > 0 else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(scans, pairs, threads):
     """Times the oracle (extract x2 + register per pair) on `threads` host threads; returns (outputs, wall seconds)."""
     from concurrent.futures import ThreadPoolExecutor
@@ -320,7 +335,8 @@ def main():
         if n_gpus == 1 and not args.no_cpu_baseline:
             import oracle_lib as O
             affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            threads = max(1, affinity)
+            quota = cgroup_cpu_quota()  # the GPU box hands one GPU's share of the host: 16 of its 256 CPUs
+            threads = max(1, min(affinity, int(quota + 0.5)) if quota else affinity)
             # ~45-50 ms of CPU per pair: 64 pairs per thread ~ 3 s of wall time; one thread: 64 pairs ~ 3 s
             n_sample = args.cpu_sample if args.cpu_sample > 0 else min(P, 64 * threads)
             n_single = min(P, 64)
@@ -333,7 +349,7 @@ def main():
                                    "single_thread": {"value": round(min(n_single, n_sample) / dt1, 3), "unit": "pairs/s", "cores": 1,
                                                      "sample": f"first {min(n_single, n_sample)} pairs, one at a time, {dt1:.2f} s wall "
                                                                "(comparable to the reference's README.md:31: 3.5 ms x 2 + 13 ms per pair)"},
-                                   "host_cpu_count": os.cpu_count(), "host_affinity": affinity}
+                                   "host_cpu_count": os.cpu_count(), "host_affinity": affinity, "cgroup_cpu_quota": quota}
             max_rot = max_trans = 0.0
             term_equal = True
             for pr, (_, pose, term, iters) in enumerate(cpu_out):

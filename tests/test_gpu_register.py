@@ -274,3 +274,26 @@ def test_scan_pairs_128x2048_use_the_big_set_paths(oracle):
         assert rot < SE3_TOL and trans < SE3_TOL, (pr, rot, trans)
     d_xyz.free()
     d_res.free()
+
+
+def test_non_finite_jacobian_path(oracle):
+    """Edge points exactly on their fitted lines (geometry-inl.h:24-26 under autodiff: residual 0, derivative 0/0):
+    Ceres fails the initial evaluation and leaves the update at the identity, which registration-inl.h:68-73 reads
+    as converged. Oracle and kernels must take the same path (tests/test_oracle_crosschecks.py builds the scene)."""
+    from test_oracle_crosschecks import nan_jacobian_scene
+    edge, planar = nan_jacobian_scene()
+    ident = np.array([0, 0, 0, 1.0, 0, 0, 0])
+    po, to, io = oracle.register_features(edge, planar, edge, planar)
+    pg, tg, ig, det = ctx().register_features(edge, planar, edge, planar, want_detail=True)
+    assert (tg, ig) == (to, io) == (capi.CONVERGED, 1)
+    assert np.array_equal(pg, ident) and np.array_equal(po, ident)
+    assert np.array_equal(det["iterations"][0]["estimate_update"], ident)
+    assert det["iterations"][0]["n_edge"] == len(edge)  # the associations exist; it is their Jacobian that is not finite
+    # moved off the lines, the same scene is solved normally and agrees with the oracle
+    T = K.pose7(K.quat_angle_axis(0.01, (0, 1, 0)), (0.01, 0.0, 0.0))
+    se, sp = K.transform_points(T, edge), K.transform_points(T, planar)
+    po, to, io = oracle.register_features(se, sp, edge, planar)
+    pg, tg, ig = ctx().register_features(se, sp, edge, planar)
+    assert (tg, ig) == (to, io)
+    rot, trans = pose_diff(oracle, po, pg)
+    assert rot < SE3_TOL and trans < SE3_TOL, (rot, trans)
