@@ -123,6 +123,12 @@ void loamx_ctx_destroy(loamx_ctx* ctx);
  * non-zero handle of an explicit side stream) before another stream or library reads the results. */
 int loamx_ctx_set_stream(loamx_ctx* ctx, void* hip_stream);
 int loamx_ctx_synchronize(loamx_ctx* ctx);
+/* Cumulative counters of the two rare paths of the extraction kernels (synchronises the stream):
+ *   tie_replays    scan lines on which two candidates of EQUAL curvature could decide a pick or the output order and
+ *                  which were therefore replayed in the order libstdc++'s std::sort gives the reference (features-inl.h:38)
+ *   scan_fallbacks calls in which a scan line gave up its (bounded) wait for the lines before it and the features were
+ *                  gathered by the fallback kernel instead — the results are the same */
+int loamx_ctx_extract_counters(loamx_ctx* ctx, uint64_t* tie_replays, uint64_t* scan_fallbacks);
 
 /* ---- host entry points (one scan / one pair; H2D, kernels, D2H, synchronous) ------------------ */
 

@@ -85,7 +85,7 @@ EXPORTS = [
     "loamx_extract_features_batch_dev_f32", "loamx_register_scan_pairs_dev_f32",
     "loamx_target_index_insert", "loamx_target_index_size",
     "loamx_shard_range", "loamx_comm_get_unique_id", "loamx_comm_create", "loamx_comm_wrap", "loamx_comm_destroy",
-    "loamx_comm_info", "loamx_gather_results_dev", "loamx_comm_barrier",
+    "loamx_comm_info", "loamx_gather_results_dev", "loamx_comm_barrier", "loamx_ctx_extract_counters",
 ]
 
 _lib = None
@@ -174,6 +174,7 @@ def load(build_if_missing=True):
     lib.loamx_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.loamx_gather_results_dev.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, vp]
     lib.loamx_comm_barrier.argtypes = [vp, vp, dp]
+    lib.loamx_ctx_extract_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = lib
     return lib
 
@@ -324,6 +325,12 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.loamx_ctx_synchronize(self.h))
+
+    def extract_counters(self):
+        """(scan lines replayed in the reference's tie order, give-up fallbacks of the fused compaction), cumulative"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.lib.loamx_ctx_extract_counters(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)

@@ -230,28 +230,42 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// LDS bytes of replay_kernel's wavefront: curvature, mask, and the 16-bit index array that is sorted
+__host__ __device__ inline size_t replay_lds_bytes(int W) { return (size_t)W * 8 + (((size_t)W + 7) & ~(size_t)7) + (((size_t)W * 2 + 7) & ~(size_t)7); }
+
+// tie: set when the best remaining candidate is not unique (two valid candidates of equal curvature compete for a
+// pick: which one the reference takes is std::sort's business — the caller replays the line, ring_replay)
 template <bool EDGE>
 __device__ __forceinline__ uint32_t select_pass(const double* s_c, volatile uint8_t* s_v, int lane, int start, int end,
                                                 double thr, uint32_t max_feats, uint32_t np, uint32_t line_base,
-                                                uint32_t* __restrict__ stage) {
+                                                uint32_t* __restrict__ stage, bool& tie) {
   uint32_t n = 0;
   for (;;) {
     double bc = 0.0;
     int32_t bi = -1;
+    bool tied = false;  // the value bc is held by more than one candidate seen so far
     for (int i = start + lane; i < end; i += 64) {
       if (s_v[i]) {
         const double c = s_c[i];
         const bool cand = EDGE ? (c > thr) : (c < thr);
-        if (cand && (bi < 0 || (EDGE ? edge_before(c, i, bc, bi) : planar_before(c, i, bc, bi)))) bc = c, bi = i;
+        if (cand) {
+          if (bi >= 0 && c == bc) tied = true;
+          else if (bi < 0 || (EDGE ? edge_before(c, i, bc, bi) : planar_before(c, i, bc, bi))) bc = c, bi = i, tied = false;
+        }
       }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       const double oc = __shfl_xor(bc, off);
       const int32_t oi = __shfl_xor(bi, off);
-      if (oi >= 0 && (bi < 0 || (EDGE ? edge_before(oc, oi, bc, bi) : planar_before(oc, oi, bc, bi)))) bc = oc, bi = oi;
+      const bool ot = __shfl_xor((int)tied, off) != 0;
+      if (oi >= 0) {
+        if (bi >= 0 && oc == bc) tied = true, bi = (EDGE ? oi > bi : oi < bi) ? oi : bi;
+        else if (bi < 0 || (EDGE ? edge_before(oc, oi, bc, bi) : planar_before(oc, oi, bc, bi))) bc = oc, bi = oi, tied = ot;
+      }
     }
     if (bi < 0) break;  // wave-uniform: every lane holds the same winner
+    if (tied) tie = true;  // (uniform)
     if (lane == 0) stage[n] = line_base + (uint32_t)bi;
     if ((uint32_t)lane < np) {  // features-inl.h:148-151 / :170-173: idx +- n for n = 0 .. np-1
       s_v[bi + lane] = 0;
@@ -267,7 +281,8 @@ __device__ __forceinline__ uint32_t select_pass(const double* s_c, volatile uint
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void select_kernel(const double* __restrict__ curv,
                                                             const uint8_t* __restrict__ mask, size_t n_lines,
-                                                            ExtractParams P, ExtractStage st) {
+                                                            ExtractParams P, ExtractStage st, unsigned long long* line_tot,
+                                                            uint32_t* flags) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const size_t line = (size_t)blockIdx.x * WAVES + wave;
@@ -282,19 +297,23 @@ __global__ __launch_bounds__(WAVES * 64) void select_kernel(const double* __rest
   }
   wave_lds_sync();
   const uint32_t line_base = (uint32_t)(line % P.H) * P.W;
-  const uint32_t idx_mask = W <= 2 ? 1u : (0xFFFFFFFFu >> __clz(W - 1));  // index-in-line bits of the sort keys
+  bool tie = false;  // wave-uniform
   for (uint32_t s = 0; s < P.S; s++) {
     const int start = (int)(s * P.pps);
     const int end = (s == P.S - 1) ? W : start + (int)P.pps;  // features-inl.h:31-35
     const size_t group = line * P.S + s;
     const uint32_t ne = select_pass<true>(s_c, s_v, lane, start, end, P.edge_thr, P.max_edge, P.np, line_base,
-                                          st.edge_stage + group * P.cap_edge);
+                                          st.edge_stage + group * P.cap_edge, tie);
     const uint32_t npl = select_pass<false>(s_c, s_v, lane, start, end, P.planar_thr, P.max_planar, P.np, line_base,
-                                            st.planar_stage + group * P.cap_planar);
+                                            st.planar_stage + group * P.cap_planar, tie);
     if (lane == 0) {
       st.edge_cnt[group] = ne;
       st.planar_cnt[group] = npl;
     }
+  }
+  if ((tie || (P.flags & kFlagForceReplay)) && line_tot && lane == 0) {  // replay_kernel redoes this line in the reference's own order
+    __hip_atomic_store(line_tot + line, 1ull << 62, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    atomicOr(flags, 2u);
   }
 }
 
@@ -377,6 +396,89 @@ __device__ __forceinline__ double xor_lane_f64(double v, int j, int lane) {  // 
   }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * The tie path (row a7). When two candidates of EQUAL curvature can decide a pick or the output order, the
+ * reference's result depends on where libstdc++'s std::sort leaves them (features-inl.h:38). The selection kernels
+ * only DETECT such scan lines (they poison the line's slot in line_tot and raise bit 1 of the flag word);
+ * replay_kernel, launched right behind them, then replays those lines literally: every sector's index array is
+ * sorted by stl_sort (extract_math.h: libstdc++'s introsort restated; one lane per sector), and one lane walks the
+ * sectors in order exactly as extractSectorEdgeFeatures / extractSectorPlanarFeatures do (features-inl.h:137-180),
+ * rewriting the line's stage entries and counts, from which the compaction kernel gathers. Slow and rare: noisy
+ * scans have no exact ties, and then every workgroup of replay_kernel leaves after one load.
+ * ---------------------------------------------------------------------------------------------- */
+constexpr unsigned long long kLinePublished = 1ull << 63, kLineTied = 1ull << 62;
+constexpr uint32_t kFlagGaveUp = 1u, kFlagTie = 2u;  // bits of the flag word behind line_tot
+
+__device__ void ring_replay(const double* s_c, uint8_t* s_v, uint16_t* s_ord, int lane, int W, const ExtractParams& P,
+                            uint32_t line_base, size_t line, const ExtractStage& st) {
+  for (int i = lane; i < W; i += 64) s_ord[i] = (uint16_t)i;
+  wave_lds_sync();
+  for (uint32_t s = (uint32_t)lane; s < P.S; s += 64) {
+    const int start = (int)(s * P.pps), end = (s == P.S - 1) ? W : start + (int)P.pps;  // features-inl.h:31-35
+    stl_sort(s_ord, start, end, [&](uint16_t a, uint16_t b) { return s_c[a] < s_c[b]; });
+  }
+  wave_lds_sync();
+  if (lane == 0) {
+    const int np = (int)P.np;
+    for (uint32_t s = 0; s < P.S; s++) {
+      const int start = (int)(s * P.pps), end = (s == P.S - 1) ? W : start + (int)P.pps;
+      const size_t group = line * P.S + s;
+      uint32_t ne = 0, npl = 0;
+      uint32_t* __restrict__ se = st.edge_stage + group * P.cap_edge;
+      uint32_t* __restrict__ spn = st.planar_stage + group * P.cap_planar;
+      for (int k = end; k > start; k--) {  // features-inl.h:143-156
+        const int idx = (int)s_ord[k - 1];
+        if (s_v[idx] && s_c[idx] > P.edge_thr) {
+          if (ne < P.cap_edge) se[ne] = line_base + (uint32_t)idx;
+          for (int n = 0; n < np; n++) {
+            if (idx + n < W) s_v[idx + n] = 0;
+            if (idx - n >= 0) s_v[idx - n] = 0;
+          }
+          ne++;
+        }
+        if (ne > P.max_edge) break;
+      }
+      for (int k = start; k < end; k++) {  // features-inl.h:166-178
+        const int idx = (int)s_ord[k];
+        if (s_v[idx] && s_c[idx] < P.planar_thr) {
+          if (npl < P.cap_planar) spn[npl] = line_base + (uint32_t)idx;
+          for (int n = 0; n < np; n++) {
+            if (idx + n < W) s_v[idx + n] = 0;
+            if (idx - n >= 0) s_v[idx - n] = 0;
+          }
+          npl++;
+        }
+        if (npl > P.max_planar) break;
+      }
+      st.edge_cnt[group] = ne < P.cap_edge ? ne : P.cap_edge;
+      st.planar_cnt[group] = npl < P.cap_planar ? npl : P.cap_planar;
+    }
+  }
+}
+
+// one wavefront per workgroup, lines dealt round-robin; a line is replayed iff its line_tot slot carries kLineTied
+__global__ __launch_bounds__(64) void replay_kernel(const double* __restrict__ curv, const uint8_t* __restrict__ mask, size_t n_lines,
+                                                    ExtractParams P, ExtractStage st, const unsigned long long* __restrict__ line_tot,
+                                                    const uint32_t* __restrict__ flags, unsigned long long* __restrict__ events) {
+  if ((__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kFlagTie) == 0u) return;  // uniform: no tied line in this launch
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x, W = (int)P.W;
+  double* s_c = reinterpret_cast<double*>(smem);
+  uint8_t* s_v = reinterpret_cast<uint8_t*>(s_c + W);
+  uint16_t* s_ord = reinterpret_cast<uint16_t*>(s_v + (((size_t)W + 7) & ~(size_t)7));
+  for (size_t line = blockIdx.x; line < n_lines; line += gridDim.x) {
+    if ((__hip_atomic_load(line_tot + line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kLineTied) == 0ull) continue;  // uniform
+    wave_lds_sync();
+    for (int i = lane; i < W; i += 64) {
+      s_c[i] = curv[line * (size_t)W + i];
+      s_v[i] = mask[line * (size_t)W + i];
+    }
+    wave_lds_sync();
+    ring_replay(s_c, s_v, s_ord, lane, W, P, (uint32_t)(line % P.H) * P.W, line, st);
+    if (lane == 0 && events) atomicAdd(&events[0], 1ull);
+  }
+}
+
 template <bool EDGE>
 __device__ __forceinline__ bool before_or_invalid(double ca, int32_t ia, double cb, int32_t ib) {
   if (ia < 0) return false;  // padding sorts last
@@ -384,10 +486,13 @@ __device__ __forceinline__ bool before_or_invalid(double ca, int32_t ia, double 
   return EDGE ? edge_before(ca, ia, cb, ib) : planar_before(ca, ia, cb, ib);
 }
 
+// tie: set when a comparison between two candidates of EQUAL curvature could decide something in this pass — two
+// candidates within R points of each other (the pick depends on which the sort put first), or two picks whose order
+// the keys cannot tell (the output order / the cap depends on it). The caller then replays the line (ring_replay).
 template <int R, bool EDGE, bool TWO>
 __device__ __forceinline__ uint32_t mis_pass(int lane, int CH, int base, int start, int end, uint64_t& V, uint64_t T,
-                                             const uint64_t gt[R], const double* s_c, double* m_c, int32_t* m_i,
-                                             uint32_t cap, uint32_t line_base, uint32_t* __restrict__ stage,
+                                             const uint64_t gt[R], const uint64_t eqm[R], bool& tie, const double* s_c, double* m_c,
+                                             int32_t* m_i, uint32_t cap, uint32_t line_base, uint32_t* __restrict__ stage,
                                              uint32_t idx_mask, uint32_t ch_magic, uint32_t slots) {
   const uint64_t cm = low_mask(CH);
   const int pbase = lane * (CH + 1);  // s_c is stored with one spare slot per lane chunk (see select_mis_kernel)
@@ -398,6 +503,13 @@ __device__ __forceinline__ uint32_t mis_pass(int lane, int CH, int base, int sta
   uint64_t U = V & T & sm;
   if (__ballot(U != 0) == 0) return 0;
   uint64_t Pk = 0;
+  {  // equal curvatures among candidates within R points of each other (window bit t <-> t + d, as gt)
+    const uint64_t Uw = mis_window<R>(U, shfl_prev(U, lane), shfl_next(U, lane), CH);
+    uint64_t adj = 0;
+#pragma unroll
+    for (int d = 1; d <= R; d++) adj |= Uw & (Uw >> d) & eqm[d - 1];
+    if (__ballot(adj != 0) != 0) tie = true;
+  }
   do {  // rounds of "local maxima win, their neighbours leave"
     const uint64_t Uw = mis_window<R>(U, shfl_prev(U, lane), shfl_next(U, lane), CH);
     const uint64_t win = (mis_winners<R, EDGE>(Uw, gt) >> R) & cm;
@@ -495,38 +607,9 @@ __device__ __forceinline__ uint32_t mis_pass(int lane, int CH, int base, int sta
       if (__ballot(same) != 0) undecided = true;
     }
     if (undecided) {
-#pragma unroll 1
-      for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll 1
-        for (int j = k >> 1; j > 0; j >>= 1) {
-          const bool keep_first = ((lane & j) == 0) == ((lane & k) == 0);
-          {
-            const double oc = __shfl_xor(c, j);
-            const int32_t oi = __shfl_xor(i, j);
-            const bool other_first = before_or_invalid<EDGE>(oc, oi, c, i);
-            const bool me_first = before_or_invalid<EDGE>(c, i, oc, oi);
-            if (keep_first ? other_first : me_first) c = oc, i = oi;
-          }
-          if (two) {  // the second half in the opposite direction
-            const double oc = __shfl_xor(c1, j);
-            const int32_t oi = __shfl_xor(i1, j);
-            const bool other_first = before_or_invalid<EDGE>(oc, oi, c1, i1);
-            const bool me_first = before_or_invalid<EDGE>(c1, i1, oc, oi);
-            if (keep_first ? me_first : other_first) c1 = oc, i1 = oi;
-          }
-        }
-      }
-      if (two) {
-        if (before_or_invalid<EDGE>(c1, i1, c, i)) c = c1, i = i1;
-#pragma unroll 1
-        for (int j = 32; j > 0; j >>= 1) {
-          const double oc = __shfl_xor(c, j);
-          const int32_t oi = __shfl_xor(i, j);
-          const bool other_first = before_or_invalid<EDGE>(oc, oi, c, i);
-          const bool me_first = before_or_invalid<EDGE>(c, i, oc, oi);
-          if ((lane & j) == 0 ? other_first : me_first) c = oc, i = oi;
-        }
-      }
+      // picks whose truncated curvatures collide (equal curvatures, practically) or that are not finite: the order
+      // among them is the sort's — the line is replayed in the reference's own order (the values below are then unused)
+      tie = true;
     } else {
       const uint32_t have = two ? 64u : total;
       i = (uint32_t)lane < have ? (int32_t)((uint32_t)__double2loint(key) & idx_mask) : -1;
@@ -597,7 +680,7 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
   }
   wave_lds_sync();
   const int pbase = lane * (CH + 1), vbase = lane * (CH + 4);
-  uint64_t V = 0, ET = 0, PT = 0, gt[R];
+  uint64_t V = 0, ET = 0, PT = 0, gt[R], eqm[R];
   for (int j = 0; j < CH; j++) {
     const int i = base + j;
     if (i < W) {
@@ -610,7 +693,7 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
   // window values base-R .. base+CH+R-1 (+R more for the comparisons), read once: the halo on either
   // side belongs to the neighbouring lanes' chunks (R <= CH)
 #pragma unroll
-  for (int d = 1; d <= R; d++) gt[d - 1] = 0;
+  for (int d = 1; d <= R; d++) gt[d - 1] = 0, eqm[d - 1] = 0;
   {
     double win[2 * R + 1];  // sliding window of R + 1 consecutive values
     // value at line index i (any lane's chunk within one chunk of mine)
@@ -629,7 +712,7 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
       win[R] = (in >= 0 && in < W) ? at(in) : 0.0;
 #pragma unroll
       for (int d = 1; d <= R; d++)
-        if (i >= 0 && i + d < W) gt[d - 1] |= (uint64_t)(win[0] > win[d]) << t;
+        if (i >= 0 && i + d < W) gt[d - 1] |= (uint64_t)(win[0] > win[d]) << t, eqm[d - 1] |= (uint64_t)(win[0] == win[d]) << t;
 #pragma unroll
       for (int u = 0; u < R; u++) win[u] = win[u + 1];
     }
@@ -637,13 +720,14 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
   const uint32_t line_base = (uint32_t)(line % P.H) * P.W;
   const uint32_t idx_mask = W <= 2 ? 1u : (0xFFFFFFFFu >> __clz(W - 1));  // index-in-line bits of the sort keys
   uint32_t my_ne = 0, my_np = 0;  // lane s: picks of sector s
+  bool tie = false;  // wave-uniform
   for (uint32_t s = 0; s < P.S; s++) {
     const int start = (int)(s * P.pps);
     const int end = (s == P.S - 1) ? W : start + (int)P.pps;  // features-inl.h:31-35
     const size_t group = line * P.S + s;
-    const uint32_t ne = mis_pass<R, true, TWO>(lane, CH, base, start, end, V, ET, gt, s_c, m_c, m_i, P.cap_edge, line_base,
+    const uint32_t ne = mis_pass<R, true, TWO>(lane, CH, base, start, end, V, ET, gt, eqm, tie, s_c, m_c, m_i, P.cap_edge, line_base,
                                           st.edge_stage + group * P.cap_edge, idx_mask, ch_magic, (uint32_t)slots);
-    const uint32_t npl = mis_pass<R, false, TWO>(lane, CH, base, start, end, V, PT, gt, s_c, m_c, m_i, P.cap_planar,
+    const uint32_t npl = mis_pass<R, false, TWO>(lane, CH, base, start, end, V, PT, gt, eqm, tie, s_c, m_c, m_i, P.cap_planar,
                                             line_base, st.planar_stage + group * P.cap_planar, idx_mask, ch_magic, (uint32_t)slots);
     if (lane == 0) {
       st.edge_cnt[group] = ne;
@@ -651,7 +735,16 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
     }
     if ((uint32_t)lane == s) my_ne = ne, my_np = npl;  // (fused path: number_sectors <= 64)
   }
-  if (!fz.line_tot) return;  // uniform
+  if (tie || (P.flags & kFlagForceReplay)) {  // uniform: a tie could decide something on this line
+    // replay_kernel redoes the line in the reference's own order; the lines behind it in the scan see the poisoned slot,
+    // stop waiting and leave their picks in the stage arrays, from which the fallback compaction gathers the scan
+    if (lane == 0 && fz.line_tot) {
+      __hip_atomic_store(fz.line_tot + line, kLinePublished | kLineTied, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicOr(fz.error, kFlagTie | kFlagGaveUp);
+    }
+    return;
+  }
+  if (!fz.fuse) return;  // uniform
   // ---- fused compaction -----------------------------------------------------------------------------
   const uint32_t li = (uint32_t)(line % P.H);
   const size_t scan = line / P.H;
@@ -659,7 +752,7 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
   const uint32_t e_incl = wave_incl_scan_u32(my_ne), p_incl = wave_incl_scan_u32(my_np);
   const uint32_t E_l = (uint32_t)__builtin_amdgcn_readlane((int)e_incl, 63), P_l = (uint32_t)__builtin_amdgcn_readlane((int)p_incl, 63);
   if (lane == 0)
-    __hip_atomic_store(fz.line_tot + line, (1ull << 63) | ((unsigned long long)E_l << 32) | (unsigned long long)P_l,
+    __hip_atomic_store(fz.line_tot + line, kLinePublished | ((unsigned long long)E_l << 32) | (unsigned long long)P_l,
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   uint32_t* __restrict__ oe = fz.edge_idx + scan * fz.edge_stride;
   uint32_t* __restrict__ op = fz.planar_idx + scan * fz.planar_stride;
@@ -713,18 +806,20 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
         if (j < li) {
           const unsigned long long* src = fz.line_tot + (line - li + j);
           t = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          for (uint32_t spins = 0; !(t >> 63) && spins < kLookbackSpins; spins++) {
+          for (uint32_t spins = 0; !(t >> 63) && spins < kLookbackSpins; spins++) {  // (a tied line publishes too: bit 62)
             __builtin_amdgcn_s_sleep(4);
             t = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
-        gave_up = gave_up || !(t >> 63);
-        const uint32_t se = (uint32_t)(t >> 32) & 0x7FFFFFFFu, sp = (uint32_t)t;
+        gave_up = gave_up || !(t >> 63) || (t & kLineTied) != 0ull;
+        const uint32_t se = (uint32_t)(t >> 32) & 0x3FFFFFFFu, sp = (uint32_t)t;
         base_e += (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(se), 63);
         base_p += (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(sp), 63);
       }
-      if (__ballot(gave_up) != 0) {  // uniform
-        if (lane == 0) atomicOr(fz.error, 1u);
+      if (__ballot(gave_up) != 0 || ((P.flags & kFlagForceGiveUp) && li > 0)) {  // uniform
+        // this line's features stay in the stage arrays (complete, as always): compact_fallback_kernel, launched
+        // right behind this kernel, sees the flag and gathers the whole batch from them
+        if (lane == 0) atomicOr(fz.error, kFlagGaveUp);
         return;
       }
     }
@@ -832,8 +927,12 @@ __global__ __launch_bounds__(256) void compact_kernel(const T* __restrict__ xyz,
                                                       double* __restrict__ edge_xyz, size_t edge_stride,
                                                       uint32_t* __restrict__ planar_idx,
                                                       uint32_t* __restrict__ n_planar, double* __restrict__ planar_xyz,
-                                                      size_t planar_stride) {
+                                                      size_t planar_stride, const uint32_t* __restrict__ only_if,
+                                                      unsigned long long* __restrict__ fallback_counter) {
   __shared__ uint32_t s_scan[256], s_off[256], s_cnt[256];
+  // the fallback of the fused compaction: nothing to do unless a scan line of select_mis_kernel gave up (uniform)
+  if (only_if && __hip_atomic_load(only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+  if (only_if && fallback_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(fallback_counter, 1ull);
   const size_t scan = blockIdx.x / kCompactSplit;
   const uint32_t split = blockIdx.x % kCompactSplit;
   const uint32_t groups = P.H * P.S;
@@ -898,7 +997,8 @@ bool launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, 
   // the fused compaction keeps the per-sector counts of a line on the lanes of its wavefront
   const bool fuse = fused && fused->line_tot && P.S <= 64 && !getenv("LOAMX_NO_FUSED_COMPACT");
   ExtractFused fz{};
-  if (fuse) fz = *fused;
+  if (fused) fz = *fused;  // (line_tot / error carry the tie flags either way)
+  fz.fuse = fuse ? 1u : 0u;
   // bitmask-MIS fast path: R = np-1 in 1..4, lane chunk wide enough for the halo, at most 64 picks
   // per sector (picks are >= R+1 points apart), the cap itself at most 64
   const int R = (int)P.np - 1, CH = ((int)P.W + 63) / 64;
@@ -918,26 +1018,35 @@ bool launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, 
   if (P.W <= 1024) {
     constexpr int WAVES = 4;
     launch_kernel(select_kernel<WAVES>, dim3((unsigned)((n_lines + WAVES - 1) / WAVES)), dim3(WAVES * 64),
-                       per_wave * WAVES, s, d_curv, d_mask, n_lines, P, st);
+                       per_wave * WAVES, s, d_curv, d_mask, n_lines, P, st, fz.line_tot, fz.error);
   } else {
     launch_kernel(select_kernel<1>, dim3((unsigned)n_lines), dim3(64), per_wave, s, d_curv, d_mask, n_lines, P,
-                       st);
+                       st, fz.line_tot, fz.error);
   }
   return false;
+}
+
+void launch_replay(const double* d_curv, const uint8_t* d_mask, size_t n_scans, const ExtractParams& P, const ExtractStage& st,
+                   const ExtractFused& fz, hipStream_t s) {
+  const size_t n_lines = n_scans * P.H;
+  if (n_lines == 0 || P.W == 0 || !fz.line_tot || !fz.error) return;
+  const unsigned grid = (unsigned)(n_lines < 2048 ? n_lines : 2048);
+  launch_kernel(replay_kernel, dim3(grid), dim3(64), replay_lds_bytes((int)P.W), s, d_curv, d_mask, n_lines, P, st, fz.line_tot, fz.error,
+                fz.events);
 }
 
 void launch_compact(const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, const ExtractStage& st,
                     uint32_t* d_edge_idx, uint32_t* d_n_edge, double* d_edge_xyz, size_t edge_stride,
                     uint32_t* d_planar_idx, uint32_t* d_n_planar, double* d_planar_xyz, size_t planar_stride,
-                    hipStream_t s) {
+                    hipStream_t s, const uint32_t* only_if, unsigned long long* fallback_counter) {
   if (n_scans == 0) return;
   const dim3 grid((unsigned)(n_scans * kCompactSplit));
   if (f32)
     launch_kernel(compact_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(d_xyz), P, st, d_edge_idx, d_n_edge,
-                       d_edge_xyz, edge_stride, d_planar_idx, d_n_planar, d_planar_xyz, planar_stride);
+                       d_edge_xyz, edge_stride, d_planar_idx, d_n_planar, d_planar_xyz, planar_stride, only_if, fallback_counter);
   else
     launch_kernel(compact_kernel<double>, grid, dim3(256), 0, s, static_cast<const double*>(d_xyz), P, st, d_edge_idx, d_n_edge,
-                       d_edge_xyz, edge_stride, d_planar_idx, d_n_planar, d_planar_xyz, planar_stride);
+                       d_edge_xyz, edge_stride, d_planar_idx, d_n_planar, d_planar_xyz, planar_stride, only_if, fallback_counter);
 }
 
 }  // namespace loamx

@@ -29,6 +29,11 @@ struct ExtractParams {
   uint32_t cap_planar;
   double min_range, max_range;
   double edge_thr, planar_thr, occ_thr, par_thr;
+  uint32_t flags;        // test switches, never set by the C ABI's callers: kFlagForceReplay, kFlagForceGiveUp
+};
+enum : uint32_t {
+  kFlagForceReplay = 1u,  // every scan line takes the tie path (std::sort replay) of the selection kernels
+  kFlagForceGiveUp = 2u   // the fused compaction's chained scan gives up at once (exercises the fallback)
 };
 
 // features-inl.h:66-67 / features.cpp:22: col < np || col >= W - np in size_t arithmetic.
@@ -100,6 +105,143 @@ LOAMX_EHD bool valid_from_codes(const uint8_t* code, int i, uint32_t col, uint32
 LOAMX_EHD bool edge_before(double ca, int32_t ia, double cb, int32_t ib) { return ca > cb || (ca == cb && ia > ib); }
 LOAMX_EHD bool planar_before(double ca, int32_t ia, double cb, int32_t ib) { return ca < cb || (ca == cb && ia < ib); }
 
+
+/* ------------------------------------------------------------------------------------------------
+ * The reference's order on ties: features-inl.h:38 sorts a sector with std::sort, which is not
+ * stable, so the walk order among points of EQUAL curvature is whatever libstdc++'s introsort leaves. That order is
+ * a deterministic function of the comparison outcomes, so it can be replayed: below is libstdc++'s std::sort
+ * (bits/stl_algo.h, bits/stl_heap.h as shipped with GCC 5 - 14: __introsort_loop with depth limit 2 lg n,
+ * median-of-three to the front, unguarded partition, heap sort when the depth runs out, threshold 16, final insertion
+ * sort) restated on an array of point indices with the comparator curvature(a) < curvature(b). tests/hostcheck runs
+ * it against the real std::sort. The kernels call it only for scan lines on which a tie can decide something.
+ * `less(a, b)` compares two array ELEMENTS (indices); moves of elements are moves of indices.
+ * ---------------------------------------------------------------------------------------------- */
+template <typename I, typename Less>
+LOAMX_EHD void stl_unguarded_linear_insert(I* a, int last, Less less) {
+  const I val = a[last];
+  int next = last - 1;
+  while (less(val, a[next])) {
+    a[last] = a[next];
+    last = next;
+    --next;
+  }
+  a[last] = val;
+}
+template <typename I, typename Less>
+LOAMX_EHD void stl_insertion_sort(I* a, int first, int last, Less less) {
+  if (first == last) return;
+  for (int i = first + 1; i != last; ++i) {
+    if (less(a[i], a[first])) {
+      const I val = a[i];
+      for (int j = i; j > first; --j) a[j] = a[j - 1];  // move_backward(first, i, i + 1)
+      a[first] = val;
+    } else {
+      stl_unguarded_linear_insert(a, i, less);
+    }
+  }
+}
+// bits/stl_heap.h: __adjust_heap (with the __push_heap at its end); `first` is the heap's base position in a
+template <typename I, typename Less>
+LOAMX_EHD void stl_adjust_heap(I* a, int first, int hole, int len, I value, Less less) {
+  const int top = hole;
+  int child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (less(a[first + child], a[first + child - 1])) child--;
+    a[first + hole] = a[first + child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    a[first + hole] = a[first + child - 1];
+    hole = child - 1;
+  }
+  int parent = (hole - 1) / 2;
+  while (hole > top && less(a[first + parent], value)) {
+    a[first + hole] = a[first + parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  a[first + hole] = value;
+}
+// __partial_sort(first, last, last) = __heap_select (make_heap only: middle == last) + __sort_heap
+template <typename I, typename Less>
+LOAMX_EHD void stl_heap_sort(I* a, int first, int last, Less less) {
+  const int len = last - first;
+  if (len >= 2) {  // __make_heap
+    int parent = (len - 2) / 2;
+    for (;;) {
+      const I value = a[first + parent];
+      stl_adjust_heap(a, first, parent, len, value, less);
+      if (parent == 0) break;
+      parent--;
+    }
+  }
+  while (last - first > 1) {  // __sort_heap: __pop_heap(first, last - 1, last - 1)
+    --last;
+    const I value = a[last];
+    a[last] = a[first];
+    stl_adjust_heap(a, first, 0, last - first, value, less);
+  }
+}
+template <typename I, typename Less>
+LOAMX_EHD void stl_sort(I* a, int first, int last, Less less) {
+  if (first == last) return;
+  constexpr int kThreshold = 16;
+  int lg = 0;  // std::__lg(n) = floor(log2 n)
+  for (int n = last - first; n > 1; n >>= 1) lg++;
+  // __introsort_loop: the recursion on [cut, last) becomes an explicit stack (disjoint ranges: the order in which
+  // they are finished does not change the result); the stack never holds more than the depth limit
+  int stk_first[40], stk_last[40], stk_depth[40], sp = 0;
+  stk_first[0] = first, stk_last[0] = last, stk_depth[0] = 2 * lg, sp = 1;
+  while (sp > 0) {
+    --sp;
+    int f = stk_first[sp], l = stk_last[sp], depth = stk_depth[sp];
+    while (l - f > kThreshold) {
+      if (depth == 0) {
+#if defined(LOAMX_STL_SORT_STATS)
+        g_heap_sorts++;
+#endif
+        stl_heap_sort(a, f, l, less);
+        break;
+      }
+      --depth;
+      // __unguarded_partition_pivot: __move_median_to_first(f, f + 1, mid, l - 1), then __unguarded_partition(f + 1, l, f)
+      const int mid = f + (l - f) / 2, ia = f + 1, ib = mid, ic = l - 1;
+      int m;
+      if (less(a[ia], a[ib])) {
+        if (less(a[ib], a[ic])) m = ib;
+        else if (less(a[ia], a[ic])) m = ic;
+        else m = ia;
+      } else if (less(a[ia], a[ic])) m = ia;
+      else if (less(a[ib], a[ic])) m = ic;
+      else m = ib;
+      {
+        const I t = a[f];
+        a[f] = a[m], a[m] = t;
+      }
+      int lo = f + 1, hi = l;
+      for (;;) {
+        while (less(a[lo], a[f])) ++lo;
+        --hi;
+        while (less(a[f], a[hi])) --hi;
+        if (!(lo < hi)) break;
+        const I t = a[lo];
+        a[lo] = a[hi], a[hi] = t;
+        ++lo;
+      }
+      if (sp < 40) stk_first[sp] = lo, stk_last[sp] = l, stk_depth[sp] = depth, sp++;  // __introsort_loop(cut, last, depth)
+      l = lo;
+    }
+  }
+  // __final_insertion_sort
+  if (last - first > kThreshold) {
+    stl_insertion_sort(a, first, first + kThreshold, less);
+    for (int i = first + kThreshold; i != last; ++i) stl_unguarded_linear_insert(a, i, less);
+  } else {
+    stl_insertion_sort(a, first, last, less);
+  }
+}
 
 /* ------------------------------------------------------------------------------------------------
  * Selection as a lexicographically-first maximal independent set on lane bitmasks.

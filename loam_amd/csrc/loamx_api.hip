@@ -23,7 +23,7 @@ enum WsId {
   WS_XYZ = 0, WS_CURV, WS_MASK, WS_EDGE_STAGE, WS_PLANAR_STAGE, WS_EDGE_CNT, WS_PLANAR_CNT,
   WS_EDGE_IDX, WS_PLANAR_IDX, WS_N_EDGE, WS_N_PLANAR, WS_EDGE_XYZ, WS_PLANAR_XYZ,
   WS_GRID_DESC_E, WS_GRID_DESC_P, WS_CELLS_E, WS_CELLS_P, WS_SORTED_E, WS_SORTED_P, WS_REL_E, WS_REL_P,
-  WS_SGRID_DESC_E, WS_SGRID_DESC_P, WS_SCELLS_E, WS_SCELLS_P, WS_SSORTED_E, WS_SSORTED_P, WS_SORT_SCRATCH, WS_ASSOC_E, WS_ASSOC_P, WS_NN_E, WS_NN_P, WS_RNN_E, WS_RNN_P, WS_NEAREST_E, WS_NEAREST_P, WS_REST_E, WS_REST_P, WS_EXACT_E, WS_EXACT_P, WS_NASSOC, WS_STATE, WS_PARTIALS, WS_MOM_PARTIALS, WS_MOMENTS, WS_FLAGGED_LIST, WS_FLAGGED_COUNT, WS_LINE_TOT, WS_EXTRACT_ERR,
+  WS_SGRID_DESC_E, WS_SGRID_DESC_P, WS_SCELLS_E, WS_SCELLS_P, WS_SSORTED_E, WS_SSORTED_P, WS_SORT_SCRATCH, WS_ASSOC_E, WS_ASSOC_P, WS_NN_E, WS_NN_P, WS_RNN_E, WS_RNN_P, WS_NEAREST_E, WS_NEAREST_P, WS_REST_E, WS_REST_P, WS_EXACT_E, WS_EXACT_P, WS_NASSOC, WS_STATE, WS_PARTIALS, WS_MOM_PARTIALS, WS_MOMENTS, WS_FLAGGED_LIST, WS_FLAGGED_COUNT, WS_LINE_TOT, WS_EXTRACT_EVENTS,
   WS_COUNTERS, WS_ITERINFO, WS_SRC_E, WS_SRC_P, WS_TGT_E, WS_TGT_P, WS_FCOUNTS, WS_RESULTS, WS_INIT,
   WS_COUNT
 };
@@ -80,6 +80,7 @@ struct loamx_target_index {
 
 namespace loamx {
 thread_local LaunchScope* g_launch_scope = nullptr;
+int g_debug_sync = getenv("LOAMX_DEBUG_SYNC") ? 1 : 0;
 }
 
 namespace {
@@ -219,6 +220,8 @@ int make_extract_params(loamx_ctx* ctx, const loamx_lidar_params* lidar, const l
   P.min_range = lidar->min_range, P.max_range = lidar->max_range;
   P.edge_thr = fe->edge_feat_threshold, P.planar_thr = fe->planar_feat_threshold;
   P.occ_thr = fe->occlusion_thresh, P.par_thr = fe->parallel_thresh;
+  // test switches (tests/test_gpu_extract.py): results never depend on them
+  P.flags = (getenv("LOAMX_FORCE_TIE_REPLAY") ? kFlagForceReplay : 0u) | (getenv("LOAMX_FORCE_SCAN_GIVEUP") ? kFlagForceGiveUp : 0u);
   return LOAMX_OK;
 }
 
@@ -245,12 +248,6 @@ int make_reg_config(loamx_ctx* ctx, const loamx_reg_params* r, RegConfig& C) {
 
 size_t edge_capacity(const ExtractParams& P) { return (size_t)P.H * P.S * P.cap_edge; }
 size_t planar_capacity(const ExtractParams& P) { return (size_t)P.H * P.S * P.cap_planar; }
-
-// The fused compaction's give-up flag (see select_mis_kernel): reported once, then cleared.
-int extract_error(loamx_ctx* ctx) {
-  if (ctx->ws[WS_EXTRACT_ERR].p) (void)hipMemsetAsync(ctx->ws[WS_EXTRACT_ERR].p, 0, sizeof(uint32_t), ctx->stream);
-  return fail(ctx, LOAMX_ERR_HIP, "feature extraction: a scan line gave up waiting for the lines before it (select_mis_kernel chained scan)");
-}
 
 // extraction over device-resident scans ------------------------------------------------------------------
 // d_xyz: double, or float when f32 (FP32-input path)
@@ -285,19 +282,33 @@ int extract_dev(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_scans, con
                   wsp<uint32_t>(ctx, WS_EDGE_CNT), wsp<uint32_t>(ctx, WS_PLANAR_CNT)};
   // the selection writes the final feature arrays itself when it can (launch_select); its chained scan over the
   // lines of a scan needs the per-line slots zeroed
-  ENSURE(ctx, WS_LINE_TOT, n_scans * P.H * sizeof(unsigned long long));
-  const bool had_err = ctx->ws[WS_EXTRACT_ERR].p != nullptr;
-  ENSURE(ctx, WS_EXTRACT_ERR, sizeof(uint32_t));
+  // ... and one more word behind them: the give-up flag of that chained scan (zeroed by the same memset)
+  const size_t n_lines = n_scans * P.H;
+  ENSURE(ctx, WS_LINE_TOT, (n_lines + 1) * sizeof(unsigned long long));
+  {
+    const bool fresh = ctx->ws[WS_EXTRACT_EVENTS].cap == 0;  // cumulative counters: zeroed once
+    ENSURE(ctx, WS_EXTRACT_EVENTS, 2 * sizeof(unsigned long long));
+    untimed(ctx);
+    if (fresh) HIP_TRY(ctx, hipMemsetAsync(ctx->ws[WS_EXTRACT_EVENTS].p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+  }
   untimed(ctx);
-  if (!had_err) HIP_TRY(ctx, hipMemsetAsync(ctx->ws[WS_EXTRACT_ERR].p, 0, sizeof(uint32_t), ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->ws[WS_LINE_TOT].p, 0, n_scans * P.H * sizeof(unsigned long long), ctx->stream));
-  const ExtractFused fz{wsp<unsigned long long>(ctx, WS_LINE_TOT), d_xyz, f32 ? 1u : 0u, d_edge_idx, d_n_edge, d_edge_xyz,
-                        edge_capacity(P), d_planar_idx, d_n_planar, d_planar_xyz, planar_capacity(P),
-                        wsp<uint32_t>(ctx, WS_EXTRACT_ERR)};
+  HIP_TRY(ctx, hipMemsetAsync(ctx->ws[WS_LINE_TOT].p, 0, (n_lines + 1) * sizeof(unsigned long long), ctx->stream));
+  uint32_t* d_gave_up = reinterpret_cast<uint32_t*>(wsp<unsigned long long>(ctx, WS_LINE_TOT) + n_lines);
+  unsigned long long* d_events = wsp<unsigned long long>(ctx, WS_EXTRACT_EVENTS);
+  const ExtractFused fz{wsp<unsigned long long>(ctx, WS_LINE_TOT), 0u, d_xyz, f32 ? 1u : 0u, d_edge_idx, d_n_edge, d_edge_xyz,
+                        edge_capacity(P), d_planar_idx, d_n_planar, d_planar_xyz, planar_capacity(P), d_gave_up, d_events};
   bool fused = false;
   {
     TimedScope t(ctx, LOAMX_K_SELECT, (double)n_scans * (double)N * 9.0, true);
     fused = launch_select(wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), n_scans, P, st, &fz, ctx->stream);
+    // scan lines on which a curvature tie can decide something: again, in the reference's std::sort order (a no-op without)
+    launch_replay(wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), n_scans, P, st, fz, ctx->stream);
+    // A scan line whose wavefront gave up waiting for the lines before it (bounded wait: unusual scheduling) left its
+    // features in the stage arrays; this launch then gathers the batch from them and is a no-op otherwise (every
+    // workgroup reads the flag and leaves): the call stays asynchronous and never fails for that reason.
+    if (fused)
+      launch_compact(d_xyz, f32, n_scans, P, st, d_edge_idx, d_n_edge, d_edge_xyz, edge_capacity(P), d_planar_idx, d_n_planar,
+                     d_planar_xyz, planar_capacity(P), ctx->stream, d_gave_up, d_events + 1);
   }
   CHECK_LAUNCH(ctx, "select_kernel");
   if (fused) return LOAMX_OK;
@@ -376,6 +387,15 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
     untimed(ctx);
     if (fresh) HIP_TRY(ctx, hipMemsetAsync(ctx->ws[WS_COUNTERS].p, 0, 128, ctx->stream));
   }
+  if (getenv("LOAMX_DEBUG_POISON")) {  // debugging: every scratch buffer of the registration starts as 0xFF bytes
+    static const int kScratch[] = {WS_GRID_DESC_E, WS_GRID_DESC_P, WS_CELLS_E, WS_CELLS_P, WS_SORTED_E, WS_SORTED_P, WS_REL_E, WS_REL_P,
+                                   WS_SGRID_DESC_E, WS_SGRID_DESC_P, WS_SCELLS_E, WS_SCELLS_P, WS_SSORTED_E, WS_SSORTED_P, WS_SORT_SCRATCH,
+                                   WS_ASSOC_E, WS_ASSOC_P, WS_NN_E, WS_NN_P, WS_RNN_E, WS_RNN_P, WS_NEAREST_E, WS_NEAREST_P, WS_REST_E,
+                                   WS_REST_P, WS_EXACT_E, WS_EXACT_P, WS_NASSOC, WS_STATE, WS_PARTIALS, WS_MOM_PARTIALS, WS_MOMENTS,
+                                   WS_FLAGGED_LIST, WS_FLAGGED_COUNT};
+    for (int id : kScratch)
+      if (ctx->ws[id].p) HIP_TRY(ctx, hipMemsetAsync(ctx->ws[id].p, 0xFF, ctx->ws[id].cap, ctx->stream));
+  }
   if (want_iter_info) ENSURE(ctx, WS_ITERINFO, np * (size_t)(C.max_iterations ? C.max_iterations : 1) * sizeof(loamx_iter_info));
   B.grid_edge = GridSet{wsp<GridDesc>(ctx, WS_GRID_DESC_E), wsp<uint32_t>(ctx, WS_CELLS_E), wsp<GridPoint>(ctx, WS_SORTED_E), es + kGridPad,
                         wsp<float>(ctx, WS_REL_E)};
@@ -418,8 +438,6 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   CHECK_LAUNCH(ctx, "state_init_kernel");
   if (!ctx->ev_counts) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_counts, hipEventDisableTiming));
   HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_pinned[16], B.max_counts, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  const bool chk_extract = ctx->ws[WS_EXTRACT_ERR].p != nullptr;  // a pipeline call ran the extraction just before
-  if (chk_extract) HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_pinned[2], ctx->ws[WS_EXTRACT_ERR].p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipEventRecord(ctx->ev_counts, s));
 
   if (prebuilt) {  // persistent target index: only the source sets are (re)ordered
@@ -439,7 +457,6 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   }
   CHECK_LAUNCH(ctx, "grid_build_kernel");
   HIP_TRY(ctx, hipEventSynchronize(ctx->ev_counts));
-  if (chk_extract && ctx->h_pinned[2] != 0) return extract_error(ctx);
   B.assoc_blocks_edge = (ctx->h_pinned[16] + 255u) / 256u;   // kAssocThreads queries per workgroup
   B.assoc_blocks_plane = (ctx->h_pinned[17] + 255u) / 256u;
   {  // which of the two k-NN kernels of a feature kind has work at all (target sizes relative to kBruteMax)
@@ -648,10 +665,21 @@ int loamx_ctx_synchronize(loamx_ctx* ctx) {
   if (!ctx) return LOAMX_ERR_BAD_PARAM;
   std::lock_guard<std::mutex> lock(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (ctx->ws[WS_EXTRACT_ERR].p)
-    HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_pinned[2], ctx->ws[WS_EXTRACT_ERR].p, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->ws[WS_EXTRACT_ERR].p && ctx->h_pinned[2] != 0) return extract_error(ctx);
+  return LOAMX_OK;
+}
+
+int loamx_ctx_extract_counters(loamx_ctx* ctx, uint64_t* tie_replays, uint64_t* scan_fallbacks) {
+  if (!ctx) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  unsigned long long ev[2] = {0, 0};
+  if (ctx->ws[WS_EXTRACT_EVENTS].p) {
+    HIP_TRY(ctx, hipMemcpyAsync(ev, ctx->ws[WS_EXTRACT_EVENTS].p, sizeof(ev), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (tie_replays) *tie_replays = ev[0];
+  if (scan_fallbacks) *scan_fallbacks = ev[1];
   return LOAMX_OK;
 }
 
@@ -747,9 +775,7 @@ static int host_extract(loamx_ctx* ctx, const void* xyz, bool f32, size_t n_poin
   if (rc != LOAMX_OK) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_pinned[0], ctx->ws[WS_N_EDGE].p, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_pinned[1], ctx->ws[WS_N_PLANAR].p, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_pinned[2], ctx->ws[WS_EXTRACT_ERR].p, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->h_pinned[2] != 0) return extract_error(ctx);
   const size_t ne = ctx->h_pinned[0], npl = ctx->h_pinned[1];
   *n_edge = ne, *n_planar = npl;
   if (ne > edge_cap || npl > planar_cap) return fail(ctx, LOAMX_ERR_CAPACITY, "feature index capacity too small");

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "../../include/loamx.h"
 #include "extract_math.h"
@@ -20,16 +21,25 @@ struct LaunchScope {
   bool first;
 };
 extern thread_local LaunchScope* g_launch_scope;
+// LOAMX_DEBUG_SYNC=1 (read once): every launch is followed by a stream synchronisation and a line on stderr with the
+// kernel's name and the status — the last line before a GPU fault names the kernel that faulted (debugging only)
+extern int g_debug_sync;
 template <typename F, typename... Args>
-inline void launch_kernel(F kernel, const dim3& grid, const dim3& block, size_t shmem, hipStream_t s, Args... args) {
+inline void launch_kernel_named(const char* name, F kernel, const dim3& grid, const dim3& block, size_t shmem, hipStream_t s, Args... args) {
   LaunchScope* sc = g_launch_scope;
+  if (g_debug_sync) fprintf(stderr, "[loamx] launch %s grid %u x %u block %u\n", name, grid.x, grid.y, block.x), fflush(stderr);
   if (sc) {
     hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)shmem, s, sc->first ? sc->start : nullptr, sc->stop, 0, args...);
     sc->first = false;
   } else {
     hipLaunchKernelGGL(kernel, grid, block, shmem, s, args...);
   }
+  if (g_debug_sync) {
+    const hipError_t e = hipStreamSynchronize(s);
+    fprintf(stderr, "[loamx]   done %s: %s\n", name, hipGetErrorString(e)), fflush(stderr);
+  }
 }
+#define launch_kernel(kernel, ...) launch_kernel_named(#kernel, kernel, __VA_ARGS__)
 
 /* ---- extraction (extract_kernels.hip) ---------------------------------------------------------- */
 constexpr int kMaxNeighborPoints = 16;  // LDS halo bound of curvature_valid_kernel
@@ -46,7 +56,8 @@ struct ExtractStage {
 // d_xyz: n_scans x H x W x 3 scalars, double or (f32) float
 // Outputs select_mis_kernel writes itself when the compaction is fused into the selection (see the kernel).
 struct ExtractFused {
-  unsigned long long* line_tot;  // [n_lines] published totals of every scan line, zeroed before the launch
+  unsigned long long* line_tot;  // [n_lines] published totals of every scan line (bit 63), or the tie mark (bit 62); zeroed before the launch
+  uint32_t fuse;                 // 1: select_mis_kernel writes the final arrays itself (chained scan over line_tot)
   const void* xyz;               // the scans (double, or float when f32)
   uint32_t f32;
   uint32_t* edge_idx;            // outputs as launch_compact
@@ -57,7 +68,10 @@ struct ExtractFused {
   uint32_t* n_planar;
   double* planar_xyz;
   size_t planar_stride;
-  uint32_t* error;  // set when a wavefront gave up waiting for the lines before it (never seen; see the kernel)
+  uint32_t* error;  // flag word (zeroed before every launch, next to line_tot). Bit 0: a wavefront gave up waiting for the
+                    // lines before it (or they are tied): the fallback compaction gathers the batch from the stage arrays;
+                    // bit 1: some line is tied (replay_kernel has work)
+  unsigned long long* events;  // [2] cumulative: scan lines replayed in the reference's tie order, give-up fallbacks taken
 };
 
 void launch_curvature_valid(const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, double* d_curv,
@@ -67,10 +81,14 @@ void launch_curvature_valid(const void* d_xyz, bool f32, size_t n_scans, const E
 bool launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, const ExtractParams& P,
                    const ExtractStage& st, const ExtractFused* fz, hipStream_t s);
 // edge_stride / planar_stride: entries per scan in the output arrays
+// the tie path: scan lines the selection kernel marked are redone in the reference's std::sort order (stage + counts)
+void launch_replay(const double* d_curv, const uint8_t* d_mask, size_t n_scans, const ExtractParams& P, const ExtractStage& st,
+                   const ExtractFused& fz, hipStream_t s);
+// only_if != nullptr: every workgroup first reads *only_if and leaves if it is 0 (the fused compaction's fallback)
 void launch_compact(const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, const ExtractStage& st,
                     uint32_t* d_edge_idx, uint32_t* d_n_edge, double* d_edge_xyz, size_t edge_stride,
                     uint32_t* d_planar_idx, uint32_t* d_n_planar, double* d_planar_xyz, size_t planar_stride,
-                    hipStream_t s);
+                    hipStream_t s, const uint32_t* only_if = nullptr, unsigned long long* fallback_counter = nullptr);
 
 /* ---- registration (register_kernels.hip) ------------------------------------------------------- */
 struct RegConfig {

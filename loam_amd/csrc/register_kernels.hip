@@ -158,7 +158,9 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
     const uint32_t c0 = tid * per < nc ? tid * per : nc, c1 = c0 + per < nc ? c0 + per : nc;
     uint32_t local = 0;
     if (PACKED) {
-      for (uint32_t w = c0 >> 1; 2 * w < c1; w++) local += (s_cells[w] & 0xFFFFu) + (s_cells[w] >> 16);  // (a half past nc is 0)
+      // (c0 < c1: a thread past the end has c0 == c1 == nc and must not touch the last word, which an odd nc leaves
+      // half used — it would count that word again and then overwrite its offsets)
+      for (uint32_t w = c0 >> 1; c0 < c1 && 2 * w < c1; w++) local += (s_cells[w] & 0xFFFFu) + (s_cells[w] >> 16);  // (a half past nc is 0)
     } else {
       for (uint32_t c = c0; c < c1; c++) local += s_cells[c];
     }
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
     for (int w = 0; w < kBuildThreads / 64; w++) pass_total += s_wave_sum[w];
     uint32_t run = wave_off + incl - local;
     if (PACKED) {
-      for (uint32_t w = c0 >> 1; 2 * w < c1; w++) {
+      for (uint32_t w = c0 >> 1; c0 < c1 && 2 * w < c1; w++) {
         const uint32_t v = s_cells[w], lo = v & 0xFFFFu, hi = v >> 16;
         s_cells[w] = run | ((run + lo) << 16);
         run += lo + hi;
@@ -1275,9 +1277,28 @@ static void launch_grid_build_big(size_t n_pairs, const double* pts, const uint3
                        s, n_pts, stride, in_pitch, gs);
 }
 
+static void debug_ptr(const char* what, const void* p, size_t need) {
+  size_t size = 0;
+  hipDeviceptr_t base = nullptr;
+  const hipError_t e = hipMemGetAddressRange(&base, &size, const_cast<void*>(p));
+  const size_t off = e == hipSuccess ? (size_t)((const char*)p - (const char*)base) : 0;
+  fprintf(stderr, "[loamx]     %-10s %p need %zu: %s, allocation %p + %zu of %zu%s\n", what, p, need, hipGetErrorString(e), base, off, size,
+          (e != hipSuccess || off + need > size) ? "  <-- TOO SMALL / INVALID" : "");
+}
+
 template <bool ORDERED>
 static void launch_grid_build(size_t n_pairs, const double* pts, const uint32_t* n_pts, size_t stride, uint32_t in_pitch,
                               double max_dist, const GridSet& gs, GridPoint* scratch, hipStream_t s) {
+  if (g_debug_sync) {
+    fprintf(stderr, "[loamx]   grid build ORDERED=%d n_pairs %zu stride %zu in_pitch %u gs.stride %zu\n", (int)ORDERED, n_pairs, stride, in_pitch, gs.stride);
+    debug_ptr("pts", pts, n_pairs * in_pitch * stride * 24);
+    debug_ptr("n_pts", n_pts, ((n_pairs - 1) * in_pitch + 1) * 4);
+    debug_ptr("desc", gs.desc, n_pairs * sizeof(GridDesc));
+    debug_ptr("cell_start", gs.cell_start, n_pairs * (size_t)(kGridCellsCap + 1) * 4);
+    debug_ptr("sorted", gs.sorted, n_pairs * gs.stride * sizeof(GridPoint));
+    if (gs.rel) debug_ptr("rel", gs.rel, n_pairs * 3 * gs.stride * 4);
+    if (scratch) debug_ptr("scratch", scratch, n_pairs * gs.stride * sizeof(GridPoint));
+  }
   if (!ORDERED && grid_big(stride, scratch)) {
     launch_grid_build_big(n_pairs, pts, n_pts, stride, in_pitch, max_dist, gs, scratch, s);
     return;

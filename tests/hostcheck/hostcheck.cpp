@@ -13,6 +13,8 @@
 // search statistics (candidates / rows visited) for tools/knn_stats.py
 #define LOAMX_KNN_STATS 1
 static uint64_t g_cand = 0, g_rows = 0, g_general = 0;
+#define LOAMX_STL_SORT_STATS 1
+static uint64_t g_heap_sorts = 0;  // times stl_sort fell back to heap sort (depth limit)
 
 #include "../../include/loamx.h"
 #include "../../loam_amd/csrc/extract_math.h"
@@ -31,6 +33,12 @@ static ExtractParams make_params(uint64_t H, uint64_t W, double rmin, double rma
   P.occ_thr = fe->occlusion_thresh, P.par_thr = fe->parallel_thresh;
   return P;
 }
+
+namespace {
+void replay_line(const double* c, std::vector<uint8_t> valid, const ExtractParams& P, uint32_t line, std::vector<uint32_t>& edge,
+                 std::vector<uint32_t>& planar);
+uint64_t g_replayed_lines = 0;
+}  // namespace
 
 extern "C" {
 
@@ -63,6 +71,9 @@ int hostcheck_select(const double* curv, const uint8_t* mask_in, uint64_t H, uin
   for (uint64_t line = 0; line < H; line++) {
     const double* c = curv + line * W;
     for (uint32_t i = 0; i < W; i++) valid[i] = mask_in[line * W + i];
+    const std::vector<uint8_t> valid0 = valid;
+    const uint64_t ne0 = ne, npl0 = npl;
+    bool tie = false;
     for (uint32_t s = 0; s < P.S; s++) {
       const uint32_t start = s * P.pps, end = (s == P.S - 1) ? P.W : start + P.pps;
       for (int pass = 0; pass < 2; pass++) {
@@ -78,6 +89,8 @@ int hostcheck_select(const double* curv, const uint8_t* mask_in, uint64_t H, uin
               best = (int32_t)i, bc = c[i];
           }
           if (best < 0) break;
+          for (uint32_t i = start; i < end; i++)  // the best is not unique (select_pass: tied)
+            if ((int32_t)i != best && valid[i] && c[i] == bc) tie = true;
           if (pass == 0)
             edge_idx[ne++] = (uint32_t)(line * W + best);
           else
@@ -88,6 +101,14 @@ int hostcheck_select(const double* curv, const uint8_t* mask_in, uint64_t H, uin
         }
       }
     }
+    if (tie || (P.flags & kFlagForceReplay)) {  // select_kernel: the line again, in the reference's own order
+      std::vector<uint32_t> e, p;
+      replay_line(c, valid0, P, (uint32_t)line, e, p);
+      ne = ne0, npl = npl0;
+      for (uint32_t v : e) edge_idx[ne++] = v;
+      for (uint32_t v : p) planar_idx[npl++] = v;
+      g_replayed_lines++;
+    }
   }
   *n_edge = ne, *n_planar = npl;
   return 0;
@@ -97,6 +118,47 @@ int hostcheck_select(const double* curv, const uint8_t* mask_in, uint64_t H, uin
 /* ---- lane-level emulation of select_mis_kernel (bitmask MIS + cap by priority order) -------------- */
 }  // extern "C"
 namespace {
+// the serial twin of ring_replay (extract_kernels.hip): stl_sort per sector + the reference's two walks
+void replay_line(const double* c, std::vector<uint8_t> valid, const ExtractParams& P, uint32_t line, std::vector<uint32_t>& edge,
+                 std::vector<uint32_t>& planar) {
+  const int W = (int)P.W, np = (int)P.np;
+  std::vector<uint16_t> ord(W);
+  for (int i = 0; i < W; i++) ord[i] = (uint16_t)i;
+  for (uint32_t s = 0; s < P.S; s++) {
+    const int start = (int)(s * P.pps), end = (s == P.S - 1) ? W : start + (int)P.pps;
+    stl_sort(ord.data(), start, end, [&](uint16_t a, uint16_t b) { return c[a] < c[b]; });
+  }
+  for (uint32_t s = 0; s < P.S; s++) {
+    const int start = (int)(s * P.pps), end = (s == P.S - 1) ? W : start + (int)P.pps;
+    uint32_t ne = 0, npl = 0;
+    for (int k = end; k > start; k--) {
+      const int idx = ord[k - 1];
+      if (valid[idx] && c[idx] > P.edge_thr) {
+        edge.push_back(line * P.W + (uint32_t)idx);
+        for (int n = 0; n < np; n++) {
+          if (idx + n < W) valid[idx + n] = 0;
+          if (idx - n >= 0) valid[idx - n] = 0;
+        }
+        ne++;
+      }
+      if (ne > P.max_edge) break;
+    }
+    for (int k = start; k < end; k++) {
+      const int idx = ord[k];
+      if (valid[idx] && c[idx] < P.planar_thr) {
+        planar.push_back(line * P.W + (uint32_t)idx);
+        for (int n = 0; n < np; n++) {
+          if (idx + n < W) valid[idx + n] = 0;
+          if (idx - n >= 0) valid[idx - n] = 0;
+        }
+        npl++;
+      }
+      if (npl > P.max_planar) break;
+    }
+  }
+}
+
+
 template <int R>
 void select_mis_line(const double* c, std::vector<uint8_t>& valid, const ExtractParams& P, uint32_t line,
                      std::vector<uint32_t>& edge, std::vector<uint32_t>& planar, bool* ok) {
@@ -105,7 +167,10 @@ void select_mis_line(const double* c, std::vector<uint8_t>& valid, const Extract
     *ok = false;
     return;
   }
-  uint64_t V[64], ET[64], PT[64], GT[64][R > 0 ? R : 1];
+  const std::vector<uint8_t> valid0 = valid;
+  const size_t edge0 = edge.size(), planar0 = planar.size();
+  bool tie = false;
+  uint64_t V[64], ET[64], PT[64], GT[64][R > 0 ? R : 1], EQ[64][R > 0 ? R : 1];
   for (int l = 0; l < 64; l++) {
     V[l] = ET[l] = PT[l] = 0;
     for (int j = 0; j < CH; j++) {
@@ -122,6 +187,12 @@ void select_mis_line(const double* c, std::vector<uint8_t>& valid, const Extract
         if (i >= 0 && i + d < W && c[i] > c[i + d]) g |= 1ull << t;
       }
       GT[l][d - 1] = g;
+      uint64_t e = 0;
+      for (int t = 0; t < CH + 2 * R; t++) {
+        const int i = l * CH - R + t;
+        if (i >= 0 && i + d < W && c[i] == c[i + d]) e |= 1ull << t;
+      }
+      EQ[l][d - 1] = e;
     }
   }
   const uint64_t cm = low_mask(CH);
@@ -141,6 +212,11 @@ void select_mis_line(const double* c, std::vector<uint8_t>& valid, const Extract
         U[l] = V[l] & (EDGE ? ET[l] : PT[l]) & sm;
         Pk[l] = 0;
         any |= U[l] != 0;
+      }
+      for (int l = 0; l < 64; l++) {  // equal curvatures among candidates within R points of each other (mis_pass)
+        const uint64_t Uw = mis_window<R>(U[l], l ? U[l - 1] : 0, l < 63 ? U[l + 1] : 0, CH);
+        for (int d = 1; d <= R; d++)
+          if (Uw & (Uw >> d) & EQ[l][d - 1]) tie = true;
       }
       while (any) {
         uint64_t win[64];
@@ -168,6 +244,8 @@ void select_mis_line(const double* c, std::vector<uint8_t>& valid, const Extract
       std::sort(mem.begin(), mem.end(), [&](const std::pair<double, int>& a, const std::pair<double, int>& b) {
         return EDGE ? edge_before(a.first, a.second, b.first, b.second) : planar_before(a.first, a.second, b.first, b.second);
       });
+      for (size_t k = 0; k + 1 < mem.size(); k++)
+        if (mem[k].first == mem[k + 1].first) tie = true;  // equal curvatures among the picks (the kernel: colliding keys)
       const size_t kept = std::min<size_t>(mem.size(), (size_t)maxf + 1);
       uint64_t K[64] = {0};
       for (size_t k = 0; k < kept; k++) {
@@ -180,10 +258,59 @@ void select_mis_line(const double* c, std::vector<uint8_t>& valid, const Extract
       }
     }
   }
+  if (tie || (P.flags & kFlagForceReplay)) {  // the reference's own order (select_mis_kernel: ring_replay)
+    edge.resize(edge0), planar.resize(planar0);
+    replay_line(c, valid0, P, line, edge, planar);
+    g_replayed_lines++;
+  }
   *ok = true;
 }
 }  // namespace
 extern "C" {
+
+uint64_t hostcheck_replayed_lines() { return g_replayed_lines; }
+
+// features-inl.h:27-48 + :137-180 restated literally on given curvature / mask arrays with the REAL std::sort on the
+// reference's element type: what select_mis_kernel must reproduce, ties included
+int hostcheck_select_stdsort(const double* curv, const uint8_t* mask_in, uint64_t H, uint64_t W, const loamx_fe_params* fe,
+                             uint32_t* edge_idx, uint64_t* n_edge, uint32_t* planar_idx, uint64_t* n_planar) {
+  struct PC {
+    size_t index;
+    double curvature;
+  };
+  std::vector<PC> cv(H * W);
+  std::vector<bool> valid(H * W);
+  for (size_t i = 0; i < H * W; i++) cv[i] = PC{i, curv[i]}, valid[i] = mask_in[i] != 0;
+  const size_t S = fe->number_sectors, pps = S ? W / S : 0, np = fe->neighbor_points;
+  size_t ne = 0, npl = 0;
+  for (size_t line = 0; line < H; line++)
+    for (size_t sector = 0; sector < S; sector++) {
+      const size_t start = line * W + sector * pps, end = sector == S - 1 ? (line + 1) * W : start + pps;
+      std::sort(cv.begin() + start, cv.begin() + end, [](const PC& l, const PC& r) { return l.curvature < r.curvature; });
+      size_t cnt = 0;
+      for (size_t k = end; k > start; k--) {
+        const PC c = cv[k - 1];
+        if (valid[c.index] && c.curvature > fe->edge_feat_threshold) {
+          edge_idx[ne++] = (uint32_t)c.index;
+          for (size_t n = 0; n < np; n++) valid[c.index + n] = false, valid[c.index - n] = false;
+          cnt++;
+        }
+        if (cnt > fe->max_edge_feats_per_sector) break;
+      }
+      cnt = 0;
+      for (size_t k = start; k < end; k++) {
+        const PC c = cv[k];
+        if (valid[c.index] && c.curvature < fe->planar_feat_threshold) {
+          planar_idx[npl++] = (uint32_t)c.index;
+          for (size_t n = 0; n < np; n++) valid[c.index + n] = false, valid[c.index - n] = false;
+          cnt++;
+        }
+        if (cnt > fe->max_planar_feats_per_sector) break;
+      }
+    }
+  *n_edge = ne, *n_planar = npl;
+  return 0;
+}
 
 // returns 0 if the MIS formulation applies to these parameters (else 1: kernel falls back)
 int hostcheck_select_mis(const double* curv, const uint8_t* mask_in, uint64_t H, uint64_t W, const loamx_fe_params* fe,
@@ -526,4 +653,46 @@ void hostcheck_synth_pose(uint64_t seed, uint64_t pair, double out[7]) {
   for (int i = 0; i < 3; i++) out[4 + i] = p.t[i];
 }
 
+}  // extern "C"
+
+// ---- row a7: the tie order. stl_sort (extract_math.h) replays libstdc++'s std::sort; here it runs next to the real one.
+extern "C" {
+// order[] <- the indices 0..n-1 as stl_sort leaves them for the comparator c[a] < c[b]
+uint64_t hostcheck_heap_sorts() { return g_heap_sorts; }
+void hostcheck_stl_sort(const double* c, uint64_t n, uint32_t* order) {
+  std::vector<uint16_t> idx(n);
+  for (uint64_t i = 0; i < n; i++) idx[i] = (uint16_t)i;
+  stl_sort(idx.data(), 0, (int)n, [&](uint16_t a, uint16_t b) { return c[a] < c[b]; });
+  for (uint64_t i = 0; i < n; i++) order[i] = idx[i];
+}
+// the same with the real std::sort on the reference's element type (features.h:79-91: {size_t index; double curvature},
+// comparator lhs.curvature < rhs.curvature)
+void hostcheck_std_sort(const double* c, uint64_t n, uint32_t* order) {
+  struct PC {
+    size_t index;
+    double curvature;
+  };
+  std::vector<PC> v(n);
+  for (uint64_t i = 0; i < n; i++) v[i] = PC{(size_t)i, c[i]};
+  std::sort(v.begin(), v.end(), [](const PC& l, const PC& r) { return l.curvature < r.curvature; });
+  for (uint64_t i = 0; i < n; i++) order[i] = (uint32_t)v[i].index;
+}
+// McIlroy's adversary ("A killer adversary for quicksort", 1999) played against the real std::sort: returns an input
+// on which the introsort's depth limit runs out, so that the heap-sort branch is part of the comparison above
+void hostcheck_killer_input(uint64_t n, double* out) {
+  std::vector<int> val(n), ptr(n);
+  const int gas = (int)n - 1;
+  int nsolid = 0, candidate = 0;
+  for (uint64_t i = 0; i < n; i++) ptr[i] = (int)i, val[i] = gas;
+  std::sort(ptr.begin(), ptr.end(), [&](int x, int y) {
+    if (val[x] == gas && val[y] == gas) {
+      if (x == candidate) val[x] = nsolid++;
+      else val[y] = nsolid++;
+    }
+    if (val[x] == gas) candidate = x;
+    else if (val[y] == gas) candidate = y;
+    return val[x] < val[y];
+  });
+  for (uint64_t i = 0; i < n; i++) out[i] = (double)val[i];
+}
 }  // extern "C"

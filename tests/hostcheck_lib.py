@@ -105,6 +105,24 @@ def select_mis(curv, mask, H, W, fe):
     return e[:ne.value].copy(), p[:npl.value].copy()
 
 
+def select_stdsort(curv, mask, H, W, fe):
+    """features-inl.h:27-48 + :137-180 literally, with the real std::sort, on given curvature / mask arrays"""
+    curv = np.ascontiguousarray(curv, dtype=np.float64)
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    e = np.empty(H * W + 1, dtype=np.uint32)
+    p = np.empty(H * W + 1, dtype=np.uint32)
+    ne, npl = C.c_uint64(0), C.c_uint64(0)
+    lib().hostcheck_select_stdsort(_dp(curv), mask.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_uint64(H), C.c_uint64(W),
+                                   C.byref(fe), e.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(ne),
+                                   p.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(npl))
+    return e[:ne.value].copy(), p[:npl.value].copy()
+
+
+def replayed_lines():
+    lib().hostcheck_replayed_lines.restype = C.c_uint64
+    return lib().hostcheck_replayed_lines()
+
+
 def knn(pts, q, k, max_dist):
     pts = np.ascontiguousarray(pts, dtype=np.float64)
     q = np.ascontiguousarray(q, dtype=np.float64)

@@ -55,11 +55,8 @@ def test_extraction_parity_synthetic(oracle, H, W, seed):
         assert np.array_equal(c.view(np.uint64), oracle.compute_curvature(xyz, H, W, ofe).view(np.uint64))
         assert np.array_equal(m, oracle.compute_valid_points(xyz, H, W, 1.0, 120.0, ofe))
         e, p = ctx().extract_features(xyz, lidar, fe)
-        se, sp, ties = oracle.extract_features(xyz, H, W, 1.0, 120.0, ofe, stable=True)
-        assert np.array_equal(e, se) and np.array_equal(p, sp)
-        if ties == 0:  # tie-free => also identical to the reference's std::sort order
-            oe, op = oracle.extract_features(xyz, H, W, 1.0, 120.0, ofe)
-            assert np.array_equal(e, oe) and np.array_equal(p, op)
+        oe, op = oracle.extract_features(xyz, H, W, 1.0, 120.0, ofe)  # the reference's std::sort order, ties included
+        assert np.array_equal(e, oe) and np.array_equal(p, op)
 
 
 def test_dropouts_and_out_of_range(oracle):
@@ -73,24 +70,95 @@ def test_dropouts_and_out_of_range(oracle):
     assert np.array_equal(c.view(np.uint64), oracle.compute_curvature(xyz, 16, 512).view(np.uint64))
     assert np.array_equal(m, oracle.compute_valid_points(xyz, 16, 512, 1.0, 120.0))
     e, p = ctx().extract_features(xyz, lidar)
-    se, sp, _ = oracle.extract_features(xyz, 16, 512, 1.0, 120.0, stable=True)
-    assert np.array_equal(e, se) and np.array_equal(p, sp)
+    oe, op = oracle.extract_features(xyz, 16, 512, 1.0, 120.0)  # (the zeroed points tie with each other: reference order)
+    assert np.array_equal(e, oe) and np.array_equal(p, op)
 
 
-@pytest.mark.parametrize("H,W", [(32, 512), (8, 2048)])  # 2048 columns: more than 64 picks per sector, two per lane
-def test_tie_policy_noise_free(oracle, H, W):
+@pytest.mark.parametrize("H,W", [(32, 512), (8, 2048), (64, 1024)])  # 2048 columns: more than 64 picks per sector, two per lane
+def test_tie_policy_noise_free(oracle, H, W, monkeypatch):
+    """Row a7: noise-free scans hold exact curvature ties (356 on a 64 x 1024 scan); where a tie can decide
+    a pick or the output order the kernels replay the scan line in the order libstdc++'s std::sort gives the
+    reference (features-inl.h:38), so the index sequences are the oracle's std::sort ones — not the stable order."""
     xyz = capi.synth_scan_host(2, 0, 0, H, W, 0.0)
-    e, p = ctx().extract_features(xyz, capi.LidarParams(H, W, 1.0, 120.0))
+    oe, op = oracle.extract_features(xyz, H, W, 1.0, 120.0)  # std::sort, as the reference
     se, sp, ties = oracle.extract_features(xyz, H, W, 1.0, 120.0, stable=True)
-    assert np.array_equal(e, se) and np.array_equal(p, sp)
-    if W == 2048:  # ... and the arg-max fallback agrees
-        import os
-        os.environ["LOAMX_NO_MIS_SELECT"] = "1"
-        try:
-            e2, p2 = ctx().extract_features(xyz, capi.LidarParams(H, W, 1.0, 120.0))
-        finally:
-            del os.environ["LOAMX_NO_MIS_SELECT"]
-        assert np.array_equal(e2, se) and np.array_equal(p2, sp)
+    assert ties > 0
+    r0 = ctx().extract_counters()[0]
+    e, p = ctx().extract_features(xyz, capi.LidarParams(H, W, 1.0, 120.0))
+    assert np.array_equal(e, oe) and np.array_equal(p, op)
+    replayed = ctx().extract_counters()[0] - r0
+    assert 0 < replayed <= H
+    if not (np.array_equal(oe, se) and np.array_equal(op, sp)):
+        assert not (np.array_equal(e, se) and np.array_equal(p, sp))
+    # ... and the arg-max fallback kernel detects and replays them too
+    monkeypatch.setenv("LOAMX_NO_MIS_SELECT", "1")
+    e2, p2 = ctx().extract_features(xyz, capi.LidarParams(H, W, 1.0, 120.0))
+    monkeypatch.delenv("LOAMX_NO_MIS_SELECT")
+    assert np.array_equal(e2, oe) and np.array_equal(p2, op)
+    assert ctx().extract_counters()[0] - r0 > replayed
+
+
+@pytest.mark.parametrize("params", PARAM_SETS)
+def test_quantised_scan_ties_in_reference_order(oracle, params):
+    """coordinates rounded to 1/64 m (a sensor that reports fixed-point ranges): ties in every sector"""
+    H, W = 16, 1024
+    xyz = np.round(capi.synth_scan_host(9, 1, 0, H, W, 0.01) * 64.0) / 64.0
+    ofe, fe = oracle.FeParams(*params), capi.FeatureExtractionParams(*params)
+    oe, op = oracle.extract_features(xyz, H, W, 1.0, 120.0, ofe)
+    _, _, ties = oracle.extract_features(xyz, H, W, 1.0, 120.0, ofe, stable=True)
+    assert ties > 0
+    e, p = ctx().extract_features(xyz, capi.LidarParams(H, W, 1.0, 120.0), fe)
+    assert np.array_equal(e, oe) and np.array_equal(p, op)
+
+
+def test_forced_replay_and_forced_fallback_change_nothing(oracle, monkeypatch):
+    """The two rare paths on ordinary (tie-free) input: every line through the std::sort replay
+    (LOAMX_FORCE_TIE_REPLAY), and every scan line after the first giving up its wait so that the fallback kernel
+    gathers the features (LOAMX_FORCE_SCAN_GIVEUP): same sequences, no error, events counted."""
+    H, W = 64, 1024
+    xyz = capi.synth_scan_host(17, 0, 0, H, W, 0.01)
+    lidar = capi.LidarParams(H, W, 1.0, 120.0)
+    oe, op = oracle.extract_features(xyz, H, W, 1.0, 120.0)
+    r0, f0 = ctx().extract_counters()
+    e, p = ctx().extract_features(xyz, lidar)
+    assert np.array_equal(e, oe) and np.array_equal(p, op)
+    assert ctx().extract_counters() == (r0, f0)  # noisy scan: neither path ran
+    monkeypatch.setenv("LOAMX_FORCE_TIE_REPLAY", "1")
+    e, p = ctx().extract_features(xyz, lidar)
+    monkeypatch.delenv("LOAMX_FORCE_TIE_REPLAY")
+    assert np.array_equal(e, oe) and np.array_equal(p, op)
+    assert ctx().extract_counters()[0] == r0 + H
+    f0 = ctx().extract_counters()[1]  # (tied lines also hand their scan to the fallback compaction)
+    monkeypatch.setenv("LOAMX_FORCE_SCAN_GIVEUP", "1")
+    e, p = ctx().extract_features(xyz, lidar)
+    assert np.array_equal(e, oe) and np.array_equal(p, op)
+    assert ctx().extract_counters()[1] == f0 + 1
+    # the batch entry point with point copies, asynchronously: still the oracle's, and the flag does not stick
+    N, ns = H * W, 3
+    c = ctx()
+    fe = capi.FeatureExtractionParams()
+    scans = np.stack([capi.synth_scan_host(200 + s, 0, 0, H, W, 0.01) for s in range(ns)])
+    d_xyz = c.alloc(scans.nbytes).upload(scans)
+    ecap, pcap = c.edge_capacity(lidar, fe), c.planar_capacity(lidar, fe)
+    d_ei, d_pi, d_ne, d_np = c.alloc(ns * ecap * 4), c.alloc(ns * pcap * 4), c.alloc(ns * 4), c.alloc(ns * 4)
+    d_ex, d_px = c.alloc(ns * ecap * 24), c.alloc(ns * pcap * 24)
+    for forced in (True, False):
+        if not forced:
+            monkeypatch.delenv("LOAMX_FORCE_SCAN_GIVEUP")
+        f1 = c.extract_counters()[1]
+        c.extract_features_batch_dev(d_xyz.ptr, ns, lidar, fe, d_ei.ptr, d_ne.ptr, d_ex.ptr, d_pi.ptr, d_np.ptr, d_px.ptr)
+        c.synchronize()
+        assert c.extract_counters()[1] == f1 + (1 if forced else 0)
+        ne, npl = d_ne.download(np.uint32, ns), d_np.download(np.uint32, ns)
+        pi = d_pi.download(np.uint32, ns * pcap).reshape(ns, pcap)
+        px = d_px.download(np.float64, ns * pcap * 3).reshape(ns, pcap, 3)
+        ei = d_ei.download(np.uint32, ns * ecap).reshape(ns, ecap)
+        for s in range(ns):
+            oe, op = oracle.extract_features(scans[s], H, W, 1.0, 120.0)
+            assert np.array_equal(ei[s, :ne[s]], oe) and np.array_equal(pi[s, :npl[s]], op)
+            assert np.array_equal(px[s, :npl[s]], scans[s][op])
+    for b_ in (d_xyz, d_ei, d_pi, d_ne, d_np, d_ex, d_px):
+        b_.free()
 
 
 def test_device_generator_bit_identical_and_batch_extract(oracle):
@@ -142,7 +210,7 @@ def test_fp32_input_path_equals_oracle_on_widened_scan(oracle, H, W, seed):
         assert np.array_equal(c.view(np.uint64), oracle.compute_curvature(wide, H, W, ofe).view(np.uint64))
         assert np.array_equal(m, oracle.compute_valid_points(wide, H, W, 1.0, 120.0, ofe))
         e, p = ctx().extract_features(xyz32, lidar, fe)
-        se, sp, _ = oracle.extract_features(wide, H, W, 1.0, 120.0, ofe, stable=True)
+        se, sp = oracle.extract_features(wide, H, W, 1.0, 120.0, ofe)
         assert np.array_equal(e, se) and np.array_equal(p, sp)
         e64, p64 = ctx().extract_features(wide, lidar, fe)
         assert np.array_equal(e, e64) and np.array_equal(p, p64)
@@ -182,7 +250,7 @@ def test_fused_and_unfused_compaction_agree(oracle, monkeypatch):
     for params in [(3, 6, 10, 50, 100.0, 1.0, 0.5, 1.0), (3, 80, 2, 3, 100.0, 1.0, 0.5, 1.0), (2, 64, 1, 4, 50.0, 1.0, 0.5, 1.0)]:
         ofe = oracle.FeParams(*params)
         fe = capi.FeatureExtractionParams(*params)
-        se, sp, _ = oracle.extract_features(xyz, H, W, 1.0, 120.0, ofe, stable=True)
+        se, sp = oracle.extract_features(xyz, H, W, 1.0, 120.0, ofe)
         monkeypatch.delenv("LOAMX_NO_FUSED_COMPACT", raising=False)
         e1, p1 = ctx().extract_features(xyz, lidar, fe)
         monkeypatch.setenv("LOAMX_NO_FUSED_COMPACT", "1")

@@ -297,3 +297,31 @@ def test_non_finite_jacobian_path(oracle):
     assert (tg, ig) == (to, io)
     rot, trans = pose_diff(oracle, po, pg)
     assert rot < SE3_TOL and trans < SE3_TOL, (rot, trans)
+
+
+@pytest.mark.parametrize("n", [82, 300, 2500])
+def test_index_build_with_an_odd_cell_count_and_an_occupied_top_corner(oracle, n):
+    """Regression (round 2): with an odd number of cells the packed cell table's last word is half used; idle threads of
+    the index build's scan rewrote it, which corrupted the offsets of the last cell whenever that cell — the
+    bounding box's maximum corner — held a point. A point set with a point AT the maximum corner, searched against
+    itself and a shifted copy: associations and nearest neighbours must be the oracle's."""
+    rng = np.random.default_rng(n)
+    pts = rng.uniform([-2.0, 0.5, -1.25], [1.0, 3.0, 1.25], (n, 3))
+    pts[0] = [1.0, 3.0, 1.25]  # the maximum corner itself
+    pts[1:9] = pts[0] - rng.uniform(0.0, 0.05, (8, 3))  # and company in its cell
+    reg = capi.RegistrationParams()
+    reg.min_associations, reg.max_iterations = 10, 2
+    oreg = oracle.RegParams()
+    oreg.min_associations, oreg.max_iterations = 10, 2
+    for shift in (0.0, 0.013):
+        src = pts + shift
+        for as_planes in (False, True):
+            e, p = (np.zeros((0, 3)), src) if as_planes else (src, np.zeros((0, 3)))
+            te, tp = (np.zeros((0, 3)), pts) if as_planes else (pts, np.zeros((0, 3)))
+            valid, nearest, _, _ = oracle.associate(src, pts, [0, 0, 0, 1.0, 0, 0, 0], as_planes, oreg)
+            pg, tg, ig, det = ctx().register_features(e, p, te, tp, reg=reg, want_detail=True)
+            if not det["iterations"]:
+                assert valid.sum() < 10
+                continue
+            pairs = det["iterations"][0]["plane_pairs" if as_planes else "edge_pairs"]
+            assert np.array_equal(pairs[:, 0], np.nonzero(valid)[0]) and np.array_equal(pairs[:, 1], nearest[valid])

@@ -32,11 +32,8 @@ def test_extraction_bit_exact_on_synthetic(oracle, H, W, seed):
         assert np.array_equal(curv.view(np.uint64), oracle.compute_curvature(xyz, H, W, ofe).view(np.uint64))
         assert np.array_equal(mask, oracle.compute_valid_points(xyz, H, W, 1.0, 120.0, ofe))
         e, p = Hc.select(curv, mask, H, W, fe)
-        oe, op = oracle.extract_features(xyz, H, W, 1.0, 120.0, ofe)
-        se, sp, ties = oracle.extract_features(xyz, H, W, 1.0, 120.0, ofe, stable=True)
-        assert np.array_equal(e, se) and np.array_equal(p, sp)
-        if ties == 0:  # tie-free: identical to the reference's std::sort order as well
-            assert np.array_equal(e, oe) and np.array_equal(p, op)
+        oe, op = oracle.extract_features(xyz, H, W, 1.0, 120.0, ofe)  # (std::sort order, ties included)
+        assert np.array_equal(e, oe) and np.array_equal(p, op)
 
 
 @pytest.mark.parametrize("H,W,seed,sigma", [(16, 1024, 1, 0.01), (8, 256, 3, 0.01), (8, 512, 2, 0.0), (4, 2048, 4, 0.01), (4, 700, 6, 0.01)])
@@ -52,21 +49,59 @@ def test_bitmask_mis_selection_matches_oracle(oracle, H, W, seed, sigma):
         r = Hc.select_mis(curv, mask, H, W, fe)
         if r is None:  # parameters outside the MIS kernel's domain: the general kernel is used
             continue
-        se, sp, _ = oracle.extract_features(xyz, H, W, 1.0, 120.0, oracle.FeParams(*params), stable=True)
-        assert np.array_equal(r[0], se) and np.array_equal(r[1], sp)
+        oe, op = oracle.extract_features(xyz, H, W, 1.0, 120.0, oracle.FeParams(*params))  # the reference's order, ties included
+        assert np.array_equal(r[0], oe) and np.array_equal(r[1], op)
         checked += 1
     assert checked >= 4
 
 
-def test_extraction_tie_policy_on_noise_free_scan(oracle):
-    # noise-free synthetic scans contain exact curvature ties: the kernels' documented
-    # policy is the stable ascending order
+def test_extraction_tie_order_on_noise_free_scan(oracle):
+    # noise-free synthetic scans contain exact curvature ties: the lines they can decide something on are
+    # replayed in the order libstdc++'s std::sort gives the reference (row a7)
     xyz = Hc.synth_scan(2, 0, 0, 32, 512, 0.0)
     ofe = oracle.FeParams()
     curv, mask = Hc.curvature_valid(xyz, 32, 512, 1.0, 120.0, Hc.fe_params())
-    e, p = Hc.select(curv, mask, 32, 512, Hc.fe_params())
+    oe, op = oracle.extract_features(xyz, 32, 512, 1.0, 120.0, ofe)
     se, sp, ties = oracle.extract_features(xyz, 32, 512, 1.0, 120.0, ofe, stable=True)
-    assert np.array_equal(e, se) and np.array_equal(p, sp)
+    assert ties > 0 and not (np.array_equal(oe, se) and np.array_equal(op, sp))  # the tie order is observable here
+    before = Hc.replayed_lines()
+    e, p = Hc.select(curv, mask, 32, 512, Hc.fe_params())
+    assert np.array_equal(e, oe) and np.array_equal(p, op)
+    e, p = Hc.select_mis(curv, mask, 32, 512, Hc.fe_params())
+    assert np.array_equal(e, oe) and np.array_equal(p, op)
+    assert 0 < Hc.replayed_lines() - before < 2 * 32  # some lines, not all of them
+
+
+@pytest.mark.parametrize("W,params", [(1024, (3, 6, 10, 50, 100.0, 1.0, 0.5, 1.0)), (512, (3, 6, 3, 8, 60.0, 20.0, 0.5, 1.0)),
+                                      (700, (4, 5, 10, 20, 50.0, 10.0, 0.5, 1.0)), (256, (2, 3, 0, 3, 10.0, 30.0, 0.5, 1.0)),
+                                      (2048, (3, 6, 10, 50, 100.0, 1.0, 0.5, 1.0))])
+def test_tie_detection_is_sufficient_on_quantised_curvature(W, params):
+    """Curvature arrays with few distinct values (ties everywhere) and random masks: the selection emulations (tie
+    detection + replay where a tie can decide something, the fast formulation elsewhere) must equal the literal
+    restatement with the real std::sort — in particular on the lines the detection lets through."""
+    rng = np.random.default_rng(W + params[0])
+    fe = Hc.fe_params(*params)
+    H = 6
+    replayed = fast = 0
+    for levels, pmask in [(4, 0.9), (30, 0.8), (300, 0.7), (5000, 0.95), (10 ** 6, 0.9)]:
+        for trial in range(6):
+            curv = rng.integers(0, levels, H * W).astype(np.float64) * (150.0 / levels)
+            mask = rng.random(H * W) < pmask
+            np_ = params[0]
+            cols = np.arange(H * W) % W
+            mask &= (cols >= np_) & (cols < W - np_)  # valid points keep neighbor_points from the line ends (features.cpp:22)
+            curv[(cols < np_) | (cols >= W - np_)] = -1.0
+            ref = Hc.select_stdsort(curv, mask, H, W, fe)
+            before = Hc.replayed_lines()
+            got = Hc.select(curv, mask, H, W, fe)
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), (levels, trial)
+            r = Hc.select_mis(curv, mask, H, W, fe)
+            if r is not None:
+                assert np.array_equal(r[0], ref[0]) and np.array_equal(r[1], ref[1]), (levels, trial)
+            n = Hc.replayed_lines() - before
+            replayed += n
+            fast += (2 if r is not None else 1) * H - n
+    assert replayed > 0 and fast > 0
 
 
 def test_out_of_range_and_dropout_points(oracle):
@@ -242,3 +277,50 @@ def test_plane_only_and_insufficient(oracle):
     assert oracle.quat_angular_distance(ph[:4], [0, 0, 0, 1.0]) < 1e-4 and np.all(np.abs(ph[4:]) < 1e-3)
     ph, th, ih = Hc.register(e, p + np.array([100.0, 0, 0]), e, p)
     assert th == 2 and ih == 0 and np.allclose(ph, [0, 0, 0, 1, 0, 0, 0])
+
+
+# ---- row a7: libstdc++'s std::sort replayed (extract_math.h: stl_sort) vs the real one ---------------------------------
+def _sort_pair(c):
+    import ctypes as C
+    lib = Hc.lib()
+    c = np.ascontiguousarray(c, dtype=np.float64)
+    a, b = np.zeros(len(c), np.uint32), np.zeros(len(c), np.uint32)
+    dp, up = C.POINTER(C.c_double), C.POINTER(C.c_uint32)
+    lib.hostcheck_stl_sort(c.ctypes.data_as(dp), C.c_uint64(len(c)), a.ctypes.data_as(up))
+    lib.hostcheck_std_sort(c.ctypes.data_as(dp), C.c_uint64(len(c)), b.ctypes.data_as(up))
+    return a, b
+
+
+def test_stl_sort_replays_std_sort_on_ties():
+    rng = np.random.default_rng(77)
+    for n in (0, 1, 2, 3, 15, 16, 17, 18, 33, 170, 174, 341, 343, 1024, 4096):
+        for levels in (1, 2, 3, 7, 40, 1000):  # few distinct values = many ties
+            for _ in range(6):
+                c = rng.integers(0, levels, n).astype(np.float64)
+                if levels == 7:
+                    c[rng.random(n) < 0.3] = -1.0  # the line-end curvature (features-inl.h:66-68)
+                a, b = _sort_pair(c)
+                assert np.array_equal(a, b), (n, levels)
+                assert np.array_equal(np.sort(a), np.arange(n))
+        c = rng.normal(size=n)  # tie free: any correct sort gives this
+        a, b = _sort_pair(c)
+        assert np.array_equal(a, b) and np.array_equal(a, np.argsort(c, kind="stable"))
+        for c in (np.arange(n, dtype=float), np.arange(n, dtype=float)[::-1], np.zeros(n), np.r_[np.zeros(n // 2), np.ones(n - n // 2)]):
+            a, b = _sort_pair(c)
+            assert np.array_equal(a, b)
+
+
+def test_stl_sort_replays_the_heap_sort_branch():
+    import ctypes as C
+    lib = Hc.lib()
+    lib.hostcheck_heap_sorts.restype = C.c_uint64
+    for n in (170, 174, 343, 1024, 4096):
+        c = np.zeros(n)
+        lib.hostcheck_killer_input(C.c_uint64(n), c.ctypes.data_as(C.POINTER(C.c_double)))
+        before = lib.hostcheck_heap_sorts()
+        a, b = _sort_pair(c)  # (the adversary's input drives std::sort to its depth limit: 2 lg n levels of bad splits)
+        assert np.array_equal(a, b)
+        assert lib.hostcheck_heap_sorts() > before, n  # the heap-sort branch really ran
+        q = np.floor(c / 3.0)  # the same shape with ties
+        a, b = _sort_pair(q)
+        assert np.array_equal(a, b)
