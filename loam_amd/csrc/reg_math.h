@@ -1016,6 +1016,183 @@ LOAMX_HD int knn_f32_round1_body(const GridDesc& g, const GridPoint* __restrict_
 }
 
 
+/* ------------------------------------------------------------------------------------------------
+ * Round 1 with the FP32 collector, lean form (round 2) — same search, same exactness argument and the same
+ * return contract as knn_f32_round1_body<KM, false>, restructured for instruction count: the PMC pass of round 1
+ * showed 2 440 vector instructions per wavefront of which the candidate loop was 1 100; the rest was set-up,
+ * divergent list handling and a 9-row x k-key scan that mapped running numbers back to positions.
+ *   - the non-empty rows of the 3x3x3 block go to the per-thread list as begin | end << 16 (16-bit positions: sets
+ *     below 65 536 points) in visiting order, with their squared slab distance as a float next to them;
+ *   - the walk takes ONE row step per trip, predicated instead of branched (a lane whose range is used up looks at
+ *     its next row and takes it or not; every lane that holds a range scans one batch): no inner loop and none of
+ *     the exec-mask bookkeeping the nested divergent loops cost (measured: 1.58 -> 1.45 ms per launch);
+ *   - every visited row appends (begin | first batch << 16) to a compact list and sets bit `first batch` in a
+ *     64-bit mask: the row of a key with batch number tb is entry popcount(mask & ((2 << tb) - 1)) - 1 — five
+ *     instructions per key instead of a scan over the rows.
+ * Per-thread list: kLeanRowWords words ([word][thread] in LDS).
+ * ---------------------------------------------------------------------------------------------- */
+constexpr int kLeanRowWords = 27;
+constexpr uint32_t kLeanMaxPoints = 65535u;  // positions are packed as 16-bit halves
+
+LOAMX_HD int knn_popcount64(uint64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __popcll(v);
+#else
+  return __builtin_popcountll(v);
+#endif
+}
+
+template <int KM>
+LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cell_start, const GridPoint* __restrict__ sp,
+                             const float* __restrict__ rel, uint32_t plane, Vec3 q, int k, double max_dist, double pass_max,
+                             uint32_t pos[KM], uint32_t* row_scratch, int row_stride) {
+#pragma unroll
+  for (int j = 0; j < KM; j++) pos[j] = 0;
+  if (g.n_points == 0 || k <= 0) return 0;
+  if (k > KM) k = KM;
+  const int32_t cx = grid_cell_coord(q.x, g.ox, g.inv_h);
+  const int32_t cy = grid_cell_coord(q.y, g.oy, g.inv_h);
+  const int32_t cz = grid_cell_coord(q.z, g.oz, g.inv_h);
+  const int32_t out = grid_outside_distance(g, cx, cy, cz);
+  if (max_dist > 0.0 && out >= 1 && (double)(out - 1) * g.h >= max_dist) return 0;
+  if (out > 1) return -1;
+  const double a = knn_f32_err_unit(g);
+  const double r2 = knn_radius_bound(max_dist);
+  const float qx = (float)(q.x - g.ox), qy = (float)(q.y - g.oy), qz = (float)(q.z - g.oz);
+  // row pruning in single precision, conservatively: slab distances rounded down, the bound up
+  const float kDown = 0.99999f, kUp = 1.00001f;
+  const double sy2m = slab_dist(q.y, g.oy, g.h, cy - 1), sy2p = slab_dist(q.y, g.oy, g.h, cy + 1);
+  const double sz2m = slab_dist(q.z, g.oz, g.h, cz - 1), sz2p = slab_dist(q.z, g.oz, g.h, cz + 1);
+  const float fy2[3] = {(float)(sy2m * sy2m) * kDown, 0.0f, (float)(sy2p * sy2p) * kDown};
+  const float fz2[3] = {(float)(sz2m * sz2m) * kDown, 0.0f, (float)(sz2p * sz2p) * kDown};
+  const float fr2 = r2 < 1e37 ? (float)r2 * kUp : 3.0e38f;
+  const float fa2 = (float)(3003.0 * a * a) * kUp;
+  int nrow = 0;
+  {  // the non-empty rows of the nine, centre first, then faces, then corners
+    const int32_t xa = cx - 1 < 0 ? 0 : cx - 1, xb = cx + 1 > g.nx - 1 ? g.nx - 1 : cx + 1;
+    uint32_t rb[9], re[9];
+#pragma unroll
+    for (int o = 0; o < 9; o++) {
+      constexpr int kOrder[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
+      const int j = kOrder[o];
+      const int32_t iy = cy + (j % 3) - 1, iz = cz + (j / 3) - 1;
+      const bool ok = xa <= xb && iy >= 0 && iy <= g.ny - 1 && iz >= 0 && iz <= g.nz - 1;
+      const uint32_t row = ok ? (uint32_t)((iz * g.ny + iy) * g.nx) : 0u;
+      rb[o] = ok ? cell_start_at(cell_start, row + (uint32_t)xa) : 0u;
+      re[o] = ok ? cell_start_at(cell_start, row + (uint32_t)xb + 1u) : 0u;
+    }
+#pragma unroll
+    for (int o = 0; o < 9; o++) {
+      constexpr int kOrder[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
+      const int j = kOrder[o];
+      if (rb[o] < re[o]) {
+        row_scratch[nrow * row_stride] = rb[o] | (re[o] << 16);
+        row_scratch[(9 + nrow) * row_stride] = knn_f32_bits(fy2[j % 3] + fz2[j / 3]);
+        nrow++;
+      }
+    }
+  }
+  KnnKeys32<KM> c;
+  knn_init(c, k);
+#ifndef LOAMX_LEAN_TMAX
+#define LOAMX_LEAN_TMAX 64
+#endif
+  constexpr uint32_t imask = 0xFFu, tmax = LOAMX_LEAN_TMAX;  // trips a lane may take before it hands its query to the queue (<= 64)
+  uint32_t p = 0, e = 0, t = 0;  // t = batches consumed so far
+  int ri = 0, nv = 0;
+  uint64_t started = 0;  // bit t: a visited row starts with batch t
+  // one row step per trip, predicated instead of branched: a lane whose range is used up looks at its next row
+  // (taking it or not), every lane that holds a range scans one batch; no inner loop, no exec-mask bookkeeping
+  for (;;) {
+    const bool need = p >= e, have = ri < nrow;
+    const int rr = have ? ri : 0;
+    const uint32_t w = row_scratch[rr * row_stride];
+    const float s2 = knn_bits_f32(row_scratch[(9 + rr) * row_stride]);
+    const uint32_t kth = c.key[KM - 1];
+    const float worst = kth >= 0x7F800000u ? 3.0e38f : (knn_bits_f32(kth | imask) + fa2) * (1.002f * kUp);
+    const float bound = worst < fr2 ? worst : fr2;
+    const bool step = need && have;
+    const bool take = step && s2 <= bound && t < tmax;
+    ri += step ? 1 : 0;
+    p = take ? (w & 0xFFFFu) : p, e = take ? (w >> 16) : e;
+    if (take) {
+      row_scratch[(18 + nv) * row_stride] = (w & 0xFFFFu) | (t << 16);
+      nv++;
+      started |= 1ull << t;
+    }
+    const bool active = p < e;
+    if (!active && !(ri < nrow)) break;  // (lanes leave for good: t stays in step for the others)
+    if (t >= tmax) break;
+    if (active) knn_scan_batch_f32(c, qx, qy, qz, rel, plane, p, e - p, t << 2, imask);
+    p += active ? 4u : 0u;
+    t++;
+  }
+  if (p < e || (t >= tmax && ri < nrow)) return -2;  // the running number is exhausted (more than 63 batches)
+  // ---- is the search over after the 3x3x3 block? (same test as knn_done, with the rigorous bound)
+  {
+    double guard = kDblMax;
+    const double m = 1e-9 * g.h;
+    const int32_t c3[3] = {cx, cy, cz}, n3[3] = {g.nx, g.ny, g.nz};
+    const double q3[3] = {q.x, q.y, q.z}, o3[3] = {g.ox, g.oy, g.oz};
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) {
+      if (c3[ax] - 1 > 0) {
+        const double d = (q3[ax] - (o3[ax] + (double)(c3[ax] - 1) * g.h)) * (1.0 - 1e-9) - m;
+        guard = d < guard ? d : guard;
+      }
+      if (c3[ax] + 1 < n3[ax] - 1) {
+        const double d = ((o3[ax] + (double)(c3[ax] + 2) * g.h) - q3[ax]) * (1.0 - 1e-9) - m;
+        guard = d < guard ? d : guard;
+      }
+    }
+    if (guard < 0.0) guard = 0.0;
+    const bool done = guard == kDblMax || knn_bound32(c, a, imask) < guard * guard || (max_dist > 0.0 && guard >= max_dist);
+    if (!done) return -1;
+  }
+  // ---- exact verification of the k selected candidates
+  int count = 0, kept = 0;
+  bool undecided = false, open = true;
+  double prev = -1.0, d5 = 0.0;
+#pragma unroll
+  for (int i = 0; i < KM; i++) {
+    const uint32_t key = c.key[i];
+    const bool real = i >= KM - k && key != 0xFFFFFFFFu;
+    if (real) {
+      if (key >= 0x7F800000u) undecided = true;
+      const uint32_t tb = (key & imask) >> 2, ii = key & 3u;
+      const int ord = knn_popcount64(started & ((2ull << tb) - 1ull)) - 1;  // the visited row this batch belongs to
+      const uint32_t v = row_scratch[(18 + (ord < 0 ? 0 : ord)) * row_stride];
+      const uint32_t pp = (v & 0xFFFFu) + (tb - (v >> 16)) * 4u + ii;
+      pos[i] = pp;
+      const GridPoint tp = sp[pp];
+      const double dx = q.x - tp.x, dy = q.y - tp.y, dz = q.z - tp.z;
+      const double d2 = dx * dx + dy * dy + dz * dz;  // as knn_scan_batch
+      if (!(d2 > prev)) undecided = true;             // a tie or an inversion: the exact order is not this one
+      if (!(d2 <= kDblMax)) undecided = true;
+      prev = d2, d5 = d2;
+      count++;
+      if (open) {
+        if (d2 <= pass_max) kept++;
+        else open = false;
+      }
+    }
+  }
+  const uint32_t k6 = c.key[KM];
+  if (count == k && k6 != 0xFFFFFFFFu) {
+    const double t6 = (double)knn_bits_f32(k6 & ~imask);
+    // an upper bound of sqrt(d5) is enough (float square root, rounded up generously)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double sd5 = (double)(__fsqrt_rn((float)d5) * 1.000001f) + 1e-18;
+#else
+    const double sd5 = (double)(sqrtf((float)d5) * 1.000001f) + 1e-18;
+#endif
+    const double err = 2.0 * (3.4641016151377544 * a * sd5 + 3.0 * a * a + 2.384185791015625e-7 * d5);  // x2 safety
+    if (!(t6 > d5 + err)) undecided = true;
+  }
+  return undecided ? -1 : kept;
+}
+
+
 // WIDE = false: 8-bit running numbers (the fast kernel; a query with more than 63 batches is queued);
 // WIDE = true: 10 or 12 bits (the queue kernel tries this before the FP64 search: dense local maps).
 template <int KM, bool WIDE = false>
@@ -1023,6 +1200,10 @@ LOAMX_HD int knn_search_f32_round1(const GridDesc& g, const uint32_t* __restrict
                                    const GridPoint* __restrict__ sp, const float* __restrict__ rel, uint32_t plane, Vec3 q,
                                    int k, double max_dist, double pass_max, uint32_t pos[KM], uint32_t* row_scratch,
                                    int row_stride) {
+#if !defined(LOAMX_NO_LEAN_KNN)
+  if (!WIDE && g.n_points <= kLeanMaxPoints)  // (wave-uniform: a property of the target set)
+    return knn_lean_round1<KM>(g, cell_start, sp, rel, plane, q, k, max_dist, pass_max, pos, row_scratch, row_stride);
+#endif
 #pragma unroll
   for (int j = 0; j < KM; j++) pos[j] = 0;
   if (g.n_points == 0 || k <= 0) return 0;

@@ -603,7 +603,7 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_kn
   const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));  // registration.cpp:34 / :75
   const uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
   const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
-  __shared__ uint32_t s_rows[18 * kAssocThreads];  // per-thread list of non-empty rows, [word][thread] (conflict free)
+  __shared__ uint32_t s_rows[kLeanRowWords * kAssocThreads];  // per-thread row lists of knn_lean_round1, [word][thread] (conflict free)
   uint32_t pos[KM];
   const float* __restrict__ rel = gs.rel + pair * 3 * gs.stride;
   const int kept = knn_search_f32_round1<KM>(g, cs, sp, rel, (uint32_t)gs.stride, p, PLANE ? C.k_plane : C.k_edge,
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(kRestThreads) void associate_knn_rest_kernel(RegBat
   if (!S.active) return;                                              // uniform per workgroup
   const uint32_t queued = B.assoc.n_assoc[8 * pair + (PLANE ? 3 : 2)];
   if (queued == 0u) return;                                           // uniform per workgroup
-  __shared__ uint32_t s_rows[18 * kRestThreads];
+  __shared__ uint32_t s_rows[kLeanRowWords * kRestThreads];
   const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
   const size_t field = B.n_pairs * stride;
   uint32_t* __restrict__ rnn = PLANE ? B.assoc.rnn_plane : B.assoc.rnn_edge;  // results by queue position

@@ -384,7 +384,7 @@ static uint64_t g_plane_streams = 0;
 static uint64_t g_knn_fallbacks = 0, g_knn_mismatch = 0, g_knn_queued = 0;
 template <int KM>
 static int knn_both(const HostGrid& G, Vec3 q, int k, double max_dist, uint32_t pos[KM]) {
-  uint32_t rows[18], fb = 0;
+  uint32_t rows[kLeanRowWords], fb = 0;
   // as the kernels do: round-1-only keyed search; what it cannot finish goes to the complete search
   const double pass_max = knn_radius_pass_max(max_dist);
   int kept = knn_search_f32_round1<KM>(G.g, G.cell_start.data(), G.sp.data(), G.rel.data(), (uint32_t)G.sp.size(), q, k, max_dist,
@@ -435,7 +435,7 @@ void hostcheck_knn_stats(const double* pts, uint64_t n, const double* queries, u
   grid_out[0] = G.g.nx, grid_out[1] = G.g.ny, grid_out[2] = G.g.nz, grid_out[3] = G.g.h;
   const double pass = knn_radius_pass_max(max_dist);
   for (uint64_t i = 0; i < nq; i++) {
-    uint32_t rows[18], pos[8];
+    uint32_t rows[kLeanRowWords], pos[8];
     g_cand = g_rows = g_general = 0;
     const Vec3 q = v3(queries[3 * i], queries[3 * i + 1], queries[3 * i + 2]);
     if (k <= 5) knn_search_keyed<5>(G.g, G.cell_start.data(), G.sp.data(), q, (int)k, max_dist, pass, pos, rows, 1);
