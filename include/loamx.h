@@ -269,7 +269,10 @@ enum {
   LOAMX_K_MOMENT = 7,    /* plane moment pass (Gram matrix of the plane coefficients), 56 B per plane slot */
   LOAMX_K_KNN_PLANE = 8, /* sub-scope of LOAMX_K_ASSOC: the round-1 k-NN kernel of the plane features alone
                             (instruction-bound: bench.py prices it against the vector-issue roofline) */
-  LOAMX_K_COUNT = 9
+  LOAMX_K_EXTRACT_FUSED = 9, /* curvature + validity + selection + compaction in one pass over the scan: 24 B/point read
+                                (12 with float input) + (4 + 24) B per feature written. LOAMX_K_CURVATURE / _SELECT count
+                                the separate kernels, which run when the parameters rule the fused one out */
+  LOAMX_K_COUNT = 10
 };
 typedef struct {
   uint64_t launches;

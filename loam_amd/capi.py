@@ -12,7 +12,7 @@ from . import build as _build
 
 OK, ERR_SCAN_SIZE, ERR_BAD_PARAM, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_COMM = range(8)
 CONVERGED, MAX_ITER, INSUFFICIENT_ASSOCIATIONS = 0, 1, 2
-K_CURVATURE, K_SELECT, K_COMPACT, K_GRID, K_ASSOC, K_SWEEP, K_LM, K_MOMENT, K_KNN_PLANE, K_COUNT = range(10)
+K_CURVATURE, K_SELECT, K_COMPACT, K_GRID, K_ASSOC, K_SWEEP, K_LM, K_MOMENT, K_KNN_PLANE, K_EXTRACT_FUSED, K_COUNT = range(11)
 
 
 class LidarParams(C.Structure):

@@ -105,27 +105,45 @@ __global__ __launch_bounds__(kCurvThreads) void curvature_valid_kernel(const T* 
 // both results with one 16-byte + one 2-byte store. Arithmetic and its order are those of curvature_at.
 constexpr int kCurvTilesPerGroup = 2;  // tiles one workgroup walks (the next tile's loads fly during this tile's arithmetic)
 
-template <int NP, typename T>
-__global__ __launch_bounds__(kCurvThreads) void curvature_valid2_kernel(const T* __restrict__ xyz, ExtractParams P,
-                                                               double* __restrict__ curv_out,
-                                                               uint8_t* __restrict__ mask_out) {
-  static_assert(kTile == 2 * kCurvThreads, "two columns per thread");
-  constexpr int np = NP, halo = NP + 1;
-  constexpr int hp = (halo + 1) & ~1;        // local index of the tile's first column: even, >= halo
-  constexpr int A = (NP + 1) & ~1;           // the pairs read start A columns before the thread's first column
-  constexpr int kPairs = (A + NP + 3) / 2;   // ... and cover li0 - A .. li0 + NP + 1
-  constexpr int kLoc = kTile + 2 * hp;
-  constexpr int kWords = (kLoc + 63) / 64 + 1;
-  constexpr int kLoads = ((kTile + 2 * halo) * 3 + kCurvThreads - 1) / kCurvThreads;  // elements per thread and tile
-  __shared__ __align__(16) double s_p[3][kLoc];
-  __shared__ double s_r[kLoc];
-  __shared__ unsigned long long s_bits[4][kWords];  // range / occlusion 1 / occlusion 2 / parallel
-  const int tid = threadIdx.x;
-  const size_t line = blockIdx.x;  // scan * H + line
-  const int W = (int)P.W;
-  const T* __restrict__ g = xyz + line * (size_t)W * 3;
-  const int t_first = (int)blockIdx.y * kCurvTilesPerGroup * kTile;
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS operations of one wavefront complete in issue order; this only stops the compiler from
+  // moving LDS accesses across the point where lanes exchange data through LDS.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
+// Tile geometry of the two-columns-per-thread form, shared by curvature_valid2_kernel and extract_fused_kernel.
+template <int NP, int THREADS = kCurvThreads>
+struct Curv2 {
+  static constexpr int kThreads = THREADS, kTileC = 2 * THREADS;  // two adjacent columns per thread
+  static constexpr int np = NP, halo = NP + 1;
+  static constexpr int hp = (halo + 1) & ~1;        // local index of the tile's first column: even, >= halo
+  static constexpr int A = (NP + 1) & ~1;           // the pairs read start A columns before the thread's first column
+  static constexpr int kPairs = (A + NP + 3) / 2;   // ... and cover li0 - A .. li0 + NP + 1
+  static constexpr int kLoc = kTileC + 2 * hp;
+  static constexpr int kWords = (kLoc + 63) / 64 + 1;
+  static constexpr int kLoads = ((kTileC + 2 * halo) * 3 + THREADS - 1) / THREADS;  // elements per thread and tile
+  static constexpr size_t kLdsBytes = sizeof(double) * 4 * kLoc + sizeof(unsigned long long) * 4 * kWords;
+};
+
+// Walks n_tiles consecutive tiles of one scan line (THREADS threads together: a workgroup with barriers, or — THREADS = 64 —
+// one wavefront on its own with wavefront-level ordering only, `tid` then being the lane) and
+// hands every thread its two results: sink(c0, cv[2], ok[2]) for the columns c0, c0 + 1 (c0 < W; c0 + 1 may be == W).
+// s_p / s_r / s_bits: Curv2<NP>::kLoc doubles x 3, kLoc doubles, kWords words x 4 of LDS.
+template <int NP, int THREADS, typename T, typename Sink>
+__device__ __forceinline__ void curvature_line_tiles(const T* __restrict__ g, const ExtractParams& P, int t_first, int n_tiles,
+                                                     double (*s_p)[Curv2<NP, THREADS>::kLoc], double* s_r,
+                                                     unsigned long long (*s_bits)[Curv2<NP, THREADS>::kWords], Sink sink) {
+  using G = Curv2<NP, THREADS>;
+  constexpr int np = NP, halo = G::halo, hp = G::hp, A = G::A, kPairs = G::kPairs, kWords = G::kWords, kLoads = G::kLoads;
+  constexpr int kCurvThreads = THREADS, kTile = G::kTileC;  // (shadow the workgroup-wide constants)
+  auto barrier = [] {
+    if constexpr (THREADS == 64) wave_lds_sync();
+    else __syncthreads();
+  };
+  const int tid = threadIdx.x % THREADS;
+  const int W = (int)P.W;
   // the tile (+halo) as registers: element k of the row-major points, coalesced 8-byte loads (16-byte loads of
   // element pairs were measured slower: 1.03 vs 0.95 ms — the pair straddles two coordinate arrays)
   T regs[kLoads];
@@ -141,7 +159,7 @@ __global__ __launch_bounds__(kCurvThreads) void curvature_valid2_kernel(const T*
   };
   fetch(t_first);
 #pragma unroll 1
-  for (int tt = 0; tt < kCurvTilesPerGroup; tt++) {
+  for (int tt = 0; tt < n_tiles; tt++) {
     const int t0 = t_first + tt * kTile;
     if (t0 >= W) break;  // uniform
     const int base = t0 - hp;  // column of local index 0
@@ -158,13 +176,13 @@ __global__ __launch_bounds__(kCurvThreads) void curvature_valid2_kernel(const T*
         }
       }
     }
-    __syncthreads();
-    if (tt + 1 < kCurvTilesPerGroup && t0 + kTile < W) fetch(t0 + kTile);  // in flight until the next trip
+    barrier();
+    if (tt + 1 < n_tiles && t0 + kTile < W) fetch(t0 + kTile);  // in flight until the next trip
     for (int c = lo + tid; c < hi; c += kCurvThreads) {
       const int li = c - base;
       s_r[li] = point_range(s_p[0][li], s_p[1][li], s_p[2][li]);
     }
-    __syncthreads();
+    barrier();
     {
       const int clo = t0 - np > 0 ? t0 - np : 0;
       const int chi = t0 + kTile + np < W ? t0 + kTile + np : W;
@@ -178,7 +196,7 @@ __global__ __launch_bounds__(kCurvThreads) void curvature_valid2_kernel(const T*
         if ((tid & 63) == 0 && w < kWords) s_bits[0][w] = b1, s_bits[1][w] = b2, s_bits[2][w] = b3, s_bits[3][w] = b4;
       }
     }
-    __syncthreads();
+    barrier();
     const int c0 = t0 + 2 * tid, li0 = hp + 2 * tid;
     if (c0 < W) {
       double d[2][3];
@@ -209,26 +227,36 @@ __global__ __launch_bounds__(kCurvThreads) void curvature_valid2_kernel(const T*
         ok[col] = !end && !code_window(s_bits[0], li - np, 2 * np + 1) && !code_window(s_bits[1], li - np, np) &&
                   !code_window(s_bits[2], li, np) && !code_window(s_bits[3], li, 1);
       }
-      const size_t o = line * (size_t)W + c0;
-      if (c0 + 1 < W && (W & 1) == 0) {  // both columns, aligned
-        *reinterpret_cast<double2*>(curv_out + o) = make_double2(cv[0], cv[1]);
-        *reinterpret_cast<uint16_t*>(mask_out + o) = (uint16_t)((ok[0] ? 1u : 0u) | (ok[1] ? 0x100u : 0u));
-      } else {
-        curv_out[o] = cv[0], mask_out[o] = ok[0] ? 1 : 0;
-        if (c0 + 1 < W) curv_out[o + 1] = cv[1], mask_out[o + 1] = ok[1] ? 1 : 0;
-      }
+      sink(c0, cv, ok);
     }
-    __syncthreads();  // the arrays are rewritten by the next trip
+    barrier();  // the arrays are rewritten by the next trip
   }
 }
 
-__device__ __forceinline__ void wave_lds_sync() {
-  // LDS operations of one wavefront complete in issue order; this only stops the compiler from
-  // moving LDS accesses across the point where lanes exchange data through LDS.
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+template <int NP, typename T>
+__global__ __launch_bounds__(kCurvThreads) void curvature_valid2_kernel(const T* __restrict__ xyz, ExtractParams P,
+                                                               double* __restrict__ curv_out,
+                                                               uint8_t* __restrict__ mask_out) {
+  using G = Curv2<NP>;
+  __shared__ __align__(16) double s_p[3][G::kLoc];
+  __shared__ double s_r[G::kLoc];
+  __shared__ unsigned long long s_bits[4][G::kWords];  // range / occlusion 1 / occlusion 2 / parallel
+  const size_t line = blockIdx.x;  // scan * H + line
+  const int W = (int)P.W;
+  const T* __restrict__ g = xyz + line * (size_t)W * 3;
+  curvature_line_tiles<NP, kCurvThreads, T>(g, P, (int)blockIdx.y * kCurvTilesPerGroup * kTile, kCurvTilesPerGroup, s_p, s_r, s_bits,
+                              [&](int c0, const double cv[2], const bool ok[2]) {
+                                const size_t o = line * (size_t)W + c0;
+                                if (c0 + 1 < W && (W & 1) == 0) {  // both columns, aligned
+                                  *reinterpret_cast<double2*>(curv_out + o) = make_double2(cv[0], cv[1]);
+                                  *reinterpret_cast<uint16_t*>(mask_out + o) = (uint16_t)((ok[0] ? 1u : 0u) | (ok[1] ? 0x100u : 0u));
+                                } else {
+                                  curv_out[o] = cv[0], mask_out[o] = ok[0] ? 1 : 0;
+                                  if (c0 + 1 < W) curv_out[o + 1] = cv[1], mask_out[o + 1] = ok[1] ? 1 : 0;
+                                }
+                              });
 }
+
 
 // LDS bytes of replay_kernel's wavefront: curvature, mask, and the 16-bit index array that is sorted
 __host__ __device__ inline size_t replay_lds_bytes(int W) { return (size_t)W * 8 + (((size_t)W + 7) & ~(size_t)7) + (((size_t)W * 2 + 7) & ~(size_t)7); }
@@ -653,32 +681,14 @@ __device__ __forceinline__ void fused_copy(const T* __restrict__ scan_xyz, uint3
   dst[0] = (double)scan_xyz[3 * (size_t)idx], dst[1] = (double)scan_xyz[3 * (size_t)idx + 1], dst[2] = (double)scan_xyz[3 * (size_t)idx + 2];
 }
 
-template <int R, int WAVES, bool TWO>
-__global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __restrict__ curv,
-                                                                const uint8_t* __restrict__ mask, size_t n_lines,
-                                                                ExtractParams P, ExtractStage st, ExtractFused fz) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const size_t line = (size_t)blockIdx.x * WAVES + wave;
-  if (line >= n_lines) return;  // whole wavefront leaves; no workgroup barrier below
-  const int W = (int)P.W, CH = (W + 63) / 64, base = lane * CH;
-  // LDS layout: every lane's chunk of CH points is followed by one spare double (4 spare bytes in
-  // the mask): with the chunk stride CH (16 for W = 1024) the lanes of a wavefront would all read the
-  // same LDS bank when each walks its own chunk; CH + 1 spreads them over all banks.
+// Selection + fused compaction of ONE scan line by one wavefront, from the line's curvature / mask in the padded LDS
+// arrays s_c / s_v (select_mis_kernel stages them from global memory, extract_fused_kernel computes them in place).
+// Returns true iff the line was marked as tied (replay_kernel redoes it and needs its curvature / mask in global memory).
+template <int R, bool TWO>
+__device__ __forceinline__ bool select_line(int lane, size_t line, int W, int CH, uint32_t ch_magic, double* s_c, double* m_c, int32_t* m_i,
+                                            uint8_t* s_v, const ExtractParams& P, const ExtractStage& st, const ExtractFused& fz) {
   constexpr int slots = TWO ? 128 : 64;
-  const size_t per_wave = select_mis_lds_bytes(W, slots);
-  double* s_c = reinterpret_cast<double*>(smem + wave * per_wave);
-  double* m_c = s_c + W + 64;
-  int32_t* m_i = reinterpret_cast<int32_t*>(m_c + slots);
-  uint8_t* s_v = reinterpret_cast<uint8_t*>(m_i + slots);
-  // i / CH == umulhi(i, ch_magic) for i < 2^16 when CH >= 2; ch_magic == 0 stands for CH == 1 (i / CH == i)
-  const uint32_t ch_magic = CH > 1 ? 0xFFFFFFFFu / (uint32_t)CH + 1u : 0u;
-  for (int i = lane; i < W; i += 64) {
-    const int owner = ch_magic ? (int)__umulhi((uint32_t)i, ch_magic) : i;
-    s_c[i + owner] = curv[line * (size_t)W + i];
-    s_v[i + 4 * owner] = mask[line * (size_t)W + i];
-  }
-  wave_lds_sync();
+  const int base = lane * CH;
   const int pbase = lane * (CH + 1), vbase = lane * (CH + 4);
   uint64_t V = 0, ET = 0, PT = 0, gt[R], eqm[R];
   for (int j = 0; j < CH; j++) {
@@ -742,9 +752,9 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
       __hip_atomic_store(fz.line_tot + line, kLinePublished | kLineTied, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       atomicOr(fz.error, kFlagTie | kFlagGaveUp);
     }
-    return;
+    return true;
   }
-  if (!fz.fuse) return;  // uniform
+  if (!fz.fuse) return false;  // uniform
   // ---- fused compaction -----------------------------------------------------------------------------
   const uint32_t li = (uint32_t)(line % P.H);
   const size_t scan = line / P.H;
@@ -820,7 +830,7 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
         // this line's features stay in the stage arrays (complete, as always): compact_fallback_kernel, launched
         // right behind this kernel, sees the flag and gathers the whole batch from them
         if (lane == 0) atomicOr(fz.error, kFlagGaveUp);
-        return;
+        return false;
       }
     }
 #pragma unroll
@@ -837,7 +847,96 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
       }
     }
   }
-  if (li == P.H - 1 && lane == 0) fz.n_edge[scan] = base_e + E_l, fz.n_planar[scan] = base_p + P_l;
+  if (li == P.H - 1 && lane == 0) {
+    fz.n_edge[scan] = base_e + E_l, fz.n_planar[scan] = base_p + P_l;
+    if (fz.events) atomicAdd(&fz.events[2], (unsigned long long)(base_e + E_l + base_p + P_l));  // (roofline bytes of the fused kernel)
+  }
+  return false;
+}
+
+template <int R, int WAVES, bool TWO>
+__global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __restrict__ curv,
+                                                                const uint8_t* __restrict__ mask, size_t n_lines,
+                                                                ExtractParams P, ExtractStage st, ExtractFused fz) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t line = (size_t)blockIdx.x * WAVES + wave;
+  if (line >= n_lines) return;  // whole wavefront leaves; no workgroup barrier below
+  const int W = (int)P.W, CH = (W + 63) / 64;
+  // LDS layout: every lane's chunk of CH points is followed by one spare double (4 spare bytes in
+  // the mask): with the chunk stride CH (16 for W = 1024) the lanes of a wavefront would all read the
+  // same LDS bank when each walks its own chunk; CH + 1 spreads them over all banks.
+  constexpr int slots = TWO ? 128 : 64;
+  const size_t per_wave = select_mis_lds_bytes(W, slots);
+  double* s_c = reinterpret_cast<double*>(smem + wave * per_wave);
+  double* m_c = s_c + W + 64;
+  int32_t* m_i = reinterpret_cast<int32_t*>(m_c + slots);
+  uint8_t* s_v = reinterpret_cast<uint8_t*>(m_i + slots);
+  // i / CH == umulhi(i, ch_magic) for i < 2^16 when CH >= 2; ch_magic == 0 stands for CH == 1 (i / CH == i)
+  const uint32_t ch_magic = CH > 1 ? 0xFFFFFFFFu / (uint32_t)CH + 1u : 0u;
+  for (int i = lane; i < W; i += 64) {
+    const int owner = ch_magic ? (int)__umulhi((uint32_t)i, ch_magic) : i;
+    s_c[i + owner] = curv[line * (size_t)W + i];
+    s_v[i + 4 * owner] = mask[line * (size_t)W + i];
+  }
+  wave_lds_sync();
+  (void)select_line<R, TWO>(lane, line, W, CH, ch_magic, s_c, m_c, m_i, s_v, P, st, fz);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * extract_fused_kernel — rows a5-a10 in ONE pass over the scan (round 2): curvature + validity, selection and
+ * compaction without the 9 B/point of curvature / mask ever reaching HBM.
+ * One wavefront (a workgroup of its own: no barriers) owns a scan line. Phase 1: the tile loop of
+ * curvature_valid2_kernel in its one-wavefront form (128-column tiles: coalesced loads -> coordinate planes in LDS ->
+ * ranges -> invalidation flag words -> two columns per lane), with the results stored into the padded selection
+ * arrays in LDS instead of global memory. Phase 2: select_line (bitmask MIS, keyed bitonic sort, chained scan over
+ * the lines of the scan, indices + point copies to their final places). (First built with four lines per workgroup
+ * and the 512-column tiles behind workgroup barriers: 60 KB of LDS, two workgroups per CU, 3.29 ms vs 2.80 ms for
+ * the separate kernels.) A line on which a curvature tie
+ * can decide something writes its curvature / mask to the workspace for replay_kernel.
+ * HBM per scan: 24 B/point read once + the picked points again (mostly L2 / MALL hits: the workgroup read them
+ * microseconds ago) + (4 + 24) B per feature written; before: 24 + 9 written + 9 read + the gather's re-read.
+ * ---------------------------------------------------------------------------------------------- */
+template <int NP, int R, typename T>
+__global__ __launch_bounds__(64) void extract_fused_kernel(const T* __restrict__ xyz, size_t n_lines, ExtractParams P, ExtractStage st,
+                                                           ExtractFused fz, double* __restrict__ curv_ws, uint8_t* __restrict__ mask_ws) {
+  using G = Curv2<NP, 64>;  // tiles of 128 columns, two per lane
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const size_t line = blockIdx.x;  // one wavefront per workgroup: nothing is shared, nobody waits at a barrier
+  const int W = (int)P.W, CH = (W + 63) / 64;
+  const uint32_t ch_magic = CH > 1 ? 0xFFFFFFFFu / (uint32_t)CH + 1u : 0u;
+  double(*s_p)[G::kLoc] = reinterpret_cast<double(*)[G::kLoc]>(smem);
+  double* s_r = reinterpret_cast<double*>(smem) + 3 * G::kLoc;
+  unsigned long long(*s_bits)[G::kWords] = reinterpret_cast<unsigned long long(*)[G::kWords]>(s_r + G::kLoc);
+  double* s_c = reinterpret_cast<double*>(smem + ((G::kLdsBytes + 15) & ~(size_t)15));
+  double* m_c = s_c + W + 64;
+  int32_t* m_i = reinterpret_cast<int32_t*>(m_c + 64);
+  uint8_t* s_v = reinterpret_cast<uint8_t*>(m_i + 64);
+  // ---- phase 1: curvature + validity of the line into the selection arrays
+  curvature_line_tiles<NP, 64, T>(xyz + line * (size_t)W * 3, P, 0, (W + G::kTileC - 1) / G::kTileC, s_p, s_r, s_bits,
+                                  [&](int c0, const double cv[2], const bool ok[2]) {
+#pragma unroll
+                                    for (int col = 0; col < 2; col++) {
+                                      const int i = c0 + col;
+                                      if (i < W) {
+                                        const int owner = ch_magic ? (int)__umulhi((uint32_t)i, ch_magic) : i;
+                                        s_c[i + owner] = cv[col];
+                                        s_v[i + 4 * owner] = ok[col] ? 1 : 0;
+                                      }
+                                    }
+                                  });
+  wave_lds_sync();
+  // ---- phase 2: selection + compaction
+  if (select_line<R, false>(lane, line, W, CH, ch_magic, s_c, m_c, m_i, s_v, P, st, fz)) {
+    // tied: replay_kernel reads the line's curvature and (unselected) mask from the workspace. The mask bytes in LDS
+    // are still the input's: the selection works on register bit masks.
+    for (int i = lane; i < W; i += 64) {
+      const int owner = ch_magic ? (int)__umulhi((uint32_t)i, ch_magic) : i;
+      curv_ws[line * (size_t)W + i] = s_c[i + owner];
+      mask_ws[line * (size_t)W + i] = s_v[i + 4 * owner];
+    }
+  }
 }
 
 // block-wide exclusive scan of one value per thread (256 threads); returns the exclusive prefix and
@@ -1024,6 +1123,32 @@ bool launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, 
                        st, fz.line_tot, fz.error);
   }
   return false;
+}
+
+// The fused path can run when the selection's fast path does (launch_select: mis_ok, one pick per lane), the compaction
+// can be fused (number_sectors <= 64) and neighbor_points is the compiled-in default.
+bool launch_extract_fused(const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, const ExtractStage& st,
+                          const ExtractFused& fz_in, double* d_curv, uint8_t* d_mask, hipStream_t s) {
+  const size_t n_lines = n_scans * P.H;
+  // Opt-in (LOAMX_FUSED_EXTRACT=1): measured on 2 048 scans of 64 x 1024, the fused kernel moves 7.9 GB instead of the
+  // 10.3 GB of the two kernels (PMC FETCH_SIZE x 2 + WRITE_SIZE; 4.2 GB are algorithmic) but takes 2.92 ms against their
+  // 0.94 + 1.86 ms: both phases are instruction-bound, so fusing them saves traffic, not time, and the gather of the
+  // picked points still re-reads most of the scan (their lines have left the L2 by the time the selection is done).
+  if (n_lines == 0 || P.W == 0 || !getenv("LOAMX_FUSED_EXTRACT") || getenv("LOAMX_NO_FUSED_COMPACT") || getenv("LOAMX_NO_MIS_SELECT")) return false;
+  const int R = (int)P.np - 1, CH = ((int)P.W + 63) / 64;
+  const uint32_t longest = P.W - (P.S - 1) * P.pps;
+  const uint32_t picks = (longest + R) / (R + 1);
+  if (P.np != 3 || !(CH >= R && CH + 2 * R <= 64) || picks > 64 || P.S > 64 || !fz_in.line_tot || (P.W & 1)) return false;
+  const size_t lds = ((Curv2<3, 64>::kLdsBytes + 15) & ~(size_t)15) + select_mis_lds_bytes((int)P.W, 64);
+  if (lds > 64 * 1024) return false;  // (wider lines: the separate kernels)
+  ExtractFused fz = fz_in;
+  fz.fuse = 1u;
+  const dim3 grid((unsigned)n_lines);
+  if (f32)
+    launch_kernel((extract_fused_kernel<3, 2, float>), grid, dim3(64), lds, s, static_cast<const float*>(d_xyz), n_lines, P, st, fz, d_curv, d_mask);
+  else
+    launch_kernel((extract_fused_kernel<3, 2, double>), grid, dim3(64), lds, s, static_cast<const double*>(d_xyz), n_lines, P, st, fz, d_curv, d_mask);
+  return true;
 }
 
 void launch_replay(const double* d_curv, const uint8_t* d_mask, size_t n_scans, const ExtractParams& P, const ExtractStage& st,

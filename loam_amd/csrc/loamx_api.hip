@@ -59,7 +59,9 @@ struct loamx_ctx {
   hipEvent_t tail_event = nullptr;  // end event of the last timed scope ...
   bool tail_fresh = false;          // ... and nothing has been enqueued on the stream since
   loamx_kernel_stat stats[LOAMX_K_COUNT] = {};
+
   unsigned long long sweep_slots_base[2] = {0, 0};
+  unsigned long long features_base = 0;  // events[2] at the last loamx_ctx_reset_kernel_stats
   std::mutex mu;
 };
 
@@ -87,7 +89,8 @@ namespace {
 
 const char* kKernelNames[LOAMX_K_COUNT] = {"curvature_valid_kernel", "select_kernel", "compact_kernel",
                                            "grid_build_kernel",      "associate_kernel", "sweep_kernel",
-                                           "lm_kernels",             "moment_kernel",    "knn_plane_kernel"};
+                                           "lm_kernels",             "moment_kernel",    "knn_plane_kernel",
+                                           "extract_fused_kernel"};
 
 int fail(loamx_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->last_error = msg;
@@ -234,6 +237,7 @@ int make_reg_config(loamx_ctx* ctx, const loamx_reg_params* r, RegConfig& C) {
   if (r->min_line_fit_points < 2 && r->num_edge_neighbors > 0)
     return fail(ctx, LOAMX_ERR_BAD_PARAM, "min_line_fit_points must be >= 2");
   if (r->max_iterations > 1000) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "max_iterations > 1000");
+  memset(&C, 0, sizeof(C));
   C.k_edge = (int)r->num_edge_neighbors, C.k_plane = (int)r->num_plane_neighbors;
   C.min_line_pts = (int)(r->min_line_fit_points > 64 ? 64 : r->min_line_fit_points);
   C.min_plane_pts = (int)(r->min_plane_fit_points > 64 ? 64 : r->min_plane_fit_points);
@@ -267,12 +271,14 @@ int extract_dev(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_scans, con
   }
   ENSURE(ctx, WS_CURV, n_scans * N * sizeof(double));
   ENSURE(ctx, WS_MASK, n_scans * N);
-  {
-    TimedScope t(ctx, LOAMX_K_CURVATURE, (double)n_scans * (double)N * (f32 ? 21.0 : 33.0), true);
-    launch_curvature_valid(d_xyz, f32, n_scans, P, wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), ctx->stream);
+  if (only_curvature_mask) {  // loamx_compute_curvature / loamx_compute_valid_points: the standalone kernel
+    {
+      TimedScope t(ctx, LOAMX_K_CURVATURE, (double)n_scans * (double)N * (f32 ? 21.0 : 33.0), true);
+      launch_curvature_valid(d_xyz, f32, n_scans, P, wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), ctx->stream);
+    }
+    CHECK_LAUNCH(ctx, "curvature_valid_kernel");
+    return LOAMX_OK;
   }
-  CHECK_LAUNCH(ctx, "curvature_valid_kernel");
-  if (only_curvature_mask) return LOAMX_OK;
   const size_t groups = n_scans * P.H * P.S;
   ENSURE(ctx, WS_EDGE_STAGE, groups * P.cap_edge * sizeof(uint32_t));
   ENSURE(ctx, WS_PLANAR_STAGE, groups * P.cap_planar * sizeof(uint32_t));
@@ -287,9 +293,9 @@ int extract_dev(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_scans, con
   ENSURE(ctx, WS_LINE_TOT, (n_lines + 1) * sizeof(unsigned long long));
   {
     const bool fresh = ctx->ws[WS_EXTRACT_EVENTS].cap == 0;  // cumulative counters: zeroed once
-    ENSURE(ctx, WS_EXTRACT_EVENTS, 2 * sizeof(unsigned long long));
+    ENSURE(ctx, WS_EXTRACT_EVENTS, 4 * sizeof(unsigned long long));
     untimed(ctx);
-    if (fresh) HIP_TRY(ctx, hipMemsetAsync(ctx->ws[WS_EXTRACT_EVENTS].p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    if (fresh) HIP_TRY(ctx, hipMemsetAsync(ctx->ws[WS_EXTRACT_EVENTS].p, 0, 4 * sizeof(unsigned long long), ctx->stream));
   }
   untimed(ctx);
   HIP_TRY(ctx, hipMemsetAsync(ctx->ws[WS_LINE_TOT].p, 0, (n_lines + 1) * sizeof(unsigned long long), ctx->stream));
@@ -297,6 +303,22 @@ int extract_dev(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_scans, con
   unsigned long long* d_events = wsp<unsigned long long>(ctx, WS_EXTRACT_EVENTS);
   const ExtractFused fz{wsp<unsigned long long>(ctx, WS_LINE_TOT), 0u, d_xyz, f32 ? 1u : 0u, d_edge_idx, d_n_edge, d_edge_xyz,
                         edge_capacity(P), d_planar_idx, d_n_planar, d_planar_xyz, planar_capacity(P), d_gave_up, d_events};
+  {
+    // rows a5-a10 in one pass over the scan when the parameters allow (the reference's defaults do): 24 B/point read +
+    // (4 + 24) B per feature written; the features are counted on the device (events[2]) for the roofline figure
+    TimedScope t(ctx, LOAMX_K_EXTRACT_FUSED, (double)n_scans * (double)N * (f32 ? 12.0 : 24.0), true);
+    if (launch_extract_fused(d_xyz, f32, n_scans, P, st, fz, wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), ctx->stream)) {
+      launch_replay(wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), n_scans, P, st, fz, ctx->stream);
+      launch_compact(d_xyz, f32, n_scans, P, st, d_edge_idx, d_n_edge, d_edge_xyz, edge_capacity(P), d_planar_idx, d_n_planar,
+                     d_planar_xyz, planar_capacity(P), ctx->stream, d_gave_up, d_events + 1);
+      return check_launch(ctx, "extract_fused_kernel");
+    }
+  }
+  {
+    TimedScope t(ctx, LOAMX_K_CURVATURE, (double)n_scans * (double)N * (f32 ? 21.0 : 33.0), true);
+    launch_curvature_valid(d_xyz, f32, n_scans, P, wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), ctx->stream);
+  }
+  CHECK_LAUNCH(ctx, "curvature_valid_kernel");
   bool fused = false;
   {
     TimedScope t(ctx, LOAMX_K_SELECT, (double)n_scans * (double)N * 9.0, true);
@@ -332,6 +354,70 @@ struct RegInputs {
 
 // host-side hook called after the association kernels of iteration `it` (detail capture)
 typedef int (*AfterAssocHook)(loamx_ctx*, const RegBatch&, uint32_t it, void* user);
+
+// the launch sequence of one ICF iteration on ctx->stream (+ the auxiliary streams); `it` only selects between the
+// first iteration's sequence (no moment pass) and the later ones'
+int enqueue_icf_iteration(loamx_ctx* ctx, const RegBatch& B, const RegConfig& C, uint32_t it, AfterAssocHook hook, void* hook_user) {
+  hipStream_t s = ctx->stream;
+    {
+      TimedScope t(ctx, LOAMX_K_ASSOC, 0.0);
+      // (a single scan-sized pair cannot fill the chip twice over: the forks and joins only add latency there —
+      // one 64 x 1024 pair 1.15 ms with the auxiliary streams, 1.10 ms without; one 128 x 2048 scan against a
+      // 1 M-point map the other way round: 5.9 vs 6.8 ms)
+      const bool side = (size_t)B.n_pairs * B.assoc_blocks_plane >= 128;
+      // sub-scope: the plane round-1 k-NN kernel alone (events attached to its own dispatch)
+      PendingEvent knn{};
+      LaunchScope knn_ls{nullptr, nullptr, true};
+      if (ctx->timing) {
+        knn.kernel = LOAMX_K_KNN_PLANE, knn.bytes = 0.0, knn.own_e0 = true;
+        knn.e0 = take_event(ctx), knn.e1 = take_event(ctx);
+        knn_ls = LaunchScope{knn.e0, knn.e1, true};
+      }
+      launch_associate(B, C, s, side ? ctx->aux_stream : nullptr, side ? ctx->aux2_stream : nullptr, ctx->ev_fork, ctx->ev_mid, ctx->ev_join,
+                       ctx->ev_join2, ctx->timing ? &knn_ls : nullptr);
+      if (ctx->timing) {
+        if (knn_ls.first) ctx->event_pool.push_back(knn.e0), ctx->event_pool.push_back(knn.e1);  // (kernel not launched)
+        else ctx->pending.push_back(knn);
+      }
+    }
+    CHECK_LAUNCH(ctx, "associate_kernel");
+#ifdef LOAMX_NN_SAME_STATS
+    debug_nn_same(B, it, s);
+#endif
+    if (hook) {
+      untimed(ctx);
+      int rc = hook(ctx, B, it, hook_user);
+      if (rc != LOAMX_OK) return rc;
+    }
+    {
+      TimedScope t(ctx, LOAMX_K_LM, 0.0, true);
+      launch_lm_begin(B, C, s);
+    }
+    if (it > 0) {  // the first ICF iteration streams its records (state_init: stream_planes = 1, use_moments = 0)
+      TimedScope t(ctx, LOAMX_K_MOMENT, 0.0, true);
+      launch_moments(B, s);
+    }
+    for (int k = 0; k < 5; k++) {  // iteration-0 evaluation + max_num_iterations = 4 candidates
+      {
+        TimedScope t(ctx, LOAMX_K_SWEEP, 0.0, true);
+        launch_sweep(B, s);
+      }
+      {
+        TimedScope t(ctx, LOAMX_K_LM, 0.0, true);
+        if (it > 0) launch_sweep_light(B, s);  // (no pair is on moments in the first ICF iteration)
+        launch_lm_step(B, s);
+      }
+    }
+    CHECK_LAUNCH(ctx, "sweep/lm kernels");
+    untimed(ctx);
+    HIP_TRY(ctx, hipMemsetAsync(B.n_active, 0, sizeof(uint32_t), s));
+    {
+      TimedScope t(ctx, LOAMX_K_LM, 0.0, true);
+      launch_outer_update(B, C, s);
+    }
+    CHECK_LAUNCH(ctx, "outer_update_kernel");
+  return LOAMX_OK;
+}
 
 int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_reg_result* d_results, bool want_iter_info,
                  AfterAssocHook hook, void* hook_user, const loamx_target_index* prebuilt = nullptr) {
@@ -465,64 +551,14 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
     uint32_t* mode[2] = {&B.knn_mode_edge, &B.knn_mode_plane};
     for (int k = 0; k < 2; k++) *mode[k] = tmin[k] > tmax[k] ? 0u : (tmin[k] > kBruteMax ? 1u : (tmax[k] <= kBruteMax ? 2u : 0u));
   }
+  // (Replaying an ICF iteration as a hipGraph was measured in round 2 — captured once, cached, ~110 kernel nodes over
+  // three streams: 13.6 vs 13.1 ms per 1 024-pair step and 1.06 vs 1.07 ms for one pair. The GPU-side turnaround of
+  // dependent kernels bounds both, not the host's launch rate, and the graph loses the stream priorities; removed.)
   for (uint32_t it = 0; it < C.max_iterations; it++) {
     {
-      TimedScope t(ctx, LOAMX_K_ASSOC, 0.0);
-      // (a single scan-sized pair cannot fill the chip twice over: the forks and joins only add latency there —
-      // one 64 x 1024 pair 1.15 ms with the auxiliary streams, 1.10 ms without; one 128 x 2048 scan against a
-      // 1 M-point map the other way round: 5.9 vs 6.8 ms)
-      const bool side = (size_t)B.n_pairs * B.assoc_blocks_plane >= 128;
-      // sub-scope: the plane round-1 k-NN kernel alone (events attached to its own dispatch)
-      PendingEvent knn{};
-      LaunchScope knn_ls{nullptr, nullptr, true};
-      if (ctx->timing) {
-        knn.kernel = LOAMX_K_KNN_PLANE, knn.bytes = 0.0, knn.own_e0 = true;
-        knn.e0 = take_event(ctx), knn.e1 = take_event(ctx);
-        knn_ls = LaunchScope{knn.e0, knn.e1, true};
-      }
-      launch_associate(B, C, s, side ? ctx->aux_stream : nullptr, side ? ctx->aux2_stream : nullptr, ctx->ev_fork, ctx->ev_mid, ctx->ev_join,
-                       ctx->ev_join2, ctx->timing ? &knn_ls : nullptr);
-      if (ctx->timing) {
-        if (knn_ls.first) ctx->event_pool.push_back(knn.e0), ctx->event_pool.push_back(knn.e1);  // (kernel not launched)
-        else ctx->pending.push_back(knn);
-      }
+      const int rc_body = enqueue_icf_iteration(ctx, B, C, it, hook, hook_user);
+      if (rc_body != LOAMX_OK) return rc_body;
     }
-    CHECK_LAUNCH(ctx, "associate_kernel");
-#ifdef LOAMX_NN_SAME_STATS
-    debug_nn_same(B, it, s);
-#endif
-    if (hook) {
-      untimed(ctx);
-      int rc = hook(ctx, B, it, hook_user);
-      if (rc != LOAMX_OK) return rc;
-    }
-    {
-      TimedScope t(ctx, LOAMX_K_LM, 0.0, true);
-      launch_lm_begin(B, C, it, s);
-    }
-    if (it > 0) {  // the first ICF iteration streams its records (state_init: stream_planes = 1, use_moments = 0)
-      TimedScope t(ctx, LOAMX_K_MOMENT, 0.0, true);
-      launch_moments(B, s);
-    }
-    for (int k = 0; k < 5; k++) {  // iteration-0 evaluation + max_num_iterations = 4 candidates
-      {
-        TimedScope t(ctx, LOAMX_K_SWEEP, 0.0, true);
-        launch_sweep(B, s);
-      }
-      {
-        TimedScope t(ctx, LOAMX_K_LM, 0.0, true);
-        if (it > 0) launch_sweep_light(B, s);  // (no pair is on moments in the first ICF iteration)
-        launch_lm_step(B, s);
-      }
-    }
-    CHECK_LAUNCH(ctx, "sweep/lm kernels");
-    untimed(ctx);
-    HIP_TRY(ctx, hipMemsetAsync(B.n_active, 0, sizeof(uint32_t), s));
-    {
-      TimedScope t(ctx, LOAMX_K_LM, 0.0, true);
-      launch_outer_update(B, C, it, s);
-    }
-    CHECK_LAUNCH(ctx, "outer_update_kernel");
     if (it + 1 < C.max_iterations && it > 0) {
       // one 4-byte readback per outer iteration: stop as soon as every pair has terminated. Not after the first
       // iteration: a registration that starts more than the convergence thresholds away from its answer cannot
@@ -1176,6 +1212,11 @@ int loamx_ctx_reset_kernel_stats(loamx_ctx* ctx) {
   memset(ctx->stats, 0, sizeof(ctx->stats));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->ws[WS_COUNTERS].p) HIP_TRY(ctx, hipMemset(wsp<unsigned char>(ctx, WS_COUNTERS) + 8, 0, 40));
+  if (ctx->ws[WS_EXTRACT_EVENTS].p) {
+    unsigned long long ev[4] = {0, 0, 0, 0};
+    HIP_TRY(ctx, hipMemcpy(ev, ctx->ws[WS_EXTRACT_EVENTS].p, sizeof(ev), hipMemcpyDeviceToHost));
+    ctx->features_base = ev[2];
+  }
   return LOAMX_OK;
 }
 
@@ -1195,6 +1236,11 @@ int loamx_ctx_get_kernel_stats(loamx_ctx* ctx, loamx_kernel_stat* stats) {
   // associate: read the 24 B source point, write the record + the 4 B nearest index
   stats[LOAMX_K_ASSOC].algorithmic_bytes = 100.0 * (double)slots[2] + 84.0 * (double)slots[3];
   stats[LOAMX_K_MOMENT].algorithmic_bytes = 56.0 * (double)slots[4];  // moment pass: every plane record once
+  if (ctx->ws[WS_EXTRACT_EVENTS].p) {  // fused extraction: + (4 + 24) B per feature written (counted by the kernel since the reset)
+    unsigned long long ev[4] = {0, 0, 0, 0};
+    HIP_TRY(ctx, hipMemcpy(ev, ctx->ws[WS_EXTRACT_EVENTS].p, sizeof(ev), hipMemcpyDeviceToHost));
+    stats[LOAMX_K_EXTRACT_FUSED].algorithmic_bytes += 28.0 * (double)(ev[2] - ctx->features_base);
+  }
   return LOAMX_OK;
 }
 

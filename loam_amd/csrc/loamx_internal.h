@@ -71,7 +71,7 @@ struct ExtractFused {
   uint32_t* error;  // flag word (zeroed before every launch, next to line_tot). Bit 0: a wavefront gave up waiting for the
                     // lines before it (or they are tied): the fallback compaction gathers the batch from the stage arrays;
                     // bit 1: some line is tied (replay_kernel has work)
-  unsigned long long* events;  // [2] cumulative: scan lines replayed in the reference's tie order, give-up fallbacks taken
+  unsigned long long* events;  // [3] cumulative: scan lines replayed in the reference's tie order, give-up fallbacks taken, features written by the fused path
 };
 
 void launch_curvature_valid(const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, double* d_curv,
@@ -81,6 +81,9 @@ void launch_curvature_valid(const void* d_xyz, bool f32, size_t n_scans, const E
 bool launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, const ExtractParams& P,
                    const ExtractStage& st, const ExtractFused* fz, hipStream_t s);
 // edge_stride / planar_stride: entries per scan in the output arrays
+// rows a5-a10 in one kernel (extract_fused_kernel); false: not applicable to these parameters, nothing was launched
+bool launch_extract_fused(const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, const ExtractStage& st,
+                          const ExtractFused& fz, double* d_curv, uint8_t* d_mask, hipStream_t s);
 // the tie path: scan lines the selection kernel marked are redone in the reference's std::sort order (stage + counts)
 void launch_replay(const double* d_curv, const uint8_t* d_mask, size_t n_scans, const ExtractParams& P, const ExtractStage& st,
                    const ExtractFused& fz, hipStream_t s);
@@ -211,12 +214,12 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
 #ifdef LOAMX_NN_SAME_STATS
 void debug_nn_same(const RegBatch& B, uint32_t it, hipStream_t s);
 #endif
-void launch_lm_begin(const RegBatch& B, const RegConfig& C, uint32_t iteration, hipStream_t s);
+void launch_lm_begin(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_sweep(const RegBatch& B, hipStream_t s);
 void launch_sweep_light(const RegBatch& B, hipStream_t s);
 void launch_lm_step(const RegBatch& B, hipStream_t s);
 void launch_moments(const RegBatch& B, hipStream_t s);
-void launch_outer_update(const RegBatch& B, const RegConfig& C, uint32_t iteration, hipStream_t s);
+void launch_outer_update(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_write_results(const RegBatch& B, loamx_reg_result* d_results, hipStream_t s);
 
 /* ---- synthetic generator (synth_kernels.hip) --------------------------------------------------- */

@@ -818,11 +818,14 @@ __global__ __launch_bounds__(kRestThreads) void associate_fit_queued_kernel(RegB
   if ((threadIdx.x & 63) == 0 && count) atomicAdd(&B.assoc.n_assoc[8 * pair + (PLANE ? 1 : 0)], count);
 }
 
-__global__ __launch_bounds__(64) void lm_begin_kernel(RegBatch B, RegConfig C, uint32_t iteration) {
+// (the ICF iteration number of an active pair is S.iterations, the iterations it has completed: no kernel argument
+// changes from one iteration to the next, so that the iteration can be replayed as a hipGraph)
+__global__ __launch_bounds__(64) void lm_begin_kernel(RegBatch B, RegConfig C) {
   const size_t pair = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pair >= B.n_pairs) return;
   PairState& S = B.state[pair];
   if (!S.active) return;
+  const uint32_t iteration = S.iterations;
   const uint32_t ne = B.assoc.n_assoc[8 * pair], np = B.assoc.n_assoc[8 * pair + 1];
   for (int c = 0; c < 6; c++) B.assoc.n_assoc[8 * pair + c] = 0;
   if ((uint64_t)ne + np < C.min_associations) {  // registration-inl.h:45-48
@@ -1213,11 +1216,12 @@ __global__ __launch_bounds__(kMomSize) void moment_finish_kernel(RegBatch B) {
   }
 }
 
-__global__ void outer_update_kernel(RegBatch B, RegConfig C, uint32_t iteration) {
+__global__ void outer_update_kernel(RegBatch B, RegConfig C) {
   const size_t pair = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pair >= B.n_pairs) return;
   PairState& S = B.state[pair];
   if (!S.active) return;
+  const uint32_t iteration = S.iterations;
   double upd[7];
   for (int i = 0; i < 7; i++) upd[i] = S.lm.x_user[i];
   if (B.iter_info) {
@@ -1472,14 +1476,14 @@ void launch_lm_step(const RegBatch& B, hipStream_t s) {
   launch_kernel(lm_step_kernel, dim3(per_pair_grid(B.n_pairs)), dim3(64), 0, s, B);
 }
 
-void launch_lm_begin(const RegBatch& B, const RegConfig& C, uint32_t iteration, hipStream_t s) {
+void launch_lm_begin(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   if (B.n_pairs == 0) return;
-  launch_kernel(lm_begin_kernel, dim3(per_pair_grid(B.n_pairs)), dim3(64), 0, s, B, C, iteration);
+  launch_kernel(lm_begin_kernel, dim3(per_pair_grid(B.n_pairs)), dim3(64), 0, s, B, C);
 }
 
-void launch_outer_update(const RegBatch& B, const RegConfig& C, uint32_t iteration, hipStream_t s) {
+void launch_outer_update(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   if (B.n_pairs == 0) return;
-  launch_kernel(outer_update_kernel, dim3(per_pair_grid(B.n_pairs)), dim3(64), 0, s, B, C, iteration);
+  launch_kernel(outer_update_kernel, dim3(per_pair_grid(B.n_pairs)), dim3(64), 0, s, B, C);
 }
 
 void launch_write_results(const RegBatch& B, loamx_reg_result* d_results, hipStream_t s) {

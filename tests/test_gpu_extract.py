@@ -287,3 +287,46 @@ def test_batch_extract_many_scans_fused_offsets(oracle):
         assert np.array_equal(px[s, :npl[s]], scans[s][op])
     for b in (d_xyz, d_ei, d_pi, d_ne, d_np, d_ex, d_px):
         b.free()
+
+
+def test_fused_extraction_kernel_equals_the_separate_kernels(oracle, monkeypatch):
+    """extract_fused_kernel (LOAMX_FUSED_EXTRACT=1: curvature + validity + selection + compaction in one pass over the
+    scan) against the oracle and against the default two-kernel path: indices, counts and point copies, double and
+    float input, with ties (replayed from the workspace copy the fused kernel leaves for tied lines) and without."""
+    H, W, ns = 64, 1024, 5
+    N = H * W
+    c = ctx()
+    lidar, fe = capi.LidarParams(H, W, 1.0, 120.0), capi.FeatureExtractionParams()
+    scans = np.stack([capi.synth_scan_host(300 + s, 0, s & 1, H, W, 0.0 if s == 2 else 0.01) for s in range(ns)])  # scan 2: noise free (ties)
+    ecap, pcap = c.edge_capacity(lidar, fe), c.planar_capacity(lidar, fe)
+    for f32 in (False, True):
+        data = scans.astype(np.float32) if f32 else scans
+        wide = data.astype(np.float64)
+        d_xyz = c.alloc(data.nbytes).upload(data)
+        out = {}
+        for fused in (True, False):
+            if fused:
+                monkeypatch.setenv("LOAMX_FUSED_EXTRACT", "1")
+            else:
+                monkeypatch.delenv("LOAMX_FUSED_EXTRACT", raising=False)
+            d_ei, d_pi, d_ne, d_np = c.alloc(ns * ecap * 4), c.alloc(ns * pcap * 4), c.alloc(ns * 4), c.alloc(ns * 4)
+            d_ex, d_px = c.alloc(ns * ecap * 24), c.alloc(ns * pcap * 24)
+            r0 = c.extract_counters()[0]
+            c.extract_features_batch_dev(d_xyz.ptr, ns, lidar, fe, d_ei.ptr, d_ne.ptr, d_ex.ptr, d_pi.ptr, d_np.ptr, d_px.ptr, f32=f32)
+            c.synchronize()
+            assert c.extract_counters()[0] > r0  # the noise-free scan has tied lines
+            ne, npl = d_ne.download(np.uint32, ns), d_np.download(np.uint32, ns)
+            ei = d_ei.download(np.uint32, ns * ecap).reshape(ns, ecap)
+            pi = d_pi.download(np.uint32, ns * pcap).reshape(ns, pcap)
+            ex = d_ex.download(np.float64, ns * ecap * 3).reshape(ns, ecap, 3)
+            px = d_px.download(np.float64, ns * pcap * 3).reshape(ns, pcap, 3)
+            out[fused] = [(ei[s, :ne[s]].copy(), pi[s, :npl[s]].copy(), ex[s, :ne[s]].copy(), px[s, :npl[s]].copy()) for s in range(ns)]
+            for b_ in (d_ei, d_pi, d_ne, d_np, d_ex, d_px):
+                b_.free()
+        d_xyz.free()
+        for s in range(ns):
+            oe, op = oracle.extract_features(wide[s], H, W, 1.0, 120.0)
+            for fused in (True, False):
+                e, p, xe, xp = out[fused][s]
+                assert np.array_equal(e, oe) and np.array_equal(p, op), (f32, fused, s)
+                assert np.array_equal(xe, wide[s][oe]) and np.array_equal(xp, wide[s][op])
