@@ -112,6 +112,7 @@ LOAMX_HD uint32_t grid_cell_of_point(const GridDesc& g, Vec3 p) {
 constexpr uint32_t kGridLdsCells = LOAMX_GRID_LDS_CELLS;  // cells counted per pass of grid_build_kernel (LDS table)
 constexpr uint32_t kGridCellsCap = 65536;  // cells of one target grid (two build passes)
 constexpr uint32_t kGridPad = 4;           // spare GridPoint entries after every sorted set (unclamped 4-wide candidate loads)
+constexpr float kRelPad = 3.0e38f;         // their single-precision offsets: farther than any point (knn_scan_batch_f32<.., false>)
 
 // Chooses the cell edge and grid dimensions for a target set with bounding box [lo, hi].
 // Cell edge: a quarter of the search radius (measured on 64x1024 feature sets: R/4 -> 48 candidates
@@ -854,7 +855,11 @@ struct alignas(4) KnnF4 {
   float v[4];
 };
 // four candidates p..p+3 of the SoA copy (planes x, y, z of `plane` floats each); lidx = 4 * batch number
-template <int KM>
+// MASK = false: the candidates past the range's end are NOT masked. They are real points of the following cells (or the
+// pad entries behind the set, whose offsets are 3e38), so the search stays exact; a point offered twice (as such an
+// extra and again in its own row) shows up as two equal distances among the keys and is caught by the verification's
+// strictly-ascending test, which sends the query to the queue.
+template <int KM, bool MASK = true>
 LOAMX_HD void knn_scan_batch_f32(KnnKeys32<KM>& c, float qx, float qy, float qz, const float* __restrict__ rel,
                                  uint32_t plane, uint32_t p, uint32_t n, uint32_t lidx, uint32_t imask) {
   const char* __restrict__ base = reinterpret_cast<const char*>(rel) + (uint32_t)(p << 2);
@@ -885,7 +890,7 @@ LOAMX_HD void knn_scan_batch_f32(KnnKeys32<KM>& c, float qx, float qy, float qz,
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     key[i] = (knn_f32_bits(d[i]) & ~imask) | (lidx + (uint32_t)i);
-    if ((uint32_t)i >= n) key[i] = 0xFFFFFFFFu;
+    if (MASK && (uint32_t)i >= n) key[i] = 0xFFFFFFFFu;
   }
 #pragma unroll
   for (int i = 0; i < 4; i++) knn_key32_insert(c, key[i]);
@@ -1123,7 +1128,7 @@ LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cel
     const bool active = p < e;
     if (!active && !(ri < nrow)) break;  // (lanes leave for good: t stays in step for the others)
     if (t >= tmax) break;
-    if (active) knn_scan_batch_f32(c, qx, qy, qz, rel, plane, p, e - p, t << 2, imask);
+    if (active) knn_scan_batch_f32<KM, false>(c, qx, qy, qz, rel, plane, p, e - p, t << 2, imask);
     p += active ? 4u : 0u;
     t++;
   }

@@ -242,6 +242,7 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
       sp[p] = GridPoint{x, y, z, i, 0u};
       if (!ORDERED && rel) rel[p] = (float)(x - g.ox), rel[gs.stride + p] = (float)(y - g.oy), rel[2 * gs.stride + p] = (float)(z - g.oz);
     }
+    if (!ORDERED && rel && (uint32_t)tid < kGridPad) rel[n + tid] = kRelPad, rel[gs.stride + n + tid] = kRelPad, rel[2 * gs.stride + n + tid] = kRelPad;
   } else if (!ORDERED && gs.rel) {
     // single-precision offsets from the grid origin, SoA (FP32 pre-selection of the k-NN): one coalesced
     // pass over the finished cell order instead of three scattered 4-byte writes per point
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
       const GridPoint e = sp[p];
       rel[p] = (float)(e.x - g.ox), rel[gs.stride + p] = (float)(e.y - g.oy), rel[2 * gs.stride + p] = (float)(e.z - g.oz);
     }
+    if ((uint32_t)tid < kGridPad) rel[n + tid] = kRelPad, rel[gs.stride + n + tid] = kRelPad, rel[2 * gs.stride + n + tid] = kRelPad;
   }
 #ifdef LOAMX_BUILD_PROFILE
   STAMP();
@@ -398,10 +400,13 @@ __global__ __launch_bounds__(kBigThreads) void gridbig_rel_kernel(const uint32_t
   const size_t pair = blockIdx.y;
   const uint32_t n_raw = n_pts[pair * in_pitch], n = n_raw < stride ? n_raw : (uint32_t)stride;
   const uint32_t p = blockIdx.x * kBigThreads + threadIdx.x;
-  if (p >= n) return;
+  float* __restrict__ rel = gs.rel + pair * 3 * gs.stride;
+  if (p >= n) {
+    if (p < n + kGridPad) rel[p] = kRelPad, rel[gs.stride + p] = kRelPad, rel[2 * gs.stride + p] = kRelPad;
+    return;
+  }
   const GridDesc g = gs.desc[pair];
   const GridPoint e = gs.sorted[pair * gs.stride + p];
-  float* __restrict__ rel = gs.rel + pair * 3 * gs.stride;
   rel[p] = (float)(e.x - g.ox), rel[gs.stride + p] = (float)(e.y - g.oy), rel[2 * gs.stride + p] = (float)(e.z - g.oz);
 }
 
@@ -1277,7 +1282,7 @@ static void launch_grid_build_big(size_t n_pairs, const double* pts, const uint3
   launch_kernel(gridbig_scan_kernel, dim3((unsigned)n_pairs), dim3(1024), 0, s, n_pts, stride, in_pitch, gs, scratch);
   launch_kernel(gridbig_pass_kernel<true>, chunks, dim3(kBigThreads), 0, s, pts, n_pts, stride, in_pitch, gs, scratch);
   if (gs.rel)
-    launch_kernel(gridbig_rel_kernel, dim3((unsigned)((stride + kBigThreads - 1) / kBigThreads), (unsigned)n_pairs), dim3(kBigThreads), 0,
+    launch_kernel(gridbig_rel_kernel, dim3((unsigned)((stride + kGridPad + kBigThreads - 1) / kBigThreads), (unsigned)n_pairs), dim3(kBigThreads), 0,
                        s, n_pts, stride, in_pitch, gs);
 }
 

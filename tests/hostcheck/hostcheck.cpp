@@ -370,7 +370,7 @@ static void build_grid(const double* pts, uint32_t n, double max_dist, HostGrid&
     G.sp[pos] = GridPoint{pts[3 * k], pts[3 * k + 1], pts[3 * k + 2], k, 0};
   }
   const size_t plane = G.sp.size();
-  G.rel.assign(3 * plane, 0.0f);
+  G.rel.assign(3 * plane, kRelPad);  // (the pad entries behind the set keep this value, as on the device)
   for (uint32_t p = 0; p < n; p++) {
     G.rel[p] = (float)(G.sp[p].x - G.g.ox), G.rel[plane + p] = (float)(G.sp[p].y - G.g.oy);
     G.rel[2 * plane + p] = (float)(G.sp[p].z - G.g.oz);
