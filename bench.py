@@ -25,7 +25,6 @@ Prints ONE JSON line on rank 0 (contract in the task description) with extra obj
   ranks        — (N > 1) what RCCL reported: communicator size, the gathered rank ids and devices
 """
 import argparse
-import hashlib
 import json
 import os
 import socket
@@ -337,9 +336,9 @@ def main():
             affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             quota = cgroup_cpu_quota()  # the GPU box hands one GPU's share of the host: 16 of its 256 CPUs
             threads = max(1, min(affinity, int(quota + 0.5)) if quota else affinity)
-            # ~45-50 ms of CPU per pair: 64 pairs per thread ~ 3 s of wall time; one thread: 64 pairs ~ 3 s
+            # ~40-50 ms of CPU per pair: 64 pairs per thread ~ 3 s of wall time; one thread: 96 pairs ~ 3.7 s
             n_sample = args.cpu_sample if args.cpu_sample > 0 else min(P, 64 * threads)
-            n_single = min(P, 64)
+            n_single = min(P, 96)
             scans = xyz[: n_sample * 2 * N * 3].double().cpu().numpy().reshape(n_sample * 2, N, 3)
             cpu_out, dt = cpu_baseline(scans, list(range(n_sample)), threads)
             _, dt1 = cpu_baseline(scans, list(range(min(n_single, n_sample))), 1)

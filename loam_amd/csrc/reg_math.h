@@ -1128,7 +1128,10 @@ LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cel
     const bool active = p < e;
     if (!active && !(ri < nrow)) break;  // (lanes leave for good: t stays in step for the others)
     if (t >= tmax) break;
-    if (active) knn_scan_batch_f32<KM, false>(c, qx, qy, qz, rel, plane, p, e - p, t << 2, imask);
+    // (masked tails: without the mask — 6 of 62 instructions per batch, measured 1.45 -> 1.435 ms — a batch that runs past
+    // its row's end offers points of the following cells; in a scene without a far wall those are the next row's first
+    // points, i.e. candidates of this very query, and every such duplicate sends the query to the queue)
+    if (active) knn_scan_batch_f32<KM, true>(c, qx, qy, qz, rel, plane, p, e - p, t << 2, imask);
     p += active ? 4u : 0u;
     t++;
   }
