@@ -320,7 +320,9 @@ def main():
                                 "unit": "G wave-instructions/s", "frac": round(ach / VALU_PEAK_GINST, 4),
                                 "valu_instructions_per_launch": insts, "avg_launch_ms": kern["knn_plane_kernel"]["avg_ms"]}
                         if "SQ_THREAD_CYCLES_VALU" in ctr[knn] and "SQ_ACTIVE_INST_VALU" in ctr[knn] and ctr[knn]["SQ_ACTIVE_INST_VALU"] > 0:
-                            comp["active_lane_fraction"] = round(ctr[knn]["SQ_THREAD_CYCLES_VALU"] / (64.0 * 4.0 * ctr[knn]["SQ_ACTIVE_INST_VALU"]), 4)
+                            comp["active_lane_fraction"] = round(ctr[knn]["SQ_THREAD_CYCLES_VALU"] / (64.0 * ctr[knn]["SQ_ACTIVE_INST_VALU"]), 4)
+                            comp["note"] = ("peak = 2 cycles per wave64 instruction (packed FP32 rate); an unpacked 32-bit instruction occupies "
+                                            "its SIMD for 4 cycles, i.e. twice this fraction of the issue slots")
                         roofline["compute"] = comp
             except Exception as e:  # no profile committed for this round yet
                 roofline["traffic_note"] = f"no usable PMC file ({type(e).__name__})"
