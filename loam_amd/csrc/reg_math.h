@@ -1106,6 +1106,7 @@ LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cel
   uint32_t p = 0, e = 0, t = 0;  // t = batches consumed so far
   int ri = 0, nv = 0;
   uint64_t started = 0;  // bit t: a visited row starts with batch t
+  bool overflow = false;
   // one row step per trip, predicated instead of branched: a lane whose range is used up looks at its next row
   // (taking it or not), every lane that holds a range scans one batch; no inner loop, no exec-mask bookkeeping
   for (;;) {
@@ -1118,6 +1119,7 @@ LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cel
     const float bound = worst < fr2 ? worst : fr2;
     const bool step = need && have;
     const bool take = step && s2 <= bound && t < tmax;
+    overflow = overflow || (step && s2 <= bound && t >= tmax);  // an admissible row the trip budget no longer covers
     ri += step ? 1 : 0;
     p = take ? (w & 0xFFFFu) : p, e = take ? (w >> 16) : e;
     if (take) {
@@ -1135,7 +1137,7 @@ LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cel
     p += active ? 4u : 0u;
     t++;
   }
-  if (p < e || (t >= tmax && ri < nrow)) return -2;  // the running number is exhausted (more than 63 batches)
+  if (p < e || overflow || (t >= tmax && ri < nrow)) return -2;  // the running number is exhausted (more than 64 trips)
   // ---- is the search over after the 3x3x3 block? (same test as knn_done, with the rigorous bound)
   {
     double guard = kDblMax;
@@ -1296,10 +1298,21 @@ LOAMX_HD void fit_line(const Vec3 pts[KM], int K, Vec3& a, Vec3& b) {
     jacobi_rotate(a00, a22, a02, a01, a12, v00, v10, v20, v02, v12, v22);  // (0,2,1)
     jacobi_rotate(a11, a22, a12, a01, a02, v01, v11, v21, v02, v12, v22);  // (1,2,0)
   }
-  Vec3 dir = v3(v00, v10, v20);
-  double best = a00;
-  if (a11 > best) best = a11, dir = v3(v01, v11, v21);
-  if (a22 > best) best = a22, dir = v3(v02, v12, v22);
+  // "The eigenvector of the largest eigenvalue" (geometry.cpp:51) as Eigen orders equal eigenvalues [RECALLED]: its
+  // selection sort takes the FIRST minimum of the remaining values, so for a diagonal covariance (neighbours on a
+  // lattice) (0, s, s) -> column 2, (s, s, 0) -> column 0, (s, 0, s) -> column 2, (s, s, s) -> column 2.
+  int c0 = 0, c1 = 1, c2 = 2;
+  double e0 = a00, e1 = a11, e2 = a22;
+  {  // i = 0: first minimum of (e0, e1, e2) goes to the front
+    int k = 0;
+    if (e1 < e0) k = 1;
+    if (e2 < (k == 1 ? e1 : e0)) k = 2;
+    if (k == 1) { double t = e0; e0 = e1; e1 = t; int ti = c0; c0 = c1; c1 = ti; }
+    if (k == 2) { double t = e0; e0 = e2; e2 = t; int ti = c0; c0 = c2; c2 = ti; }
+  }
+  if (e2 < e1) { int ti = c1; c1 = c2; c2 = ti; }  // i = 1
+  (void)c0, (void)c1, (void)e0;
+  const Vec3 dir = c2 == 0 ? v3(v00, v10, v20) : (c2 == 1 ? v3(v01, v11, v21) : v3(v02, v12, v22));
   a = vadd(center, vscale(0.1, dir));  // geometry.cpp:53
   b = vsub(center, vscale(0.1, dir));
 }

@@ -264,8 +264,19 @@ void symeig3(const double A_in[3][3], double evals[3], double V[3][3]) {
       }
     }
   }
+  // [RECALLED] Eigen sorts the (eigenvalue, eigenvector) pairs ascending with a selection sort that takes the FIRST
+  // minimum of the remaining ones (SelfAdjointEigenSolver.h, computeFromTridiagonal_impl: diag.segment(i, n - i)
+  // .minCoeff(&k); swap if k > 0). It decides which eigenvector "the largest" is when eigenvalues are EQUAL — a
+  // covariance that is exactly diagonal with two equal entries, i.e. neighbours on a lattice: (0, s, s) -> z,
+  // (s, s, 0) -> x, (s, 0, s) -> z, (s, s, s) -> z (for a diagonal input Eigen's tridiagonalisation and QL iteration
+  // leave values and vectors in place, as the Jacobi sweeps above do).
   int order[3] = {0, 1, 2};
-  std::sort(order, order + 3, [&](int a, int b) { return A[a][a] < A[b][b]; });
+  for (int i = 0; i < 2; i++) {
+    int k = 0;
+    for (int j = 1; j < 3 - i; j++)
+      if (A[order[i + j]][order[i + j]] < A[order[i + k]][order[i + k]]) k = j;
+    if (k > 0) std::swap(order[i], order[i + k]);
+  }
   double Vs[3][3];
   for (int k = 0; k < 3; k++) {
     evals[k] = A[order[k]][order[k]];

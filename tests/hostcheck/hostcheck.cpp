@@ -5,6 +5,7 @@
 // GPU will execute can be compared with the oracle in this GPU-less container. It is built only by
 // tests/ (tests/hostcheck/Makefile), is never linked into libloamx.so and is not a product path.
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -598,7 +599,7 @@ int hostcheck_register(const double* src_edge, uint64_t n_se, const double* src_
     lm_init(st);
     // as the kernels: from the second ICF iteration on the plane records enter through their moment matrix
     // while that is provably exact (Huber inactive at the candidate), else they are streamed like the edges
-    const bool use_moments = it >= 1;
+    const bool use_moments = it >= 1 && !getenv("HOSTCHECK_NO_MOMENTS");
     std::vector<double> M(kMomSize + 2, 0.0);
     std::vector<Slot> flagged;  // plane records that start far from their plane: evaluated one by one
     if (use_moments) {

@@ -330,3 +330,32 @@ def test_fused_extraction_kernel_equals_the_separate_kernels(oracle, monkeypatch
                 e, p, xe, xp = out[fused][s]
                 assert np.array_equal(e, oe) and np.array_equal(p, op), (f32, fused, s)
                 assert np.array_equal(xe, wide[s][oe]) and np.array_equal(xp, wide[s][op])
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_extraction_fuzz_against_the_oracle(oracle, seed):
+    """Random scan shapes and random FeatureExtractionParams (neighbor_points 1..6, 1..9 sectors, caps 0..60, thresholds
+    on either side of the data, quantised and dropped-out ranges): curvature bits, mask and both index sequences against
+    the oracle, whichever kernels the parameters select (bitmask MIS with one or two picks per lane, arg-max fallback,
+    separate compaction, tie replay)."""
+    rng = np.random.default_rng(5000 + seed)
+    H, W = int(rng.integers(1, 10)), int(rng.choice([12, 37, 64, 100, 333, 512, 1024, 1500, 2048]))
+    xyz = capi.synth_scan_host(int(rng.integers(1, 1000)), int(rng.integers(0, 5)), int(rng.integers(0, 2)), H, W, float(rng.choice([0.0, 0.01, 0.05])))
+    if rng.random() < 0.4:
+        xyz = np.round(xyz * 32.0) / 32.0  # fixed-point sensor: ties
+    if rng.random() < 0.4:
+        xyz[rng.random(len(xyz)) < 0.05] = 0.0  # drop-outs
+    np_ = int(rng.integers(1, 7))
+    params = (np_, int(rng.integers(1, 10)), int(rng.integers(0, 25)), int(rng.integers(0, 61)), float(rng.choice([5.0, 50.0, 100.0, 1e4])),
+              float(rng.choice([0.05, 1.0, 20.0])), float(rng.choice([0.1, 0.5])), float(rng.choice([0.02, 1.0])))
+    if W < 2 * np_ + 2:
+        params = (1,) + params[1:]
+    ofe, fe = oracle.FeParams(*params), capi.FeatureExtractionParams(*params)
+    lidar = capi.LidarParams(H, W, 1.0, 120.0)
+    c = ctx().compute_curvature(xyz, lidar, fe)
+    m = ctx().compute_valid_points(xyz, lidar, fe)
+    assert np.array_equal(c.view(np.uint64), oracle.compute_curvature(xyz, H, W, ofe).view(np.uint64)), (seed, params)
+    assert np.array_equal(m, oracle.compute_valid_points(xyz, H, W, 1.0, 120.0, ofe)), (seed, params)
+    e, p = ctx().extract_features(xyz, lidar, fe)
+    oe, op = oracle.extract_features(xyz, H, W, 1.0, 120.0, ofe)
+    assert np.array_equal(e, oe) and np.array_equal(p, op), (seed, H, W, params)

@@ -324,3 +324,55 @@ def test_stl_sort_replays_the_heap_sort_branch():
         q = np.floor(c / 3.0)  # the same shape with ties
         a, b = _sort_pair(q)
         assert np.array_equal(a, b)
+
+
+def test_fit_line_on_degenerate_lattice_neighbourhoods(oracle):
+    """Neighbours on a lattice give an exactly diagonal covariance with EQUAL eigenvalues; "the largest" is then whatever
+    Eigen's selection sort of the eigenvalues leaves last [RECALLED]: (0, s, s) -> z, (s, s, 0) -> x, (s, 0, s) -> z,
+    (s, s, s) -> z. Oracle and kernel math must agree on these (found by the association fuzz test, round 2)."""
+    c = np.array([1.25, -0.5, 2.0])
+    h = 0.25
+    ex, ey, ez = np.eye(3) * h
+    cases = [([c, c + ey, c - ey, c + ez, c - ez], 2),            # (0, s, s) -> z
+             ([c, c + ex, c - ex, c + ey, c - ey], 0),            # (s, s, 0) -> x
+             ([c, c + ex, c - ex, c + ez, c - ez], 2),            # (s, 0, s) -> z
+             ([c + ex, c - ex, c + ey, c - ey, c], 0)]
+    six = [c + ex, c - ex, c + ey, c - ey, c + ez][:5]
+    for pts, axis in cases:
+        pts = np.array(pts)
+        a, b, _ = oracle.fit_line(pts)
+        d = (a - b) / np.linalg.norm(a - b)
+        assert abs(abs(d[axis]) - 1.0) < 1e-12, (pts, d)
+        ha, hb = Hc.fit_line(pts)
+        assert np.allclose(ha, a, atol=1e-15) and np.allclose(hb, b, atol=1e-15)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_knn_fuzz_every_path_is_exact(oracle, seed):
+    """Random clouds (dense blobs, planes, shells with a far cluster, lattices) x radii (on / off / tiny): the search the
+    kernels run — FP32 round 1 in its lean form, its wide retry, the keyed FP64 rounds, the exact collector — against
+    brute force, and the fast paths against the exact collector query by query (mismatch counter). The dense blob with
+    the radius filter off is the case that overran the lean walk's trip budget in round 2 (an admissible row was
+    dropped silently instead of handing the query to the queue)."""
+    rng = np.random.default_rng(900 + seed)
+    kind = seed % 4
+    n = int(rng.choice([300, 3000, 9000]))
+    if kind == 0:
+        pts = rng.normal(size=(n, 3)) * rng.uniform(0.5, 5.0)
+    elif kind == 1:
+        u, v = rng.normal(size=3), rng.normal(size=3)
+        pts = np.outer(rng.uniform(-4, 4, n), u / np.linalg.norm(u)) + np.outer(rng.uniform(-4, 4, n), v / np.linalg.norm(v)) + rng.normal(size=(n, 3)) * 0.01
+    elif kind == 2:
+        d = rng.normal(size=(n, 3))
+        pts = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(5, 30)
+        pts[: n // 10] = rng.normal(size=(n // 10, 3)) * 0.2 + 100.0
+    else:
+        g = int(round(n ** (1 / 3))) + 1
+        pts = np.stack(np.meshgrid(*[np.arange(g) * 0.25] * 3), -1).reshape(-1, 3)[:n] + rng.normal(size=3)
+    pts = np.ascontiguousarray(pts)
+    before = Hc.knn_mismatches()
+    for R in (2.0, -1.0, 0.3):
+        for q in pts[rng.integers(0, len(pts), 60)] + rng.normal(size=(60, 3)) * 0.05:
+            for k in (5, 8):
+                assert np.array_equal(oracle.knn_bruteforce(pts, q, k, R), Hc.knn(pts, q, k, R)), (seed, R, k)
+    assert Hc.knn_mismatches() == before
