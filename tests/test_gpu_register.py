@@ -352,9 +352,12 @@ def test_association_fuzz_against_the_oracle(oracle, seed):
             d = rng.normal(size=(n, 3))
             pts = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(5, 30)
             pts[: n // 10] = rng.normal(size=(n // 10, 3)) * 0.2 + 100.0
-        else:  # lattice (exact distance ties)
+        else:  # lattice with three different spacings: rows of equidistant neighbours, cells filled evenly. (With ONE
+            # spacing the five neighbours of an edge point form a cross whose covariance has two equal eigenvalues
+            # and off-diagonals of rounding noise: "the" direction of the line is then decided by that noise — in
+            # Eigen by the order its reductions add in — and no restatement can be held to it)
             g = int(round(n ** (1 / 3))) + 1
-            pts = np.stack(np.meshgrid(*[np.arange(g) * 0.25] * 3), -1).reshape(-1, 3)[:n]
+            pts = np.stack(np.meshgrid(np.arange(g) * 0.25, np.arange(g) * 0.27, np.arange(g) * 0.31), -1).reshape(-1, 3)[:n]
         return np.ascontiguousarray(pts + rng.normal(size=3))
 
     n_e, n_p = int(rng.choice([0, 3, 7, 60, 400, 700])), int(rng.choice([4, 9, 150, 2000, 9000]))
