@@ -896,6 +896,51 @@ LOAMX_HD void knn_scan_batch_f32(KnnKeys32<KM>& c, float qx, float qy, float qz,
   for (int i = 0; i < 4; i++) knn_key32_insert(c, key[i]);
 }
 
+// The same batch with the three coordinate planes as separate (wave-uniform) base pointers and one 32-bit offset:
+// three loads off scalar bases, no per-lane 64-bit address arithmetic. Tails masked; 8-bit running numbers.
+template <int KM>
+LOAMX_HD void knn_scan_batch_f32_soa(KnnKeys32<KM>& c, float qx, float qy, float qz, const float* __restrict__ rel_x,
+                                     const float* __restrict__ rel_y, const float* __restrict__ rel_z, uint32_t p,
+                                     uint32_t n, uint32_t lidx, uint32_t keep) {
+  const uint32_t off = p << 2;
+  const KnnF4 x = *reinterpret_cast<const KnnF4*>(reinterpret_cast<const char*>(rel_x) + off);
+  const KnnF4 y = *reinterpret_cast<const KnnF4*>(reinterpret_cast<const char*>(rel_y) + off);
+  const KnnF4 z = *reinterpret_cast<const KnnF4*>(reinterpret_cast<const char*>(rel_z) + off);
+#if defined(LOAMX_KNN_STATS)
+  g_cand += n < 4u ? n : 4u;
+#endif
+  uint32_t key[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 mqx = {-qx, -qx}, mqy = {-qy, -qy}, mqz = {-qz, -qz};
+  const f2 x01 = {x.v[0], x.v[1]}, x23 = {x.v[2], x.v[3]}, y01 = {y.v[0], y.v[1]}, y23 = {y.v[2], y.v[3]};
+  const f2 z01 = {z.v[0], z.v[1]}, z23 = {z.v[2], z.v[3]};
+  const f2 dx01 = x01 + mqx, dx23 = x23 + mqx, dy01 = y01 + mqy, dy23 = y23 + mqy, dz01 = z01 + mqz, dz23 = z23 + mqz;
+  f2 s01 = dx01 * dx01, s23 = dx23 * dx23;
+  s01 = __builtin_elementwise_fma(dy01, dy01, s01), s23 = __builtin_elementwise_fma(dy23, dy23, s23);
+  s01 = __builtin_elementwise_fma(dz01, dz01, s01), s23 = __builtin_elementwise_fma(dz23, dz23, s23);
+  const float d[4] = {s01.x, s01.y, s23.x, s23.y};
+#else
+  float d[4];
+  for (int i = 0; i < 4; i++) {
+    const float dx = x.v[i] - qx, dy = y.v[i] - qy, dz = z.v[i] - qz;
+    d[i] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+  }
+#endif
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (one v_and_or_b32 with `keep` in a vector and the wave-uniform running number in a scalar register)
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key[i]) : "v"(knn_f32_bits(d[i])), "v"(keep), "s"(lidx + (uint32_t)i));
+#else
+    key[i] = (knn_f32_bits(d[i]) & keep) | (lidx + (uint32_t)i);
+#endif
+    if ((uint32_t)i >= n) key[i] = 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) knn_key32_insert(c, key[i]);
+}
+
 // Round 1 with the FP32 collector. Returns the number of neighbours kept, or -1 (undecided / needs
 // more rounds: queue it). pos as in knn_search_keyed (neighbour j in pos[(KM - k) + j]).
 // `rel` = SoA single-precision offsets of the sorted target points from the grid origin, planes of
@@ -1073,7 +1118,7 @@ LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cel
   const float fr2 = r2 < 1e37 ? (float)r2 * kUp : 3.0e38f;
   const float fa2 = (float)(3003.0 * a * a) * kUp;
   int nrow = 0;
-  {  // the non-empty rows of the nine, centre first, then faces, then corners
+  {  // the non-empty rows of the nine within the radius, centre first, then faces, then corners
     const int32_t xa = cx - 1 < 0 ? 0 : cx - 1, xb = cx + 1 > g.nx - 1 ? g.nx - 1 : cx + 1;
     uint32_t rb[9], re[9];
 #pragma unroll
@@ -1090,9 +1135,17 @@ LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cel
     for (int o = 0; o < 9; o++) {
       constexpr int kOrder[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
       const int j = kOrder[o];
-      if (rb[o] < re[o]) {
+      // A row is admissible while its squared slab distance s2 is not above the bound on the k-th distance,
+      // (float(kth | imask) + fa2) * 1.002 * kUp, nor above the radius. As a test on the KEY: kth >= thr with
+      // thr = bits(x) & ~imask for any x <= s2 / (1.002 kUp) - fa2 (float bits of positive values are monotone, and
+      // (kth | imask) >= bits(x) is a comparison of the upper 24 bits) — one integer compare per row step instead of
+      // rebuilding the bound from the key every trip. x is taken low: 0.99799 < 1 / (1.002 * 1.00001) by 4e-6.
+      const float s2 = fy2[j % 3] + fz2[j / 3];
+      const float x = (s2 * 0.99799f - fa2) * kDown;
+      const uint32_t thr = x > 0.0f ? (knn_f32_bits(x) & ~0xFFu) : 0u;
+      if (rb[o] < re[o] && s2 <= fr2) {
         row_scratch[nrow * row_stride] = rb[o] | (re[o] << 16);
-        row_scratch[(9 + nrow) * row_stride] = knn_f32_bits(fy2[j % 3] + fz2[j / 3]);
+        row_scratch[(9 + nrow) * row_stride] = thr;
         nrow++;
       }
     }
@@ -1103,41 +1156,56 @@ LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cel
 #define LOAMX_LEAN_TMAX 64
 #endif
   constexpr uint32_t imask = 0xFFu, tmax = LOAMX_LEAN_TMAX;  // trips a lane may take before it hands its query to the queue (<= 64)
-  uint32_t p = 0, e = 0, t = 0;  // t = batches consumed so far
+  static_assert(imask == 0xFFu, "the row thresholds above clear the same bits");
+  const float* __restrict__ rel_x = rel;
+  const float* __restrict__ rel_y = rel + (size_t)plane;
+  const float* __restrict__ rel_z = rel + 2 * (size_t)plane;
+  uint32_t p = 0, e = 0;
   int ri = 0, nv = 0;
   uint64_t started = 0;  // bit t: a visited row starts with batch t
-  bool overflow = false;
-  // one row step per trip, predicated instead of branched: a lane whose range is used up looks at its next row
-  // (taking it or not), every lane that holds a range scans one batch; no inner loop, no exec-mask bookkeeping
-  for (;;) {
-    const bool need = p >= e, have = ri < nrow;
+  // One row step per trip, predicated instead of branched: a lane whose range is used up looks at its next row (taking
+  // it or not), every lane that holds a range scans one batch; no inner loop, no exec-mask bookkeeping. Every lane
+  // still in the loop has made the same number of trips, so the trip counter lives in a scalar register and so do the
+  // running numbers derived from it.
+  // ~imask held in a vector register the compiler cannot fold back into a literal: (bits & keep) | number is then one
+  // v_and_or_b32 per key (a 32-bit literal is not encodable in that instruction; with it the compiler emits two)
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t keep;
+  asm volatile("v_mov_b32 %0, 0xffffff00" : "=v"(keep));
+#else
+  const uint32_t keep = ~imask;
+#endif
+  uint32_t t = 0;
+  for (; t < tmax; t++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t tu = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+#else
+    const uint32_t tu = t;
+#endif
+    const bool have = ri < nrow, step = p >= e && have;
     const int rr = have ? ri : 0;
-    const uint32_t w = row_scratch[rr * row_stride];
-    const float s2 = knn_bits_f32(row_scratch[(9 + rr) * row_stride]);
-    const uint32_t kth = c.key[KM - 1];
-    const float worst = kth >= 0x7F800000u ? 3.0e38f : (knn_bits_f32(kth | imask) + fa2) * (1.002f * kUp);
-    const float bound = worst < fr2 ? worst : fr2;
-    const bool step = need && have;
-    const bool take = step && s2 <= bound && t < tmax;
-    overflow = overflow || (step && s2 <= bound && t >= tmax);  // an admissible row the trip budget no longer covers
+    const uint32_t w = row_scratch[rr * row_stride], thr = row_scratch[(9 + rr) * row_stride];
+    const bool take = step && c.key[KM - 1] >= thr;
     ri += step ? 1 : 0;
     p = take ? (w & 0xFFFFu) : p, e = take ? (w >> 16) : e;
     if (take) {
-      row_scratch[(18 + nv) * row_stride] = (w & 0xFFFFu) | (t << 16);
+      row_scratch[(18 + nv) * row_stride] = (w & 0xFFFFu) | (tu << 16);
       nv++;
-      started |= 1ull << t;
+      started |= 1ull << tu;
     }
-    const bool active = p < e;
-    if (!active && !(ri < nrow)) break;  // (lanes leave for good: t stays in step for the others)
-    if (t >= tmax) break;
+    if (p >= e && ri >= nrow) break;  // (lanes leave for good)
     // (masked tails: without the mask — 6 of 62 instructions per batch, measured 1.45 -> 1.435 ms — a batch that runs past
     // its row's end offers points of the following cells; in a scene without a far wall those are the next row's first
     // points, i.e. candidates of this very query, and every such duplicate sends the query to the queue)
-    if (active) knn_scan_batch_f32<KM, true>(c, qx, qy, qz, rel, plane, p, e - p, t << 2, imask);
-    p += active ? 4u : 0u;
-    t++;
+    if (p < e) {
+      knn_scan_batch_f32_soa<KM>(c, qx, qy, qz, rel_x, rel_y, rel_z, p, e - p, tu << 2, keep);
+      p += 4u;
+    }
   }
-  if (p < e || overflow || (t >= tmax && ri < nrow)) return -2;  // the running number is exhausted (more than 64 trips)
+#if defined(LOAMX_KNN_STATS)
+  g_lean_trips = t, g_lean_nrow = (uint32_t)nrow, g_lean_taken = (uint32_t)nv;
+#endif
+  if (p < e || ri < nrow) return -2;  // the trip budget is used up with rows still to look at: the queue's business
   // ---- is the search over after the 3x3x3 block? (same test as knn_done, with the rigorous bound)
   {
     double guard = kDblMax;
