@@ -896,16 +896,11 @@ LOAMX_HD void knn_scan_batch_f32(KnnKeys32<KM>& c, float qx, float qy, float qz,
   for (int i = 0; i < 4; i++) knn_key32_insert(c, key[i]);
 }
 
-// The same batch with the three coordinate planes as separate (wave-uniform) base pointers and one 32-bit offset:
-// three loads off scalar bases, no per-lane 64-bit address arithmetic. Tails masked; 8-bit running numbers.
+// Four loaded candidates (offsets from the grid origin) through the collector: 8-bit running numbers lidx..lidx+3, tail
+// masked by n (valid candidates, may exceed 4).
 template <int KM>
-LOAMX_HD void knn_scan_batch_f32_soa(KnnKeys32<KM>& c, float qx, float qy, float qz, const float* __restrict__ rel_x,
-                                     const float* __restrict__ rel_y, const float* __restrict__ rel_z, uint32_t p,
-                                     uint32_t n, uint32_t lidx, uint32_t keep) {
-  const uint32_t off = p << 2;
-  const KnnF4 x = *reinterpret_cast<const KnnF4*>(reinterpret_cast<const char*>(rel_x) + off);
-  const KnnF4 y = *reinterpret_cast<const KnnF4*>(reinterpret_cast<const char*>(rel_y) + off);
-  const KnnF4 z = *reinterpret_cast<const KnnF4*>(reinterpret_cast<const char*>(rel_z) + off);
+LOAMX_HD void knn_collect_batch_f32(KnnKeys32<KM>& c, float qx, float qy, float qz, const KnnF4& x, const KnnF4& y,
+                                    const KnnF4& z, uint32_t n, uint32_t lidx, uint32_t keep) {
 #if defined(LOAMX_KNN_STATS)
   g_cand += n < 4u ? n : 4u;
 #endif
@@ -939,6 +934,18 @@ LOAMX_HD void knn_scan_batch_f32_soa(KnnKeys32<KM>& c, float qx, float qy, float
   }
 #pragma unroll
   for (int i = 0; i < 4; i++) knn_key32_insert(c, key[i]);
+}
+// The batch at position p of the three coordinate planes, given as separate (wave-uniform) base pointers: three loads
+// off scalar bases with one 32-bit offset, no per-lane 64-bit address arithmetic.
+template <int KM>
+LOAMX_HD void knn_scan_batch_f32_soa(KnnKeys32<KM>& c, float qx, float qy, float qz, const float* __restrict__ rel_x,
+                                     const float* __restrict__ rel_y, const float* __restrict__ rel_z, uint32_t p,
+                                     uint32_t n, uint32_t lidx, uint32_t keep) {
+  const uint32_t off = p << 2;
+  const KnnF4 x = *reinterpret_cast<const KnnF4*>(reinterpret_cast<const char*>(rel_x) + off);
+  const KnnF4 y = *reinterpret_cast<const KnnF4*>(reinterpret_cast<const char*>(rel_y) + off);
+  const KnnF4 z = *reinterpret_cast<const KnnF4*>(reinterpret_cast<const char*>(rel_z) + off);
+  knn_collect_batch_f32<KM>(c, qx, qy, qz, x, y, z, n, lidx, keep);
 }
 
 // Round 1 with the FP32 collector. Returns the number of neighbours kept, or -1 (undecided / needs
@@ -1079,9 +1086,10 @@ LOAMX_HD int knn_f32_round1_body(const GridDesc& g, const GridPoint* __restrict_
  *   - every visited row appends (begin | first batch << 16) to a compact list and sets bit `first batch` in a
  *     64-bit mask: the row of a key with batch number tb is entry popcount(mask & ((2 << tb) - 1)) - 1 — five
  *     instructions per key instead of a scan over the rows.
- * Per-thread list: kLeanRowWords words ([word][thread] in LDS).
+ * Per-thread list: kLeanRowWords words ([word][thread] in LDS): 9 row ranges, 9 thresholds; the visited list overwrites
+ * the row ranges from the front (entry nv <= the index of the row being taken, whose range is in a register by then).
  * ---------------------------------------------------------------------------------------------- */
-constexpr int kLeanRowWords = 27;
+constexpr int kLeanRowWords = 18;
 constexpr uint32_t kLeanMaxPoints = 65535u;  // positions are packed as 16-bit halves
 
 LOAMX_HD int knn_popcount64(uint64_t v) {
@@ -1090,6 +1098,48 @@ LOAMX_HD int knn_popcount64(uint64_t v) {
 #else
   return __builtin_popcountll(v);
 #endif
+}
+
+// one batch of four candidates in registers (n = 0: none)
+struct LeanBatch {
+  KnnF4 x, y, z;
+  uint32_t n;
+};
+
+// Half of the pipelined loop's body (trip `tu`): step to the next row if the range is used up, issue the loads of the next
+// batch into `nxt`, run `cur` (loaded one trip ago) through the collector. Returns whether this lane has anything left.
+template <int KM>
+LOAMX_HD bool knn_lean_half_trip(KnnKeys32<KM>& c, LeanBatch& cur, LeanBatch& nxt, uint32_t tu, uint32_t& p, uint32_t& e, int& ri,
+                                 int& nv, uint64_t& started, uint32_t& rw, uint32_t& rthr, int nrow, uint32_t* row_scratch,
+                                 int row_stride, float qx, float qy, float qz, const float* __restrict__ rel_x,
+                                 const float* __restrict__ rel_y, const float* __restrict__ rel_z, uint32_t keep) {
+  const bool step = p >= e && ri < nrow;
+  const bool take = step && c.key[KM - 1] >= rthr;
+  if (take) {
+    row_scratch[nv * row_stride] = (rw & 0xFFFFu) | ((tu + 1u) << 16);
+    nv++;
+    started |= 1ull << ((tu + 1u) & 63u);
+  }
+  p = take ? (rw & 0xFFFFu) : p, e = take ? (rw >> 16) : e;
+  ri += step ? 1 : 0;
+  {  // the entry of the row that is next now (used one trip later at the earliest)
+    const int rr = ri < 8 ? ri : 8;
+    rw = row_scratch[rr * row_stride], rthr = row_scratch[(9 + rr) * row_stride];
+  }
+  {  // (unconditionally as well — a lane without a range reads position 0 — so that the wait for `cur` below can be
+     // "all but the three loads just issued" on every path)
+    const bool work = p < e;
+    nxt.n = work ? e - p : 0u;
+    const uint32_t off = (work ? p : 0u) << 2;
+    nxt.x = *reinterpret_cast<const KnnF4*>(reinterpret_cast<const char*>(rel_x) + off);
+    nxt.y = *reinterpret_cast<const KnnF4*>(reinterpret_cast<const char*>(rel_y) + off);
+    nxt.z = *reinterpret_cast<const KnnF4*>(reinterpret_cast<const char*>(rel_z) + off);
+    p += work ? 4u : 0u;
+  }
+  // (unconditionally: with n = 0 every key is masked. Inside a branch the wait for `cur`'s loads would be conditional too,
+  // and the compiler would then drain the load queue before it issues the next loads)
+  knn_collect_batch_f32<KM>(c, qx, qy, qz, cur.x, cur.y, cur.z, cur.n, tu << 2, keep);
+  return nxt.n != 0u || ri < nrow;
 }
 
 template <int KM>
@@ -1176,6 +1226,30 @@ LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cel
   const uint32_t keep = ~imask;
 #endif
   uint32_t t = 0;
+#if !defined(LOAMX_LEAN_UNPIPELINED)
+  // Software-pipelined form: the batch scanned in trip t was loaded in trip t - 1, so the loads of the next batch are in
+  // flight while this one goes through the collector. The row step for the next batch is therefore decided BEFORE the
+  // current batch is inserted (a bound that is one batch stale: still an upper bound, the search stays exact), and a
+  // visited row's first batch number is t + 1. Two register sets alternate (the loop is unrolled by two), so nothing is
+  // copied. The list entry of row `ri` is fetched from LDS one trip ahead as well.
+  LeanBatch b0 = {}, b1 = {};
+  uint32_t rw = row_scratch[0], rthr = row_scratch[9 * row_stride];
+  bool more = true;
+  for (; t < tmax; t += 2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t tu = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+#else
+    const uint32_t tu = t;
+#endif
+    // (no exit test between the halves: the compiler would sink the first half's loads behind it, next to their use)
+    knn_lean_half_trip<KM>(c, b0, b1, tu, p, e, ri, nv, started, rw, rthr, nrow, row_scratch, row_stride, qx, qy, qz, rel_x, rel_y,
+                           rel_z, keep);
+    more = knn_lean_half_trip<KM>(c, b1, b0, tu + 1u, p, e, ri, nv, started, rw, rthr, nrow, row_scratch, row_stride, qx, qy, qz,
+                                  rel_x, rel_y, rel_z, keep);
+    if (!more) break;
+  }
+  if (more) return -2;  // the trip budget is used up with work left: the queue's business
+#else
   for (; t < tmax; t++) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t tu = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
@@ -1189,7 +1263,7 @@ LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cel
     ri += step ? 1 : 0;
     p = take ? (w & 0xFFFFu) : p, e = take ? (w >> 16) : e;
     if (take) {
-      row_scratch[(18 + nv) * row_stride] = (w & 0xFFFFu) | (tu << 16);
+      row_scratch[nv * row_stride] = (w & 0xFFFFu) | (tu << 16);
       nv++;
       started |= 1ull << tu;
     }
@@ -1202,10 +1276,13 @@ LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cel
       p += 4u;
     }
   }
+#endif
 #if defined(LOAMX_KNN_STATS)
   g_lean_trips = t, g_lean_nrow = (uint32_t)nrow, g_lean_taken = (uint32_t)nv;
 #endif
+#if defined(LOAMX_LEAN_UNPIPELINED)
   if (p < e || ri < nrow) return -2;  // the trip budget is used up with rows still to look at: the queue's business
+#endif
   // ---- is the search over after the 3x3x3 block? (same test as knn_done, with the rigorous bound)
   {
     double guard = kDblMax;
@@ -1227,23 +1304,35 @@ LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cel
     const bool done = guard == kDblMax || knn_bound32(c, a, imask) < guard * guard || (max_dist > 0.0 && guard >= max_dist);
     if (!done) return -1;
   }
-  // ---- exact verification of the k selected candidates
+  // ---- exact verification of the k selected candidates. Three passes, each unconditional over the KM slots, so that
+  // the list reads, then the 2 * KM point loads, are all in flight together (as five branches they were five round trips)
   int count = 0, kept = 0;
   bool undecided = false, open = true;
   double prev = -1.0, d5 = 0.0;
+  uint32_t vrow[KM];
+#pragma unroll
+  for (int i = 0; i < KM; i++) {
+    const uint32_t tb = (c.key[i] & imask) >> 2;
+    const int ord = knn_popcount64(started & ((2ull << tb) - 1ull)) - 1;  // the visited row this batch belongs to
+    vrow[i] = row_scratch[(ord < 0 ? 0 : (ord > 8 ? 8 : ord)) * row_stride];
+  }
+  GridPoint tp[KM];
+#pragma unroll
+  for (int i = 0; i < KM; i++) {
+    const uint32_t key = c.key[i];
+    const bool real = i >= KM - k && key != 0xFFFFFFFFu;
+    const uint32_t tb = (key & imask) >> 2, ii = key & 3u;
+    const uint32_t pp = real ? (vrow[i] & 0xFFFFu) + (tb - (vrow[i] >> 16)) * 4u + ii : 0u;
+    pos[i] = pp;
+    tp[i] = sp[pp < g.n_points ? pp : 0u];
+  }
 #pragma unroll
   for (int i = 0; i < KM; i++) {
     const uint32_t key = c.key[i];
     const bool real = i >= KM - k && key != 0xFFFFFFFFu;
     if (real) {
       if (key >= 0x7F800000u) undecided = true;
-      const uint32_t tb = (key & imask) >> 2, ii = key & 3u;
-      const int ord = knn_popcount64(started & ((2ull << tb) - 1ull)) - 1;  // the visited row this batch belongs to
-      const uint32_t v = row_scratch[(18 + (ord < 0 ? 0 : ord)) * row_stride];
-      const uint32_t pp = (v & 0xFFFFu) + (tb - (v >> 16)) * 4u + ii;
-      pos[i] = pp;
-      const GridPoint tp = sp[pp];
-      const double dx = q.x - tp.x, dy = q.y - tp.y, dz = q.z - tp.z;
+      const double dx = q.x - tp[i].x, dy = q.y - tp[i].y, dz = q.z - tp[i].z;
       const double d2 = dx * dx + dy * dy + dz * dz;  // as knn_scan_batch
       if (!(d2 > prev)) undecided = true;             // a tie or an inversion: the exact order is not this one
       if (!(d2 <= kDblMax)) undecided = true;

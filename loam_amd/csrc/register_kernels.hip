@@ -720,7 +720,7 @@ __global__ __launch_bounds__(kAssocThreads) void associate_knn_exact_kernel(RegB
 
 // fitLine / fitPlane on the neighbours of query i of `pair` and its association record; the neighbour
 // count and positions are read at index nidx of the (1 + KM)-field array nnsrc. Returns "valid".
-template <bool PLANE, int KM>
+template <bool PLANE, int KM, bool QUEUED = false>
 __device__ __forceinline__ bool fit_one(const RegBatch& B, const RegConfig& C, const PairState& S, size_t pair, uint32_t i,
                                         const uint32_t* __restrict__ nnsrc, size_t nidx) {
   const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
@@ -736,18 +736,21 @@ __device__ __forceinline__ bool fit_one(const RegBatch& B, const RegConfig& C, c
   double prim[6] = {0, 0, 0, 0, 0, 0};
   uint32_t nearest = 0xFFFFFFFFu;
   bool valid = false;
+  // The KM positions, then the KM points, fetched unconditionally (slots past `kept` hold position 0 or a stale but
+  // valid one; clamped to the set's capacity anyway): two round trips for the lane instead of one or two per neighbour
+  // behind a branch each.
+  uint32_t at[KM];
+#pragma unroll
+  for (int j = 0; j < KM; j++) at[j] = shift + j < KM ? nnsrc[(size_t)(1 + shift + j) * field + nidx] : 0u;
+  if (!QUEUED && kept == -1) return false;  // 0xFFFFFFFF: round 1 queued this query, associate_fit_queued_kernel writes its record
+  GridPoint tp[KM];
+#pragma unroll
+  for (int j = 0; j < KM; j++) tp[j] = sp[at[j] < (uint32_t)gs.stride ? at[j] : 0u];
   if (kept >= (PLANE ? C.min_plane_pts : C.min_line_pts)) {  // registration.cpp:39 / :80
     Vec3 nb[KM];
 #pragma unroll
-    for (int j = 0; j < KM; j++) {
-      if (j < kept) {
-        const GridPoint t = sp[nnsrc[(1 + shift + j) * field + nidx]];
-        nb[j] = v3(t.x, t.y, t.z);
-        if (j == 0) nearest = t.orig;
-      } else {
-        nb[j] = v3(0, 0, 0);
-      }
-    }
+    for (int j = 0; j < KM; j++) nb[j] = j < kept ? v3(tp[j].x, tp[j].y, tp[j].z) : v3(0, 0, 0);
+    if (kept > 0) nearest = tp[0].orig;
     if (PLANE) {
       Vec3 nrm;
       double d;
@@ -790,7 +793,7 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_FIT_WAVES) void associate_fit_
   const uint32_t n_src = PLANE ? B.n_src_planar[pair * B.in_pitch] : B.n_src_edge[pair * B.in_pitch];
   const uint32_t* __restrict__ nn = PLANE ? B.assoc.nn_plane : B.assoc.nn_edge;
   bool valid = false;
-  if (i < n_src && i < stride && nn[pair * stride + i] != 0xFFFFFFFFu) valid = fit_one<PLANE, KM>(B, C, S, pair, i, nn, pair * stride + i);
+  if (i < n_src && i < stride) valid = fit_one<PLANE, KM>(B, C, S, pair, i, nn, pair * stride + i);  // (queued queries: skipped inside)
   const unsigned long long m = __ballot(valid);
   if ((threadIdx.x & 63) == 0) s_count[threadIdx.x >> 6] = (uint32_t)__popcll(m);
   __syncthreads();
@@ -817,7 +820,7 @@ __global__ __launch_bounds__(kRestThreads) void associate_fit_queued_kernel(RegB
   const uint32_t* __restrict__ rest = (PLANE ? B.assoc.rest_plane : B.assoc.rest_edge) + pair * stride;
   uint32_t count = 0;
   for (uint32_t t = chunk0 * kRestThreads + threadIdx.x; t < queued; t += blocks_per_pair * kRestThreads)
-    count += fit_one<PLANE, KM>(B, C, S, pair, rest[t] & 0x7FFFFFFFu, rnn, pair * stride + t) ? 1u : 0u;
+    count += fit_one<PLANE, KM, true>(B, C, S, pair, rest[t] & 0x7FFFFFFFu, rnn, pair * stride + t) ? 1u : 0u;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) count += __shfl_xor(count, off);
   if ((threadIdx.x & 63) == 0 && count) atomicAdd(&B.assoc.n_assoc[8 * pair + (PLANE ? 1 : 0)], count);
