@@ -397,15 +397,20 @@ int enqueue_icf_iteration(loamx_ctx* ctx, const RegBatch& B, const RegConfig& C,
       TimedScope t(ctx, LOAMX_K_MOMENT, 0.0, true);
       launch_moments(B, s);
     }
-    for (int k = 0; k < 5; k++) {  // iteration-0 evaluation + max_num_iterations = 4 candidates
-      {
-        TimedScope t(ctx, LOAMX_K_SWEEP, 0.0, true);
-        launch_sweep(B, s);
-      }
-      {
-        TimedScope t(ctx, LOAMX_K_LM, 0.0, true);
-        if (it > 0) launch_sweep_light(B, s);  // (no pair is on moments in the first ICF iteration)
-        launch_lm_step(B, s);
+    if (it > 0) {
+      // one workgroup per pair runs the whole solve off the moments (and streams by itself whatever they cannot cover)
+      TimedScope t(ctx, LOAMX_K_LM, 0.0, true);
+      launch_lm_pair_loop(B, s);
+    } else {
+      for (int k = 0; k < 5; k++) {  // iteration-0 evaluation + max_num_iterations = 4 candidates
+        {
+          TimedScope t(ctx, LOAMX_K_SWEEP, 0.0, true);
+          launch_sweep(B, s);
+        }
+        {
+          TimedScope t(ctx, LOAMX_K_LM, 0.0, true);
+          launch_lm_step(B, s);
+        }
       }
     }
     CHECK_LAUNCH(ctx, "sweep/lm kernels");

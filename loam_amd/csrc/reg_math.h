@@ -1089,6 +1089,11 @@ LOAMX_HD int knn_f32_round1_body(const GridDesc& g, const GridPoint* __restrict_
  * Per-thread list: kLeanRowWords words ([word][thread] in LDS): 9 row ranges, 9 thresholds; the visited list overwrites
  * the row ranges from the front (entry nv <= the index of the row being taken, whose range is in a register by then).
  * ---------------------------------------------------------------------------------------------- */
+#if defined(LOAMX_KNN_STATS)
+#define LOAMX_LEAN_REASON(r) (g_lean_reason = (r))
+#else
+#define LOAMX_LEAN_REASON(r) ((void)0)
+#endif
 constexpr int kLeanRowWords = 18;
 constexpr uint32_t kLeanMaxPoints = 65535u;  // positions are packed as 16-bit halves
 
@@ -1155,7 +1160,7 @@ LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cel
   const int32_t cz = grid_cell_coord(q.z, g.oz, g.inv_h);
   const int32_t out = grid_outside_distance(g, cx, cy, cz);
   if (max_dist > 0.0 && out >= 1 && (double)(out - 1) * g.h >= max_dist) return 0;
-  if (out > 1) return -1;
+  if (out > 1) { LOAMX_LEAN_REASON(3); return -1; }
   const double a = knn_f32_err_unit(g);
   const double r2 = knn_radius_bound(max_dist);
   const float qx = (float)(q.x - g.ox), qy = (float)(q.y - g.oy), qz = (float)(q.z - g.oz);
@@ -1302,7 +1307,7 @@ LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cel
     }
     if (guard < 0.0) guard = 0.0;
     const bool done = guard == kDblMax || knn_bound32(c, a, imask) < guard * guard || (max_dist > 0.0 && guard >= max_dist);
-    if (!done) return -1;
+    if (!done) { LOAMX_LEAN_REASON(1); return -1; }
   }
   // ---- exact verification of the k selected candidates. Three passes, each unconditional over the KM slots, so that
   // the list reads, then the 2 * KM point loads, are all in flight together (as five branches they were five round trips)
@@ -1356,6 +1361,7 @@ LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cel
     const double err = 2.0 * (3.4641016151377544 * a * sd5 + 3.0 * a * a + 2.384185791015625e-7 * d5);  // x2 safety
     if (!(t6 > d5 + err)) undecided = true;
   }
+  if (undecided) LOAMX_LEAN_REASON(2);
   return undecided ? -1 : kept;
 }
 

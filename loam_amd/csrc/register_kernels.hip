@@ -876,8 +876,8 @@ __global__ __launch_bounds__(kSweepThreads, LOAMX_SWEEP_WAVES) void sweep_kernel
   for (int j = 0; j < kAccSize; j++) acc[j] = 0.0;
   // the slot space of a pair is [edges 0..n_se) ++ [planes 0..n_sp); chunk `blk` of it. A pair whose moment
   // matrix can stand in for its plane records at this point (reg_math.h: "Plane residuals through moments") is
-  // left to sweep_light_kernel.
-  if (S.stream_planes == 0u) return;  // uniform: sweep_light_kernel evaluates this pair (moments + listed records)
+  // left to lm_pair_loop_kernel.
+  if (S.stream_planes == 0u) return;  // uniform (moments + listed records)
   const uint32_t total = n_se + n_sp;
   const uint32_t base = blk * kSweepChunk;
   if (base >= total) return;  // uniform per workgroup
@@ -944,29 +944,23 @@ __global__ __launch_bounds__(kSweepThreads, LOAMX_SWEEP_WAVES) void sweep_kernel
   }
 }
 
-/* The sweep of a pair that is on moments: one workgroup evaluates its edge records and the listed
- * (far-from-plane) plane records one by one, adds the plane terms of all other records from the moment
- * matrix (the 13x7 products M [Z | phi] spread over the threads), and writes the pair's single partial. */
-__global__ __launch_bounds__(kSweepThreads) void sweep_light_kernel(RegBatch B) {
-  __shared__ double s_part[kSweepThreads / 64][kAccSize];
-  __shared__ double s_T[kMomDim][7], s_Z[kMomDim][7];
-  const size_t pair = blockIdx.x;
-  const PairState& S = B.state[pair];
-  if (!S.active || !S.lm.active || S.stream_planes != 0u) return;  // uniform per workgroup
-  double x[7];
-#pragma unroll
-  for (int i = 0; i < 7; i++) x[i] = S.lm.xeval[i];
-  const uint32_t n_se_raw = B.n_src_edge[pair * B.in_pitch], n_sp_raw = B.n_src_planar[pair * B.in_pitch];
-  const uint32_t n_se = n_se_raw < B.edge_stride ? n_se_raw : (uint32_t)B.edge_stride;
-  const uint32_t n_sp = n_sp_raw < B.planar_stride ? n_sp_raw : (uint32_t)B.planar_stride;
+/* The evaluation of a pair that is on moments, by ONE WAVEFRONT: its edge records and the listed (far-from-plane)
+ * plane records one by one, plus the plane terms of all other records from the moment matrix (the 13x7 products
+ * M [Z | phi] spread over the lanes). Lanes 0..kAccSize-1 return their entry of the pair's partial. `mom` is in LDS. */
+struct LightLds {
+  double T[kMomDim][7], Z[kMomDim][7];
+};
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ double light_eval(const RegBatch& B, size_t pair, const double x[7], uint32_t n_se, uint32_t n_sp,
+                                             const double* mom, LightLds& L) {
+  const int lane = threadIdx.x;  // (64-thread workgroup)
   const size_t efield = B.n_pairs * B.edge_stride, pfield = B.n_pairs * B.planar_stride;
   const double* __restrict__ E = B.assoc.edge + pair * B.edge_stride;
   const double* __restrict__ Pl = B.assoc.plane + pair * B.planar_stride;
-  if (threadIdx.x == 0 && B.sweep_slots) atomicAdd(&B.sweep_slots[0], (unsigned long long)n_se);
   double acc[kAccSize];
 #pragma unroll
   for (int j = 0; j < kAccSize; j++) acc[j] = 0.0;
-  for (uint32_t v = threadIdx.x; v < n_se; v += kSweepThreads) {
+  for (uint32_t v = lane; v < n_se; v += 64) {
     const double f0 = E[v];
     if (f0 == f0) {  // NaN in field 0 marks an invalid slot
       double prim[6];
@@ -978,28 +972,24 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_light_kernel(RegBatch B) 
   for (uint32_t lb = 0; lb < B.mom_blocks_per_pair * 4 && (lb / 4) * kSweepChunk < n_sp; lb++) {
     const uint32_t cnt = B.flagged_count[pair * B.mom_blocks_per_pair * 4 + lb];
     const uint32_t* __restrict__ fl = B.flagged_list + (pair * B.mom_blocks_per_pair * 4 + lb) * (size_t)(kSweepChunk / 4);
-    for (uint32_t k = threadIdx.x; k < cnt; k += kSweepThreads) {
+    for (uint32_t k = lane; k < cnt; k += 64) {
       const uint32_t q = fl[k];
       const double prim[6] = {Pl[3 * pfield + q], Pl[4 * pfield + q], Pl[5 * pfield + q], Pl[6 * pfield + q], 0.0, 0.0};
       residual_accumulate(true, v3(Pl[q], Pl[pfield + q], Pl[2 * pfield + q]), prim, x, acc);
     }
   }
+  // every lane ends up with the wavefront's sums (xor butterfly: the same value in every lane, fixed order)
 #pragma unroll
   for (int j = 0; j < kAccSize; j++) {
     double v = acc[j];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off);
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
     acc[j] = v;
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) {
-#pragma unroll
-    for (int j = 0; j < kAccSize; j++) s_part[wave][j] = acc[j];
-  }
   // ---- plane terms from the moments: [Z | phi] (13 x 7), T = M [Z | phi], then Z^T T
-  const double* __restrict__ mom = B.moments + pair * (size_t)(kMomSize + 2);
-  if (threadIdx.x < kMomDim * 7) {
-    const int j = threadIdx.x / 7, a = threadIdx.x % 7;
+  wave_lds_fence();  // (L may still be read from the previous evaluation)
+  for (int idx = lane; idx < kMomDim * 7; idx += 64) {
+    const int j = idx / 7, a = idx % 7;
     const double ux = x[0], uy = x[1], uz = x[2], w = x[3];
     double val;
     if (a == 6) {  // phi_j
@@ -1030,21 +1020,24 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_light_kernel(RegBatch B) 
       const double z2 = g[0] * (-Zq) + g[1] * (-Y) + g[2] * X + g[3] * W;
       val = a == 0 ? z0 : (a == 1 ? z1 : (a == 2 ? z2 : ((j == 10 + (a - 3)) ? 1.0 : 0.0)));
     }
-    s_Z[j][a] = val;
+    L.Z[j][a] = val;
   }
-  __syncthreads();
-  if (threadIdx.x < kMomDim * 7) {
-    const int i = threadIdx.x / 7, a = threadIdx.x % 7;
+  wave_lds_fence();
+  for (int idx = lane; idx < kMomDim * 7; idx += 64) {
+    const int i = idx / 7, a = idx % 7;
     double t = 0.0;
 #pragma unroll
-    for (int j = 0; j < kMomDim; j++) t += mom[i * kMomStride + j] * s_Z[j][a];
-    s_T[i][a] = t;
+    for (int j = 0; j < kMomDim; j++) t += mom[i * kMomStride + j] * L.Z[j][a];
+    L.T[i][a] = t;
   }
-  __syncthreads();
-  if (threadIdx.x < kAccSize) {
-    const int o = threadIdx.x;
-    double v = s_part[0][o];
-    for (int wv = 1; wv < kSweepThreads / 64; wv++) v += s_part[wv][o];
+  wave_lds_fence();
+  double v = 0.0;
+  if (lane < kAccSize) {
+    const int o = lane;
+    v = 0.0;
+#pragma unroll
+    for (int j = 0; j < kAccSize; j++)
+      if (j == o) v = acc[j];
     // plane terms: o < 21: (Z^T T)[a][b]; 21..26: Z^T (M phi); 27: phi . (M phi) / 2; 28: non-finite flag
     if (o < 21) {
       int a = 0, rem = o;
@@ -1052,23 +1045,72 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_light_kernel(RegBatch B) 
       const int b = a + rem;
       double sum = 0.0;
 #pragma unroll
-      for (int i = 0; i < kMomDim; i++) sum += s_Z[i][a] * s_T[i][b];
+      for (int i = 0; i < kMomDim; i++) sum += L.Z[i][a] * L.T[i][b];
       v += sum;
     } else if (o < 27) {
       const int a = o - 21;
       double sum = 0.0;
 #pragma unroll
-      for (int i = 0; i < kMomDim; i++) sum += s_Z[i][a] * s_T[i][6];
+      for (int i = 0; i < kMomDim; i++) sum += L.Z[i][a] * L.T[i][6];
       v += sum;
     } else {
       double cost = 0.0;
 #pragma unroll
-      for (int i = 0; i < kMomDim; i++) cost += s_Z[i][6] * s_T[i][6];
+      for (int i = 0; i < kMomDim; i++) cost += L.Z[i][6] * L.T[i][6];
       if (o == 27) v += 0.5 * cost;
       else if (!(cost - cost == 0.0)) v += 1.0;
     }
-    B.partials[(pair * B.blocks_per_pair) * kAccSize + o] = v;
   }
+  return v;
+}
+
+/* All association records of a pair streamed by one wavefront (an evaluation its moments cannot stand in for: the
+ * candidate has left their validity bound — rare). Lanes 0..kAccSize-1 return their entry of the sums. */
+__device__ __forceinline__ double stream_eval_wave(const RegBatch& B, size_t pair, const double x[7], uint32_t n_se, uint32_t n_sp) {
+  const int lane = threadIdx.x;
+  const size_t efield = B.n_pairs * B.edge_stride, pfield = B.n_pairs * B.planar_stride;
+  const double* __restrict__ E = B.assoc.edge + pair * B.edge_stride;
+  const double* __restrict__ Pl = B.assoc.plane + pair * B.planar_stride;
+  double acc[kAccSize];
+#pragma unroll
+  for (int j = 0; j < kAccSize; j++) acc[j] = 0.0;
+  for (uint32_t v = lane; v < n_se; v += 64) {
+    const double f0 = E[v];
+    if (f0 == f0) {
+      double prim[6];
+#pragma unroll
+      for (int f = 0; f < 6; f++) prim[f] = E[(3 + f) * efield + v];
+      residual_accumulate(false, v3(f0, E[efield + v], E[2 * efield + v]), prim, x, acc);
+    }
+  }
+  for (uint32_t q = lane; q < n_sp; q += 64) {
+    const double f0 = Pl[q];
+    if (f0 == f0) {
+      const double prim[6] = {Pl[3 * pfield + q], Pl[4 * pfield + q], Pl[5 * pfield + q], Pl[6 * pfield + q], 0.0, 0.0};
+      residual_accumulate(true, v3(f0, Pl[pfield + q], Pl[2 * pfield + q]), prim, x, acc);
+    }
+  }
+  double mine = 0.0;
+#pragma unroll
+  for (int j = 0; j < kAccSize; j++) {
+    double v = acc[j];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == j) mine = v;
+  }
+  return mine;
+}
+
+// the reduction of a pair's partials is done: one Levenberg-Marquardt bookkeeping step, and whether the moments can
+// stand in for the plane records at the next candidate
+__device__ __forceinline__ void lm_step_pair(const RegBatch& B, size_t pair, PairState& S, const double* acc) {
+  const double* __restrict__ mom = B.moments + pair * (size_t)(kMomSize + 2);
+  LmState lm = S.lm;
+  lm_consume(lm, acc, S.first_sweep != 0);
+  S.lm = lm;
+  S.first_sweep = 0;
+  // the next sweep: may the moments stand in for the plane records at the new candidate?
+  S.stream_planes = (!S.use_moments || (lm.active && !plane_moments_valid_at(mom[kMomSize], mom[kMomSize + 1], lm.xeval))) ? 1u : 0u;
 }
 
 __global__ __launch_bounds__(64) void lm_step_kernel(RegBatch B) {  // one wavefront: the 6x6 solve may use the whole register file
@@ -1086,13 +1128,79 @@ __global__ __launch_bounds__(64) void lm_step_kernel(RegBatch B) {  // one wavef
     const double* __restrict__ p = B.partials + (pair * B.blocks_per_pair + b) * kAccSize;
     for (int j = 0; j < kAccSize; j++) acc[j] += p[j];
   }
-  const double* __restrict__ mom = B.moments + pair * (size_t)(kMomSize + 2);
-  LmState lm = S.lm;
-  lm_consume(lm, acc, S.first_sweep != 0);
-  S.lm = lm;
-  S.first_sweep = 0;
-  // the next sweep: may the moments stand in for the plane records at the new candidate?
-  S.stream_planes = (!S.use_moments || (lm.active && !plane_moments_valid_at(mom[kMomSize], mom[kMomSize + 1], lm.xeval))) ? 1u : 0u;
+  lm_step_pair(B, pair, S, acc);
+}
+
+/* The whole Levenberg-Marquardt solve of one ICF iteration for a pair whose plane records are summarised by moments
+ * (every ICF iteration but the first), by ONE WAVEFRONT in ONE launch: the moment tiles of the pair are added up,
+ * then up to five times { evaluate at the candidate, bookkeeping step }. Before, that was moment_finish + 5 x
+ * { sweep_kernel (nothing to do), sweep_light_kernel, lm_step_kernel }: sixteen dependent launches of a few
+ * microseconds each, 9-10 us apart (0.39 ms per ICF iteration). One wavefront per pair because the bookkeeping step
+ * (a 6x6 Cholesky unrolled in registers) wants most of the register file: at one wavefront per SIMD a chip still
+ * holds 1 024 pairs at once. An evaluation the moments cannot stand in for (the candidate leaves their validity bound)
+ * is streamed by the same wavefront: rare, slow, self-contained. From the second ICF iteration on this kernel is the
+ * only evaluator, so a pair's result does not depend on the batch it is in. */
+__global__ __launch_bounds__(64) void lm_pair_loop_kernel(RegBatch B) {
+  __shared__ LightLds L;
+  __shared__ double s_mom[kMomSize + 2];
+  __shared__ double s_acc[kAccSize];
+  const int lane = threadIdx.x;
+  const size_t pair = blockIdx.x;
+  PairState& S = B.state[pair];
+  if (!S.active || !S.lm.active) return;  // uniform
+  const uint32_t n_se_raw = B.n_src_edge[pair * B.in_pitch], n_sp_raw = B.n_src_planar[pair * B.in_pitch];
+  const uint32_t n_se = n_se_raw < B.edge_stride ? n_se_raw : (uint32_t)B.edge_stride;
+  const uint32_t n_sp = n_sp_raw < B.planar_stride ? n_sp_raw : (uint32_t)B.planar_stride;
+  // ---- the pair's moment matrix: its wavefront tiles in a fixed order
+  uint32_t stream = 1u;
+  if (S.use_moments) {
+    uint32_t used = (n_sp + kSweepChunk - 1) / kSweepChunk;
+    used = used < B.mom_blocks_per_pair ? used : B.mom_blocks_per_pair;
+    const double* __restrict__ part = B.mom_partials + pair * B.mom_blocks_per_pair * 4 * (size_t)(kMomSize + 2);
+    double* __restrict__ mom = B.moments + pair * (size_t)(kMomSize + 2);
+    double v[kMomSize / 64];
+#pragma unroll
+    for (int c = 0; c < kMomSize / 64; c++) v[c] = 0.0;
+    double s0max = 0.0, v2max = 0.0;
+    for (uint32_t t = 0; t < used * 4; t++) {
+#pragma unroll
+      for (int c = 0; c < kMomSize / 64; c++) v[c] += part[t * (size_t)(kMomSize + 2) + c * 64 + lane];
+      s0max = fmax(s0max, part[t * (size_t)(kMomSize + 2) + kMomSize]);  // (uniform loads)
+      v2max = fmax(v2max, part[t * (size_t)(kMomSize + 2) + kMomSize + 1]);
+    }
+#pragma unroll
+    for (int c = 0; c < kMomSize / 64; c++) mom[c * 64 + lane] = v[c], s_mom[c * 64 + lane] = v[c];
+    if (lane == 0) mom[kMomSize] = s0max, mom[kMomSize + 1] = v2max, s_mom[kMomSize] = s0max, s_mom[kMomSize + 1] = v2max;
+    const double ident[7] = {0, 0, 0, 1, 0, 0, 0};
+    stream = plane_moments_valid_at(s0max, v2max, ident) ? 0u : 1u;
+  }
+  if (lane == 0) S.stream_planes = stream;
+  uint32_t lm_active = 1u;
+  double x[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) x[i] = S.lm.xeval[i];
+  wave_lds_fence();
+  for (int k = 0; k < 5 && lm_active; k++) {  // iteration-0 evaluation + max_num_iterations = 4 candidates
+    const double v = stream ? stream_eval_wave(B, pair, x, n_se, n_sp) : light_eval(B, pair, x, n_se, n_sp, s_mom, L);
+    if (lane < kAccSize) s_acc[lane] = 0.0 + v;
+    wave_lds_fence();
+    if (lane == 0) {
+      double acc[kAccSize];
+      for (int j = 0; j < kAccSize; j++) acc[j] = s_acc[j];
+      lm_step_pair(B, pair, S, acc);
+    }
+    wave_lds_fence();
+    // (lane 0's stores to S, read back by every lane: same wavefront, program order)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    lm_active = __builtin_amdgcn_readfirstlane((int)(lane == 0 ? S.lm.active : 0u));
+    stream = __builtin_amdgcn_readfirstlane((int)(lane == 0 ? S.stream_planes : 0u));
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+      const double xi = lane == 0 ? S.lm.xeval[i] : 0.0;
+      x[i] = __longlong_as_double(((long long)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(xi) >> 32)) << 32) |
+                                  (unsigned int)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(xi) & 0xFFFFFFFFll)));
+    }
+  }
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -1102,7 +1210,7 @@ __global__ __launch_bounds__(64) void lm_step_kernel(RegBatch B) {  // one wavef
  * Every lane loads one record (coalesced), computes its 13 coefficients, stages them in its wavefront's
  * LDS tile, and the wavefront then issues 16 MFMAs over the 64 staged records (lane l feeds c[l % 16]
  * of record 4 t + l / 16 as both operands). Same chunking as sweep_kernel; every wavefront writes its
- * 16x16 tile, moment_finish_kernel adds the tiles of a pair in a fixed order.
+ * 16x16 tile, lm_pair_loop_kernel adds the tiles of a pair in a fixed order.
  * ---------------------------------------------------------------------------------------------- */
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int kMomLdsRow = 65;  // 64 records + 1: the 16 rows of a tile start in different banks
@@ -1195,35 +1303,6 @@ __global__ __launch_bounds__(64) void moment_kernel(RegBatch B) {  // one wavefr
 
 // one workgroup per pair: fixed-order sum of the wavefront tiles, the two maxima, and whether the first
 // sweep (x = identity) may use the moments
-__global__ __launch_bounds__(kMomSize) void moment_finish_kernel(RegBatch B) {
-  const size_t pair = blockIdx.x;
-  PairState& S = B.state[pair];
-  if (!S.active || !S.lm.active) return;  // uniform
-  if (!S.use_moments) {
-    if (threadIdx.x == 0) S.stream_planes = 1;
-    return;
-  }
-  const uint32_t n_sp_raw = B.n_src_planar[pair * B.in_pitch];
-  const uint32_t n_sp = n_sp_raw < B.planar_stride ? n_sp_raw : (uint32_t)B.planar_stride;
-  uint32_t used = (n_sp + kSweepChunk - 1) / kSweepChunk;
-  used = used < B.mom_blocks_per_pair ? used : B.mom_blocks_per_pair;
-  const double* __restrict__ part = B.mom_partials + pair * B.mom_blocks_per_pair * 4 * (size_t)(kMomSize + 2);
-  double* __restrict__ mom = B.moments + pair * (size_t)(kMomSize + 2);
-  double v = 0.0;
-  for (uint32_t t = 0; t < used * 4; t++) v += part[t * (size_t)(kMomSize + 2) + threadIdx.x];
-  mom[threadIdx.x] = v;
-  if (threadIdx.x == 0) {
-    double s0max = 0.0, v2max = 0.0;
-    for (uint32_t t = 0; t < used * 4; t++) {
-      s0max = fmax(s0max, part[t * (size_t)(kMomSize + 2) + kMomSize]);
-      v2max = fmax(v2max, part[t * (size_t)(kMomSize + 2) + kMomSize + 1]);
-    }
-    mom[kMomSize] = s0max, mom[kMomSize + 1] = v2max;
-    const double ident[7] = {0, 0, 0, 1, 0, 0, 0};
-    S.stream_planes = plane_moments_valid_at(s0max, v2max, ident) ? 0u : 1u;
-  }
-}
-
 __global__ void outer_update_kernel(RegBatch B, RegConfig C) {
   const size_t pair = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pair >= B.n_pairs) return;
@@ -1468,15 +1547,14 @@ void launch_sweep(const RegBatch& B, hipStream_t s) {
 }
 
 // the same evaluation for the pairs that are on moments (timed with the LM kernels: it streams next to nothing)
-void launch_sweep_light(const RegBatch& B, hipStream_t s) {
+void launch_lm_pair_loop(const RegBatch& B, hipStream_t s) {
   if (B.n_pairs == 0 || B.blocks_per_pair == 0) return;
-  launch_kernel(sweep_light_kernel, dim3((unsigned)B.n_pairs), dim3(kSweepThreads), 0, s, B);
+  launch_kernel(lm_pair_loop_kernel, dim3((unsigned)B.n_pairs), dim3(64), 0, s, B);
 }
 
 void launch_moments(const RegBatch& B, hipStream_t s) {
   if (B.n_pairs == 0 || B.mom_blocks_per_pair == 0) return;
-  launch_kernel(moment_kernel, dim3((unsigned)(B.n_pairs * B.mom_blocks_per_pair * 4)), dim3(64), 0, s, B);
-  launch_kernel(moment_finish_kernel, dim3((unsigned)B.n_pairs), dim3(kMomSize), 0, s, B);
+  launch_kernel(moment_kernel, dim3((unsigned)(B.n_pairs * B.mom_blocks_per_pair * 4)), dim3(64), 0, s, B);  // (tiles added up by lm_pair_loop_kernel)
 }
 
 void launch_lm_step(const RegBatch& B, hipStream_t s) {

@@ -14,7 +14,7 @@
 // search statistics (candidates / rows visited) for tools/knn_stats.py
 #define LOAMX_KNN_STATS 1
 static uint64_t g_cand = 0, g_rows = 0, g_general = 0;
-static uint32_t g_lean_trips = 0, g_lean_nrow = 0, g_lean_taken = 0;
+static uint32_t g_lean_trips = 0, g_lean_nrow = 0, g_lean_taken = 0, g_lean_reason = 0;
 #define LOAMX_STL_SORT_STATS 1
 static uint64_t g_heap_sorts = 0;  // times stl_sort fell back to heap sort (depth limit)
 
@@ -467,12 +467,12 @@ void hostcheck_lean_stats(const double* pts, uint64_t n, const double* queries, 
   const double pass = knn_radius_pass_max(max_dist);
   for (uint64_t i = 0; i < nq; i++) {
     uint32_t rows[kLeanRowWords], pos[8];
-    g_cand = 0, g_lean_trips = g_lean_nrow = g_lean_taken = 0;
+    g_cand = 0, g_lean_trips = g_lean_nrow = g_lean_taken = g_lean_reason = 0;
     const Vec3 q = v3(queries[3 * i], queries[3 * i + 1], queries[3 * i + 2]);
     const int r = knn_lean_round1<5>(G.g, G.cell_start.data(), G.sp.data(), G.rel.data(), (uint32_t)G.sp.size(), q, (int)k,
                                      max_dist, pass, pos, rows, 1);
     out[5 * i] = g_lean_trips, out[5 * i + 1] = g_lean_nrow, out[5 * i + 2] = g_lean_taken, out[5 * i + 3] = (uint32_t)g_cand;
-    out[5 * i + 4] = (uint32_t)(r + 2);
+    out[5 * i + 4] = (uint32_t)(r + 2) | (g_lean_reason << 8);
   }
 }
 
