@@ -356,7 +356,7 @@ __global__ __launch_bounds__(WAVES * 64) void select_kernel(const double* __rest
  * ---------------------------------------------------------------------------------------------- */
 // LDS bytes per wavefront: padded curvature (W + 64 doubles), 64 or 128 pick slots (double + int), padded mask
 __host__ __device__ inline size_t select_mis_lds_bytes(int W, int slots) {
-  return ((size_t)W + 64) * 8 + (size_t)slots * 12 + (((size_t)W + 256 + 7) & ~(size_t)7);
+  return ((size_t)W + 64) * 8 + (size_t)slots * 12;
 }
 // picks a sector can yield (they are at least R + 1 points apart): 64 slots, or 128 for the long sectors of
 // 2048-column scans (then only with caps <= 64: the lanes hold the first 64 picks of the order)
@@ -686,16 +686,16 @@ __device__ __forceinline__ void fused_copy(const T* __restrict__ scan_xyz, uint3
 // Returns true iff the line was marked as tied (replay_kernel redoes it and needs its curvature / mask in global memory).
 template <int R, bool TWO>
 __device__ __forceinline__ bool select_line(int lane, size_t line, int W, int CH, uint32_t ch_magic, double* s_c, double* m_c, int32_t* m_i,
-                                            uint8_t* s_v, const ExtractParams& P, const ExtractStage& st, const ExtractFused& fz) {
+                                            uint64_t V, const ExtractParams& P, const ExtractStage& st, const ExtractFused& fz) {
+  // V: validity of the lane's chunk, bit j = point lane * CH + j (bits of points past the line's end are 0)
   constexpr int slots = TWO ? 128 : 64;
   const int base = lane * CH;
-  const int pbase = lane * (CH + 1), vbase = lane * (CH + 4);
-  uint64_t V = 0, ET = 0, PT = 0, gt[R], eqm[R];
+  const int pbase = lane * (CH + 1);
+  uint64_t ET = 0, PT = 0, gt[R], eqm[R];
   for (int j = 0; j < CH; j++) {
     const int i = base + j;
     if (i < W) {
       const double c = s_c[pbase + j];
-      V |= (uint64_t)(s_v[vbase + j] != 0) << j;
       ET |= (uint64_t)(c > P.edge_thr) << j;
       PT |= (uint64_t)(c < P.planar_thr) << j;
     }
@@ -871,16 +871,33 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
   double* s_c = reinterpret_cast<double*>(smem + wave * per_wave);
   double* m_c = s_c + W + 64;
   int32_t* m_i = reinterpret_cast<int32_t*>(m_c + slots);
-  uint8_t* s_v = reinterpret_cast<uint8_t*>(m_i + slots);
   // i / CH == umulhi(i, ch_magic) for i < 2^16 when CH >= 2; ch_magic == 0 stands for CH == 1 (i / CH == i)
   const uint32_t ch_magic = CH > 1 ? 0xFFFFFFFFu / (uint32_t)CH + 1u : 0u;
   for (int i = lane; i < W; i += 64) {
     const int owner = ch_magic ? (int)__umulhi((uint32_t)i, ch_magic) : i;
     s_c[i + owner] = curv[line * (size_t)W + i];
-    s_v[i + 4 * owner] = mask[line * (size_t)W + i];
+  }
+  // the validity bytes of the lane's own chunk straight into its bit mask (the selection works on register bit masks:
+  // the bytes need no LDS — 1.3 KB per wavefront less, which is one more wavefront per SIMD)
+  uint64_t V = 0;
+  {
+    const uint8_t* __restrict__ mrow = mask + line * (size_t)W;
+    const int base = lane * CH;
+    if ((CH & 3) == 0 && (W & 3) == 0) {
+      for (int j = 0; j < CH; j += 4) {
+        if (base + j < W) {  // (W and CH are multiples of four: the word is inside the line)
+          const uint32_t w4 = *reinterpret_cast<const uint32_t*>(mrow + base + j);
+          V |= (uint64_t)(((w4 & 0xFFu) != 0u) | (((w4 & 0xFF00u) != 0u) << 1) | (((w4 & 0xFF0000u) != 0u) << 2) |
+                          (((w4 & 0xFF000000u) != 0u) << 3)) << j;
+        }
+      }
+    } else {
+      for (int j = 0; j < CH; j++)
+        if (base + j < W) V |= (uint64_t)(mrow[base + j] != 0) << j;
+    }
   }
   wave_lds_sync();
-  (void)select_line<R, TWO>(lane, line, W, CH, ch_magic, s_c, m_c, m_i, s_v, P, st, fz);
+  (void)select_line<R, TWO>(lane, line, W, CH, ch_magic, s_c, m_c, m_i, V, P, st, fz);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -928,7 +945,10 @@ __global__ __launch_bounds__(64) void extract_fused_kernel(const T* __restrict__
                                   });
   wave_lds_sync();
   // ---- phase 2: selection + compaction
-  if (select_line<R, false>(lane, line, W, CH, ch_magic, s_c, m_c, m_i, s_v, P, st, fz)) {
+  uint64_t V = 0;
+  for (int j = 0; j < CH; j++)
+    if (lane * CH + j < W) V |= (uint64_t)(s_v[lane * (CH + 4) + j] != 0) << j;
+  if (select_line<R, false>(lane, line, W, CH, ch_magic, s_c, m_c, m_i, V, P, st, fz)) {
     // tied: replay_kernel reads the line's curvature and (unselected) mask from the workspace. The mask bytes in LDS
     // are still the input's: the selection works on register bit masks.
     for (int i = lane; i < W; i += 64) {
@@ -1074,7 +1094,11 @@ template <int R, bool TWO>
 static void launch_select_mis2(const double* d_curv, const uint8_t* d_mask, size_t n_lines, const ExtractParams& P,
                                const ExtractStage& st, const ExtractFused& fz, hipStream_t s) {
   const size_t per_wave = select_mis_lds_bytes((int)P.W, TWO ? 128 : 64);
+#if defined(LOAMX_SELECT_ONE_WAVE)
+  if (false) {
+#else
   if (per_wave * 4 <= 48 * 1024) {
+#endif
     launch_kernel((select_mis_kernel<R, 4, TWO>), dim3((unsigned)((n_lines + 3) / 4)), dim3(256), per_wave * 4, s, d_curv,
                        d_mask, n_lines, P, st, fz);
   } else {
@@ -1139,7 +1163,8 @@ bool launch_extract_fused(const void* d_xyz, bool f32, size_t n_scans, const Ext
   const uint32_t longest = P.W - (P.S - 1) * P.pps;
   const uint32_t picks = (longest + R) / (R + 1);
   if (P.np != 3 || !(CH >= R && CH + 2 * R <= 64) || picks > 64 || P.S > 64 || !fz_in.line_tot || (P.W & 1)) return false;
-  const size_t lds = ((Curv2<3, 64>::kLdsBytes + 15) & ~(size_t)15) + select_mis_lds_bytes((int)P.W, 64);
+  const size_t lds = ((Curv2<3, 64>::kLdsBytes + 15) & ~(size_t)15) + select_mis_lds_bytes((int)P.W, 64) +
+                     (((size_t)P.W + 256 + 7) & ~(size_t)7);  // + the line's validity bytes (4 spare per lane chunk)
   if (lds > 64 * 1024) return false;  // (wider lines: the separate kernels)
   ExtractFused fz = fz_in;
   fz.fuse = 1u;
