@@ -438,8 +438,8 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   B.init = in.init;
   ENSURE(ctx, WS_GRID_DESC_E, np * sizeof(GridDesc));
   ENSURE(ctx, WS_GRID_DESC_P, np * sizeof(GridDesc));
-  ENSURE(ctx, WS_CELLS_E, np * (size_t)(kGridCellsCap + 1) * sizeof(uint32_t));
-  ENSURE(ctx, WS_CELLS_P, np * (size_t)(kGridCellsCap + 1) * sizeof(uint32_t));
+  ENSURE(ctx, WS_CELLS_E, (np * (size_t)(kGridCellsCap + 1) + 4) * sizeof(uint32_t));  // (+4: the search reads four entries at a time)
+  ENSURE(ctx, WS_CELLS_P, (np * (size_t)(kGridCellsCap + 1) + 4) * sizeof(uint32_t));
   ENSURE(ctx, WS_SORTED_E, np * (es + kGridPad) * sizeof(GridPoint));
   ENSURE(ctx, WS_SORTED_P, np * (ps + kGridPad) * sizeof(GridPoint));
   ENSURE(ctx, WS_REL_E, np * 3 * (es + kGridPad) * sizeof(float));
@@ -1007,7 +1007,7 @@ int index_build(loamx_ctx* ctx, loamx_target_index* idx) {
     idx->cells_cap[k] = idx->n[k] > 200000 ? (mc ? (1u << atoi(mc)) : kGridMapCellsCap) : 0u;
     if (idx->cells_cap[k] <= kGridCellsCap) idx->cells_cap[k] = 0u;
     const size_t cap = idx->cells_cap[k] ? idx->cells_cap[k] : kGridCellsCap;
-    const size_t need = (cap + 1) * sizeof(uint32_t);
+    const size_t need = (cap + 1 + 4) * sizeof(uint32_t);  // (+4: the search reads four entries at a time)
     if (idx->cells_alloc[k] < need) {
       HIP_TRY(ctx, hipStreamSynchronize(s));
       if (idx->cells[k]) (void)hipFree(idx->cells[k]);

@@ -98,6 +98,12 @@ LOAMX_HD int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo 
 LOAMX_HD uint32_t cell_start_at(const uint32_t* __restrict__ cell_start, uint32_t i) {
   return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(cell_start) + (uint32_t)(i << 2));
 }
+struct alignas(4) CellStart4 {
+  uint32_t v[4];
+};
+LOAMX_HD CellStart4 cell_start4_at(const uint32_t* __restrict__ cell_start, uint32_t i) {
+  return *reinterpret_cast<const CellStart4*>(reinterpret_cast<const char*>(cell_start) + (uint32_t)(i << 2));
+}
 // cell of a target point at build time (always inside the grid)
 LOAMX_HD uint32_t grid_cell_of_point(const GridDesc& g, Vec3 p) {
   const int32_t ix = clampi(grid_cell_coord(p.x, g.ox, g.inv_h), 0, g.nx - 1);
@@ -1183,8 +1189,13 @@ LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cel
       const int32_t iy = cy + (j % 3) - 1, iz = cz + (j / 3) - 1;
       const bool ok = xa <= xb && iy >= 0 && iy <= g.ny - 1 && iz >= 0 && iz <= g.nz - 1;
       const uint32_t row = ok ? (uint32_t)((iz * g.ny + iy) * g.nx) : 0u;
-      rb[o] = ok ? cell_start_at(cell_start, row + (uint32_t)xa) : 0u;
-      re[o] = ok ? cell_start_at(cell_start, row + (uint32_t)xb + 1u) : 0u;
+      // both ends of the row's range with ONE 16-byte load of entries xa .. xa + 3 (the range ends at xb + 1 <= xa + 3;
+      // the table carries spare entries behind its last cell), issued unconditionally: 9 loads instead of 18 behind
+      // branches (the kernel is co-limited by the texture addresser: measured 1.24 -> 1.21 ms)
+      const CellStart4 c4 = cell_start4_at(cell_start, ok ? row + (uint32_t)xa : 0u);
+      const int span = xb + 1 - xa;  // 1 .. 3
+      rb[o] = ok ? c4.v[0] : 0u;
+      re[o] = ok ? (span == 1 ? c4.v[1] : (span == 2 ? c4.v[2] : c4.v[3])) : 0u;
     }
 #pragma unroll
     for (int o = 0; o < 9; o++) {

@@ -356,7 +356,7 @@ static void build_grid(const double* pts, uint32_t n, double max_dist, HostGrid&
   }
   grid_choose(G.g, lo, hi, n, max_dist, kGridCellsCap);
   const uint32_t ncell = (uint32_t)(G.g.nx * G.g.ny * G.g.nz);
-  G.cell_start.assign(ncell + 1, 0);
+  G.cell_start.assign(ncell + 1 + 4, 0);  // (+4 spare entries, as the device tables)
   std::vector<uint32_t> cell(n);
   for (uint32_t i = 0; i < n; i++) {
     cell[i] = grid_cell_of_point(G.g, v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
