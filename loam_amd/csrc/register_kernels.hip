@@ -636,8 +636,11 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_kn
 #define LOAMX_REST_THREADS 64
 #endif
 constexpr int kRestThreads = LOAMX_REST_THREADS;  // small workgroups: the queues are short and uneven
+#ifndef LOAMX_REST_WAVES
+#define LOAMX_REST_WAVES 5  // measured (association scope): unconstrained (150 VGPRs, 3 waves/SIMD) 2.18 ms, 4 -> 2.12, 5 -> 2.11, 6 -> 2.14
+#endif
 template <bool PLANE, int KM>
-__global__ __launch_bounds__(kRestThreads) void associate_knn_rest_kernel(RegBatch B, RegConfig C,
+__global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_rest_kernel(RegBatch B, RegConfig C,
                                                                                               uint32_t blocks_per_pair) {
   size_t pair;
   uint32_t chunk0;
