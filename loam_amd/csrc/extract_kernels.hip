@@ -233,8 +233,11 @@ __device__ __forceinline__ void curvature_line_tiles(const T* __restrict__ g, co
   }
 }
 
+#ifndef LOAMX_CURV_WAVES
+#define LOAMX_CURV_WAVES 4
+#endif
 template <int NP, typename T>
-__global__ __launch_bounds__(kCurvThreads) void curvature_valid2_kernel(const T* __restrict__ xyz, ExtractParams P,
+__global__ __launch_bounds__(kCurvThreads, LOAMX_CURV_WAVES) void curvature_valid2_kernel(const T* __restrict__ xyz, ExtractParams P,
                                                                double* __restrict__ curv_out,
                                                                uint8_t* __restrict__ mask_out) {
   using G = Curv2<NP>;

@@ -247,6 +247,7 @@ int make_reg_config(loamx_ctx* ctx, const loamx_reg_params* r, RegConfig& C) {
   C.max_iterations = (uint32_t)r->max_iterations;
   C.rot_thresh = r->rotation_convergence_thresh, C.pos_thresh = r->position_convergence_thresh;
   C.min_associations = (uint32_t)(r->min_associations > 0xFFFFFFFFull ? 0xFFFFFFFFull : r->min_associations);
+  C.flags = getenv("LOAMX_NO_MOMENTS") ? kRegFlagNoMoments : 0u;
   return LOAMX_OK;
 }
 

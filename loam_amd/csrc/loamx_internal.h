@@ -103,7 +103,9 @@ struct RegConfig {
   uint32_t max_iterations;
   double rot_thresh, pos_thresh;
   uint32_t min_associations;
+  uint32_t flags;  // debug: bit 0 = never use the moments (LOAMX_NO_MOMENTS=1: every evaluation streams the records)
 };
+constexpr uint32_t kRegFlagNoMoments = 1u;
 
 // One target feature set's spatial index (device pointers into the workspace)
 struct GridSet {

@@ -1324,7 +1324,7 @@ __global__ void outer_update_kernel(RegBatch B, RegConfig C) {
   const bool converged = outer_update(est, upd, C.rot_thresh, C.pos_thresh);  // registration-inl.h:65-73
   // From the second ICF iteration on the updates are small and the moment pass pays off (the first one usually
   // moves the pose by more than the validity bound of the moments allows: its sweeps stream the records).
-  S.use_moments = 1u;
+  S.use_moments = (C.flags & kRegFlagNoMoments) ? 0u : 1u;
   for (int i = 0; i < 7; i++) S.est[i] = est[i];
   if (converged) {
     S.termination = LOAMX_CONVERGED;

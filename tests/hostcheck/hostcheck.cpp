@@ -476,6 +476,84 @@ void hostcheck_lean_stats(const double* pts, uint64_t n, const double* queries, 
   }
 }
 
+// analysis only: trips of one query under three walks of its 3x3x3 block (exact distances, exact pruning):
+// out[6 * i + ...] = {batches A, rejections A, batches B (rows sorted by slab distance, stop at the first miss),
+//                     batches C (rows split into a near two-cell and a far one-cell piece, sorted), candidates A, candidates C}
+void hostcheck_walk_stats(const double* pts, uint64_t n, const double* queries, uint64_t nq, uint64_t k, double max_dist,
+                          uint32_t* out) {
+  HostGrid G;
+  build_grid(pts, (uint32_t)n, max_dist, G);
+  const GridDesc& g = G.g;
+  const double r2 = max_dist > 0 ? max_dist * max_dist : 1e300;
+  struct Piece { double s2; uint32_t b, e; };
+  for (uint64_t qi = 0; qi < nq; qi++) {
+    const Vec3 q = v3(queries[3 * qi], queries[3 * qi + 1], queries[3 * qi + 2]);
+    const int32_t cx = grid_cell_coord(q.x, g.ox, g.inv_h), cy = grid_cell_coord(q.y, g.oy, g.inv_h), cz = grid_cell_coord(q.z, g.oz, g.inv_h);
+    for (int j = 0; j < 6; j++) out[6 * qi + j] = 0;
+    if (grid_outside_distance(g, cx, cy, cz) > 1) continue;
+    auto gap = [&](double v, double o, int32_t c, int32_t cc) {  // distance from v to cell cc along one axis
+      if (cc == c) return 0.0;
+      const double lo = o + cc * g.h, hi = lo + g.h;
+      return cc < c ? v - hi : lo - v;
+    };
+    std::vector<Piece> rows, pieces;
+    constexpr int kOrder[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
+    const bool left = (q.x - (g.ox + cx * g.h)) < 0.5 * g.h;
+    for (int o = 0; o < 9; o++) {
+      const int j = kOrder[o];
+      const int32_t iy = cy + (j % 3) - 1, iz = cz + (j / 3) - 1;
+      if (iy < 0 || iy >= g.ny || iz < 0 || iz >= g.nz) continue;
+      const double gy = gap(q.y, g.oy, cy, iy), gz = gap(q.z, g.oz, cz, iz);
+      const double s2 = gy * gy + gz * gz;
+      const int32_t xa = std::max(cx - 1, 0), xb = std::min(cx + 1, g.nx - 1);
+      const uint32_t row = (uint32_t)((iz * g.ny + iy) * g.nx);
+      const uint32_t b = G.cell_start[row + xa], e = G.cell_start[row + xb + 1];
+      if (b < e) rows.push_back({s2, b, e});
+      // pieces: near = {cx, cx -/+ 1 on the query's side}, far = the third cell
+      const int32_t fx = left ? cx + 1 : cx - 1;
+      const int32_t na = left ? std::max(cx - 1, 0) : cx, nb = left ? cx : std::min(cx + 1, g.nx - 1);
+      const uint32_t pb = G.cell_start[row + na], pe = G.cell_start[row + nb + 1];
+      if (pb < pe) pieces.push_back({s2, pb, pe});
+      if (fx >= 0 && fx < g.nx) {
+        const uint32_t fb = G.cell_start[row + fx], fe = G.cell_start[row + fx + 1];
+        const double gx = gap(q.x, g.ox, cx, fx);
+        if (fb < fe) pieces.push_back({s2 + gx * gx, fb, fe});
+      }
+    }
+    auto walk = [&](std::vector<Piece> list, bool sorted, uint32_t& batches, uint32_t& rejects, uint32_t& cands) {
+      if (sorted) std::stable_sort(list.begin(), list.end(), [](const Piece& a, const Piece& b) { return a.s2 < b.s2; });
+      std::vector<double> best;  // the k smallest so far
+      batches = rejects = cands = 0;
+      for (const Piece& P : list) {
+        const double kth = best.size() >= k ? best[k - 1] : 1e300;
+        const double bound = std::min(kth, r2);
+        if (P.s2 > bound) {
+          if (sorted) break;
+          rejects++;
+          continue;
+        }
+        for (uint32_t p = P.b; p < P.e; p += 4) {
+          batches++;
+          for (uint32_t t = p; t < std::min(p + 4, P.e); t++) {
+            const double dx = q.x - G.sp[t].x, dy = q.y - G.sp[t].y, dz = q.z - G.sp[t].z;
+            best.push_back(dx * dx + dy * dy + dz * dz);
+            cands++;
+          }
+          std::sort(best.begin(), best.end());
+          if (best.size() > k) best.resize(k);
+        }
+      }
+    };
+    uint32_t b, r, c;
+    walk(rows, false, b, r, c);
+    out[6 * qi] = b, out[6 * qi + 1] = r, out[6 * qi + 4] = c;
+    walk(rows, true, b, r, c);
+    out[6 * qi + 2] = b;
+    walk(pieces, true, b, r, c);
+    out[6 * qi + 3] = b, out[6 * qi + 5] = c;
+  }
+}
+
 double hostcheck_fit_plane(const double* pts, uint64_t k, double out[4]) {
   Vec3 P[kMaxK];
   for (uint64_t i = 0; i < k; i++) P[i] = v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);

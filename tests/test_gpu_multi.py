@@ -94,3 +94,37 @@ def test_eight_shard_plan_equals_one_8192_pair_call():
     assert np.array_equal(_run(c, d_xyz.ptr, P, d_res), parts[5])
     d_xyz.free()
     d_res.free()
+
+
+def test_lm_loop_streaming_path_agrees_with_the_moment_path(oracle, monkeypatch):
+    """From the second ICF iteration on one wavefront per pair runs the whole LM solve (lm_pair_loop_kernel): off the
+    plane moments, or — when a candidate leaves their validity bound — by streaming the pair's records itself. The bench
+    workload never takes the second route; LOAMX_NO_MOMENTS=1 forces it for every evaluation. Both routes must tell the
+    same story: terminations and iteration counts equal, poses within the summation-order noise of each other (1e-9),
+    and the forced route within the 1e-5 bar of the oracle."""
+    c = ctx()
+    P = 96
+    d_xyz, d_res = c.alloc(P * 2 * N * 24), c.alloc(P * 64)
+    c.synth_scan_pairs_dev(SEED, 300, P, H, W, 0.01, d_xyz.ptr)
+    ref = _run(c, d_xyz.ptr, P, d_res).view(capi.RESULT_DTYPE)
+    monkeypatch.setenv("LOAMX_NO_MOMENTS", "1")
+    forced = _run(c, d_xyz.ptr, P, d_res).view(capi.RESULT_DTYPE)
+    monkeypatch.delenv("LOAMX_NO_MOMENTS")
+    again = _run(c, d_xyz.ptr, P, d_res).view(capi.RESULT_DTYPE)
+    d_xyz.free()
+    d_res.free()
+    assert np.array_equal(ref.view(np.uint8), again.view(np.uint8))  # (the switch is read per call and leaves no state)
+    assert np.array_equal(ref["termination"], forced["termination"]) and np.array_equal(ref["iterations"], forced["iterations"])
+    assert not np.array_equal(ref["pose"], forced["pose"])  # a different summation order: the route really was taken
+    for pr in range(P):
+        rot, trans = pose_diff(oracle, ref[pr]["pose"], forced[pr]["pose"])
+        assert rot < 1e-9 and trans < 1e-9, (pr, rot, trans)
+    for pr in range(0, P, 12):
+        A = capi.synth_scan_host(SEED, 300 + pr, 0, H, W, 0.01)
+        B = capi.synth_scan_host(SEED, 300 + pr, 1, H, W, 0.01)
+        ea, pa = oracle.extract_features(A, H, W, 1.0, 120.0)
+        eb, pb = oracle.extract_features(B, H, W, 1.0, 120.0)
+        po, to, io = oracle.register_features(B[eb], B[pb], A[ea], A[pa])
+        assert (forced[pr]["termination"], forced[pr]["iterations"]) == (to, io), pr
+        rot, trans = pose_diff(oracle, po, forced[pr]["pose"])
+        assert rot < 1e-5 and trans < 1e-5, (pr, rot, trans)
