@@ -192,7 +192,11 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
     }
     __syncthreads();
     STAMP();  // scan
-    for (uint32_t c = tid; c < nc; c += kBuildThreads) cs[c_lo + c] = cell_get(c);  // coalesced copy of the scan
+    // coalesced copy of the scan — for the sets whose table somebody reads: not the source sets that are ranked in LDS
+    // (they are only ordered) and not the target sets small enough for associate_knn_brute_kernel, whose 300 points
+    // would otherwise leave a table of up to 65 536 entries behind (0.5 GB of writes per 1 024-pair step)
+    if (!(ORDERED && PACKED) && (ORDERED || n > kBruteMax))
+      for (uint32_t c = tid; c < nc; c += kBuildThreads) cs[c_lo + c] = cell_get(c);
     __syncthreads();
     STAMP();  // table write
     if (PACKED) {
