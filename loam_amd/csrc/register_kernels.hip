@@ -2,18 +2,21 @@
 // (reference: loam/include/loam/registration-inl.h:11-78, loam/src/registration.cpp:23-103).
 //
 // Per outer ICF iteration the host enqueues, for all pairs at once:
-//   associate_kernel<edge>, associate_kernel<plane>   rows a16-a19: move the source point by the
+//   associate_knn_* / associate_fit_* kernels (edge, plane)   rows a16-a19: move the source point by the
 //                           current estimate, exact k-NN in the target's uniform grid (replaces the
 //                           nanoflann KD-tree), fitLine / fitPlane in registers, guards, write the
-//                           association record (structure of arrays).
+//                           association record (structure of arrays). See launch_associate.
 //   lm_begin_kernel         min_associations check, Ceres problem/solver state reset.
-//   5 x { sweep_kernel, lm_step_kernel }
+//   first ICF iteration: 5 x { sweep_kernel, lm_step_kernel }
 //                           rows a20-a22: sweep = residual + Jacobian row + Huber + 6x6 normal
 //                           equations over all association slots of a pair, streamed from HBM
 //                           (72 B per edge slot, 56 B per plane slot), wavefront shuffle + LDS
 //                           reduction to one 29-double partial per workgroup; lm_step = fixed-order
 //                           reduction of the partials and the trust-region bookkeeping of one
 //                           Levenberg-Marquardt iteration (6x6 Cholesky) per pair.
+//   later ICF iterations: moment_kernel, lm_pair_loop_kernel
+//                           the plane records of a pair summarised by a 13x13 moment matrix (FP64 MFMA), then
+//                           ONE wavefront per pair runs the whole Levenberg-Marquardt solve off it.
 //   outer_update_kernel     row a23: est <- update (+) est, convergence test, termination type.
 // grid_build_kernel (once per call) builds the per-target-set grid entirely in LDS.
 #include "loamx_internal.h"
@@ -1555,7 +1558,7 @@ void launch_sweep(const RegBatch& B, hipStream_t s) {
 
 // the same evaluation for the pairs that are on moments (timed with the LM kernels: it streams next to nothing)
 void launch_lm_pair_loop(const RegBatch& B, hipStream_t s) {
-  if (B.n_pairs == 0 || B.blocks_per_pair == 0) return;
+  if (B.n_pairs == 0) return;
   launch_kernel(lm_pair_loop_kernel, dim3((unsigned)B.n_pairs), dim3(64), 0, s, B);
 }
 
