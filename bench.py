@@ -323,6 +323,11 @@ def main():
                             comp["active_lane_fraction"] = round(ctr[knn]["SQ_THREAD_CYCLES_VALU"] / (64.0 * ctr[knn]["SQ_ACTIVE_INST_VALU"]), 4)
                             comp["note"] = ("peak = 2 cycles per wave64 instruction (packed FP32 rate); an unpacked 32-bit instruction occupies "
                                             "its SIMD for 4 cycles, i.e. twice this fraction of the issue slots")
+                        if ctr[knn].get("TA_BUSY_avr") and ctr[knn].get("GRBM_GUI_ACTIVE"):
+                            # second limiter of the same kernel: the texture addressers (per-lane 16-byte gathers of the
+                            # candidate batches). TA_BUSY_avr = busy cycles averaged over the TAs, GRBM_GUI_ACTIVE is
+                            # summed over the 8 XCDs
+                            comp["texture_addresser_busy_frac"] = round(ctr[knn]["TA_BUSY_avr"] / (ctr[knn]["GRBM_GUI_ACTIVE"] / 8.0), 4)
                         roofline["compute"] = comp
             except Exception as e:  # no profile committed for this round yet
                 roofline["traffic_note"] = f"no usable PMC file ({type(e).__name__})"
