@@ -401,7 +401,7 @@ int enqueue_icf_iteration(loamx_ctx* ctx, const RegBatch& B, const RegConfig& C,
     if (it > 0) {
       // one workgroup per pair runs the whole solve off the moments (and streams by itself whatever they cannot cover)
       TimedScope t(ctx, LOAMX_K_LM, 0.0, true);
-      launch_lm_pair_loop(B, s);
+      launch_lm_pair_loop(B, C, s);  // (ends with the pair's outer update)
     } else {
       for (int k = 0; k < 5; k++) {  // iteration-0 evaluation + max_num_iterations = 4 candidates
         {
@@ -415,9 +415,7 @@ int enqueue_icf_iteration(loamx_ctx* ctx, const RegBatch& B, const RegConfig& C,
       }
     }
     CHECK_LAUNCH(ctx, "sweep/lm kernels");
-    untimed(ctx);
-    HIP_TRY(ctx, hipMemsetAsync(B.n_active, 0, sizeof(uint32_t), s));
-    {
+    if (it == 0) {  // (later iterations: inside lm_pair_loop_kernel; the active-pair counter is reset by lm_begin_kernel)
       TimedScope t(ctx, LOAMX_K_LM, 0.0, true);
       launch_outer_update(B, C, s);
     }

@@ -218,7 +218,7 @@ void debug_nn_same(const RegBatch& B, uint32_t it, hipStream_t s);
 #endif
 void launch_lm_begin(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_sweep(const RegBatch& B, hipStream_t s);
-void launch_lm_pair_loop(const RegBatch& B, hipStream_t s);
+void launch_lm_pair_loop(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_lm_step(const RegBatch& B, hipStream_t s);
 void launch_moments(const RegBatch& B, hipStream_t s);
 void launch_outer_update(const RegBatch& B, const RegConfig& C, hipStream_t s);

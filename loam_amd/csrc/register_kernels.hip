@@ -841,6 +841,7 @@ __global__ __launch_bounds__(kRestThreads) void associate_fit_queued_kernel(RegB
 __global__ __launch_bounds__(64) void lm_begin_kernel(RegBatch B, RegConfig C) {
   const size_t pair = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pair >= B.n_pairs) return;
+  if (pair == 0) *B.n_active = 0u;  // outer_update_pair counts the pairs that go on (read back by the host after the iteration)
   PairState& S = B.state[pair];
   if (!S.active) return;
   const uint32_t iteration = S.iterations;
@@ -1141,6 +1142,33 @@ __global__ __launch_bounds__(64) void lm_step_kernel(RegBatch B) {  // one wavef
   lm_step_pair(B, pair, S, acc);
 }
 
+// row a23 for one pair: est <- update (+) est, convergence test, termination type (registration-inl.h:59-76)
+__device__ __forceinline__ void outer_update_pair(const RegBatch& B, const RegConfig& C, size_t pair, PairState& S) {
+  const uint32_t iteration = S.iterations;
+  double upd[7];
+  for (int i = 0; i < 7; i++) upd[i] = S.lm.x_user[i];
+  if (B.iter_info) {
+    loamx_iter_info& I = B.iter_info[pair * C.max_iterations + iteration];
+    for (int i = 0; i < 7; i++) I.estimate_update[i] = upd[i];
+  }
+  S.iterations = iteration + 1;
+  double est[7];
+  for (int i = 0; i < 7; i++) est[i] = S.est[i];
+  const bool converged = outer_update(est, upd, C.rot_thresh, C.pos_thresh);  // registration-inl.h:65-73
+  // From the second ICF iteration on the updates are small and the moment pass pays off (the first one usually
+  // moves the pose by more than the validity bound of the moments allows: its sweeps stream the records).
+  S.use_moments = (C.flags & kRegFlagNoMoments) ? 0u : 1u;
+  for (int i = 0; i < 7; i++) S.est[i] = est[i];
+  if (converged) {
+    S.termination = LOAMX_CONVERGED;
+    S.active = 0;
+  } else if (iteration + 1 >= C.max_iterations) {
+    S.active = 0;  // termination stays MAX_ITER
+  } else {
+    atomicAdd(B.n_active, 1u);
+  }
+}
+
 /* The whole Levenberg-Marquardt solve of one ICF iteration for a pair whose plane records are summarised by moments
  * (every ICF iteration but the first), by ONE WAVEFRONT in ONE launch: the moment tiles of the pair are added up,
  * then up to five times { evaluate at the candidate, bookkeeping step }. Before, that was moment_finish + 5 x
@@ -1150,14 +1178,18 @@ __global__ __launch_bounds__(64) void lm_step_kernel(RegBatch B) {  // one wavef
  * holds 1 024 pairs at once. An evaluation the moments cannot stand in for (the candidate leaves their validity bound)
  * is streamed by the same wavefront: rare, slow, self-contained. From the second ICF iteration on this kernel is the
  * only evaluator, so a pair's result does not depend on the batch it is in. */
-__global__ __launch_bounds__(64) void lm_pair_loop_kernel(RegBatch B) {
+__global__ __launch_bounds__(64) void lm_pair_loop_kernel(RegBatch B, RegConfig C) {
   __shared__ LightLds L;
   __shared__ double s_mom[kMomSize + 2];
   __shared__ double s_acc[kAccSize];
   const int lane = threadIdx.x;
   const size_t pair = blockIdx.x;
   PairState& S = B.state[pair];
-  if (!S.active || !S.lm.active) return;  // uniform
+  if (!S.active) return;  // uniform
+  if (!S.lm.active) {     // (uniform; lm_begin_kernel starts every active pair's solve, so this does not happen)
+    if (lane == 0) outer_update_pair(B, C, pair, S);
+    return;
+  }
   const uint32_t n_se_raw = B.n_src_edge[pair * B.in_pitch], n_sp_raw = B.n_src_planar[pair * B.in_pitch];
   const uint32_t n_se = n_se_raw < B.edge_stride ? n_se_raw : (uint32_t)B.edge_stride;
   const uint32_t n_sp = n_sp_raw < B.planar_stride ? n_sp_raw : (uint32_t)B.planar_stride;
@@ -1211,6 +1243,8 @@ __global__ __launch_bounds__(64) void lm_pair_loop_kernel(RegBatch B) {
                                   (unsigned int)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(xi) & 0xFFFFFFFFll)));
     }
   }
+  // ---- the outer step of the ICF iteration (what outer_update_kernel does after the first iteration's solve)
+  if (lane == 0) outer_update_pair(B, C, pair, S);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -1318,29 +1352,7 @@ __global__ void outer_update_kernel(RegBatch B, RegConfig C) {
   if (pair >= B.n_pairs) return;
   PairState& S = B.state[pair];
   if (!S.active) return;
-  const uint32_t iteration = S.iterations;
-  double upd[7];
-  for (int i = 0; i < 7; i++) upd[i] = S.lm.x_user[i];
-  if (B.iter_info) {
-    loamx_iter_info& I = B.iter_info[pair * C.max_iterations + iteration];
-    for (int i = 0; i < 7; i++) I.estimate_update[i] = upd[i];
-  }
-  S.iterations = iteration + 1;
-  double est[7];
-  for (int i = 0; i < 7; i++) est[i] = S.est[i];
-  const bool converged = outer_update(est, upd, C.rot_thresh, C.pos_thresh);  // registration-inl.h:65-73
-  // From the second ICF iteration on the updates are small and the moment pass pays off (the first one usually
-  // moves the pose by more than the validity bound of the moments allows: its sweeps stream the records).
-  S.use_moments = (C.flags & kRegFlagNoMoments) ? 0u : 1u;
-  for (int i = 0; i < 7; i++) S.est[i] = est[i];
-  if (converged) {
-    S.termination = LOAMX_CONVERGED;
-    S.active = 0;
-  } else if (iteration + 1 >= C.max_iterations) {
-    S.active = 0;  // termination stays MAX_ITER
-  } else {
-    atomicAdd(B.n_active, 1u);
-  }
+  outer_update_pair(B, C, pair, S);
 }
 
 __global__ void write_results_kernel(RegBatch B, loamx_reg_result* __restrict__ out) {
@@ -1557,9 +1569,9 @@ void launch_sweep(const RegBatch& B, hipStream_t s) {
 }
 
 // the same evaluation for the pairs that are on moments (timed with the LM kernels: it streams next to nothing)
-void launch_lm_pair_loop(const RegBatch& B, hipStream_t s) {
+void launch_lm_pair_loop(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   if (B.n_pairs == 0) return;
-  launch_kernel(lm_pair_loop_kernel, dim3((unsigned)B.n_pairs), dim3(64), 0, s, B);
+  launch_kernel(lm_pair_loop_kernel, dim3((unsigned)B.n_pairs), dim3(64), 0, s, B, C);
 }
 
 void launch_moments(const RegBatch& B, hipStream_t s) {
