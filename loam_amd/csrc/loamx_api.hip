@@ -23,7 +23,7 @@ enum WsId {
   WS_XYZ = 0, WS_CURV, WS_MASK, WS_EDGE_STAGE, WS_PLANAR_STAGE, WS_EDGE_CNT, WS_PLANAR_CNT,
   WS_EDGE_IDX, WS_PLANAR_IDX, WS_N_EDGE, WS_N_PLANAR, WS_EDGE_XYZ, WS_PLANAR_XYZ,
   WS_GRID_DESC_E, WS_GRID_DESC_P, WS_CELLS_E, WS_CELLS_P, WS_SORTED_E, WS_SORTED_P, WS_REL_E, WS_REL_P,
-  WS_SGRID_DESC_E, WS_SGRID_DESC_P, WS_SCELLS_E, WS_SCELLS_P, WS_SSORTED_E, WS_SSORTED_P, WS_SORT_SCRATCH, WS_ASSOC_E, WS_ASSOC_P, WS_NN_E, WS_NN_P, WS_RNN_E, WS_RNN_P, WS_NEAREST_E, WS_NEAREST_P, WS_REST_E, WS_REST_P, WS_EXACT_E, WS_EXACT_P, WS_NASSOC, WS_STATE, WS_PARTIALS, WS_MOM_PARTIALS, WS_MOMENTS, WS_FLAGGED_LIST, WS_FLAGGED_COUNT, WS_LINE_TOT, WS_EXTRACT_EVENTS,
+  WS_SGRID_DESC_E, WS_SGRID_DESC_P, WS_SCELLS_E, WS_SCELLS_P, WS_SSORTED_E, WS_SSORTED_P, WS_SORT_SCRATCH, WS_SORT_SCRATCH_SRC, WS_ASSOC_E, WS_ASSOC_P, WS_NN_E, WS_NN_P, WS_RNN_E, WS_RNN_P, WS_NEAREST_E, WS_NEAREST_P, WS_REST_E, WS_REST_P, WS_EXACT_E, WS_EXACT_P, WS_NASSOC, WS_STATE, WS_PARTIALS, WS_MOM_PARTIALS, WS_MOMENTS, WS_FLAGGED_LIST, WS_FLAGGED_COUNT, WS_LINE_TOT, WS_EXTRACT_EVENTS,
   WS_COUNTERS, WS_ITERINFO, WS_SRC_E, WS_SRC_P, WS_TGT_E, WS_TGT_P, WS_FCOUNTS, WS_RESULTS, WS_INIT,
   WS_COUNT
 };
@@ -450,6 +450,8 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   ENSURE(ctx, WS_SSORTED_E, np * es * sizeof(GridPoint));
   ENSURE(ctx, WS_SSORTED_P, np * ps * sizeof(GridPoint));
   ENSURE(ctx, WS_SORT_SCRATCH, np * (es > ps ? es : ps) * sizeof(GridPoint));
+  // (sets up to kGridSmallCap points are ordered in LDS and need no scratch)
+  ENSURE(ctx, WS_SORT_SCRATCH_SRC, (es > ps ? es : ps) > kGridSmallCap ? np * (es > ps ? es : ps) * sizeof(GridPoint) : sizeof(GridPoint));
   ENSURE(ctx, WS_ASSOC_E, 9 * np * es * sizeof(double));
   ENSURE(ctx, WS_ASSOC_P, 7 * np * ps * sizeof(double));
   ENSURE(ctx, WS_NN_E, (size_t)(1 + kMaxK) * np * es * sizeof(uint32_t));
@@ -494,6 +496,7 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   B.src_grid_edge = GridSet{wsp<GridDesc>(ctx, WS_SGRID_DESC_E), wsp<uint32_t>(ctx, WS_SCELLS_E), wsp<GridPoint>(ctx, WS_SSORTED_E), es, nullptr};
   B.src_grid_plane = GridSet{wsp<GridDesc>(ctx, WS_SGRID_DESC_P), wsp<uint32_t>(ctx, WS_SCELLS_P), wsp<GridPoint>(ctx, WS_SSORTED_P), ps, nullptr};
   B.sort_scratch = wsp<GridPoint>(ctx, WS_SORT_SCRATCH);
+  B.sort_scratch_src = wsp<GridPoint>(ctx, WS_SORT_SCRATCH_SRC);
   B.assoc = AssocBuffers{wsp<double>(ctx, WS_ASSOC_E), wsp<double>(ctx, WS_ASSOC_P), wsp<uint32_t>(ctx, WS_NN_E),
                          wsp<uint32_t>(ctx, WS_NN_P), wsp<uint32_t>(ctx, WS_RNN_E), wsp<uint32_t>(ctx, WS_RNN_P),
                          wsp<uint32_t>(ctx, WS_NEAREST_E),

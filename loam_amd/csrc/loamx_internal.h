@@ -176,7 +176,8 @@ struct RegBatch {
   const double* init;  // may be null
   GridSet grid_edge, grid_plane;          // target sets: searched
   GridSet src_grid_edge, src_grid_plane;  // source sets: only their cell-sorted order is used (coherent queries)
-  GridPoint* sort_scratch;  // [n_pairs][max(edge_stride, planar_stride)] scratch of the ordered source build
+  GridPoint* sort_scratch;      // [n_pairs][max(edge_stride, planar_stride)] scratch of the multi-workgroup target builds
+  GridPoint* sort_scratch_src;  // the same for the ordered source builds (they run next to the target builds on another stream)
   AssocBuffers assoc;
   PairState* state;      // [n_pairs]
   double* partials;      // [n_pairs][blocks_per_pair][kAccSize]
@@ -204,6 +205,7 @@ constexpr size_t kGridBigScratchBytes = 64 + (size_t)kGridCellsCap * sizeof(uint
 // cell table of a map-sized persistent index. Measured on a 1.02 M-point map (config 5; index build / registration
 // of a 39 k-feature scan): 2^16 cells 1.04 / 6.71 ms, 2^17 1.07 / 5.97, 2^18 1.38 / 5.88, 2^19 1.77 / 5.71,
 // 2^20 2.49 / 5.74, 2^21 4.75 / 8.19 (cells too small for the 5th neighbour: more second rounds)
+constexpr uint32_t kGridSmallCap = 20480;  // sets up to this size are indexed by the packed single-workgroup build (no scratch)
 constexpr uint32_t kBruteMax = 512;  // target sets up to this size are searched by associate_knn_brute_kernel
 constexpr uint32_t kGridMapCellsCap = 1u << 18;
 void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_t s);

@@ -53,7 +53,6 @@ constexpr int kBuildThreads = LOAMX_BUILD_THREADS;
 // Measured per workgroup before: the scattered 2 x 16-byte global stores per point took 52-68 us of the
 // build's 110-135 us and the float-copy pass another 14-30 us. ORDERED sets get their reproducible order in LDS
 // as well (rank among the cell mates -> second list), which replaces the scratch copy and grid_rank_kernel.
-constexpr uint32_t kGridSmallCap = 20480;
 template <bool ORDERED, bool PACKED>
 __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double* __restrict__ pts_base,
                                                                    const uint32_t* __restrict__ n_pts, size_t stride,
@@ -1433,16 +1432,18 @@ void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_
 // source sets: only the cell-sorted (Morton) order is used
 void launch_grid_build_sources(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   if (B.n_pairs == 0) return;
-  // (the scratch copy is shared: build + rank of one set complete before the next set's build starts)
-  launch_grid_build<true>(B.n_pairs, B.src_edge, B.n_src_edge, B.edge_stride, B.in_pitch, C.r_edge, B.src_grid_edge, B.sort_scratch, s);
+  // (the scratch copy is shared by the two source sets: build + rank of one complete before the next one's build starts.
+  // It is NOT the target builds' scratch: those run on another stream at the same time, and the multi-workgroup build of a
+  // target set above kGridSmallCap points keeps its box keys and cursors there)
+  launch_grid_build<true>(B.n_pairs, B.src_edge, B.n_src_edge, B.edge_stride, B.in_pitch, C.r_edge, B.src_grid_edge, B.sort_scratch_src, s);
   if (B.edge_stride && !grid_small(B.edge_stride))
     launch_kernel(grid_rank_kernel, dim3((unsigned)((B.edge_stride + kRankThreads - 1) / kRankThreads), (unsigned)B.n_pairs),
-                       dim3(kRankThreads), 0, s, B.n_src_edge, B.edge_stride, B.in_pitch, B.src_grid_edge, B.sort_scratch);
-  launch_grid_build<true>(B.n_pairs, B.src_planar, B.n_src_planar, B.planar_stride, B.in_pitch, C.r_plane, B.src_grid_plane, B.sort_scratch, s);
+                       dim3(kRankThreads), 0, s, B.n_src_edge, B.edge_stride, B.in_pitch, B.src_grid_edge, B.sort_scratch_src);
+  launch_grid_build<true>(B.n_pairs, B.src_planar, B.n_src_planar, B.planar_stride, B.in_pitch, C.r_plane, B.src_grid_plane, B.sort_scratch_src, s);
   if (B.planar_stride && !grid_small(B.planar_stride))
     launch_kernel(grid_rank_kernel, dim3((unsigned)((B.planar_stride + kRankThreads - 1) / kRankThreads), (unsigned)B.n_pairs),
                        dim3(kRankThreads), 0, s, B.n_src_planar, B.planar_stride, B.in_pitch, B.src_grid_plane,
-                       B.sort_scratch);
+                       B.sort_scratch_src);
 }
 
 void launch_state_init(const RegBatch& B, const RegConfig& C, hipStream_t s) {

@@ -128,3 +128,36 @@ def test_lm_loop_streaming_path_agrees_with_the_moment_path(oracle, monkeypatch)
         assert (forced[pr]["termination"], forced[pr]["iterations"]) == (to, io), pr
         rot, trans = pose_diff(oracle, po, forced[pr]["pose"])
         assert rot < 1e-5 and trans < 1e-5, (pr, rot, trans)
+
+
+def test_128_beam_batch_source_and_target_builds_do_not_share_scratch(oracle):
+    """Feature sets above 20 480 points (128-beam scans: ~34 k planar features) take the index builds that need scratch
+    memory — the multi-workgroup build of the target sets and the ordered single-workgroup build + rank of the source
+    sets — and in a batch the two run side by side on two streams. They used to share one scratch buffer (a GPU memory
+    fault on 64 pairs of 128 x 2048, found by tools/bench_other_sensors.py); now each has its own. Two runs must agree
+    bit for bit, and with the oracle."""
+    c = ctx()
+    Hb, Wb, P = 128, 1024, 16
+    Nb = Hb * Wb
+    lidar = capi.LidarParams(Hb, Wb, 1.0, 120.0)
+    d_xyz, d_res = c.alloc(P * 2 * Nb * 24), c.alloc(P * 64)
+    c.synth_scan_pairs_dev(SEED, 0, P, Hb, Wb, 0.01, d_xyz.ptr)
+    runs = []
+    for _ in range(3):
+        c.register_scan_pairs_dev(d_xyz.ptr, P, lidar, capi.FeatureExtractionParams(), capi.RegistrationParams(), d_res.ptr)
+        c.synchronize()
+        runs.append(d_res.download(np.uint8, P * 64).copy())
+    d_xyz.free()
+    d_res.free()
+    assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])
+    res = runs[0].view(capi.RESULT_DTYPE)
+    for pr in (0, 9):
+        A = capi.synth_scan_host(SEED, pr, 0, Hb, Wb, 0.01)
+        B = capi.synth_scan_host(SEED, pr, 1, Hb, Wb, 0.01)
+        ea, pa = oracle.extract_features(A, Hb, Wb, 1.0, 120.0)
+        eb, pb = oracle.extract_features(B, Hb, Wb, 1.0, 120.0)
+        assert len(pa) > 20480 and len(pb) > 20480
+        po, to, io = oracle.register_features(B[eb], B[pb], A[ea], A[pa])
+        assert (res[pr]["termination"], res[pr]["iterations"]) == (to, io), pr
+        rot, trans = pose_diff(oracle, po, res[pr]["pose"])
+        assert rot < 1e-5 and trans < 1e-5, (pr, rot, trans)
