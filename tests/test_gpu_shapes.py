@@ -54,3 +54,71 @@ def test_batches_of_other_shapes_twice_and_against_the_oracle(oracle, H, W, P, f
     if to == capi.CONVERGED:
         rot, trans = pose_diff(oracle, po, res[pr]["pose"])
         assert rot < 1e-5 and trans < 1e-5, (rot, trans)
+
+
+def _scene(rng, n_e, n_p):
+    """target sets on a few planes / lines of a room, source = a moved noisy subset"""
+    def planes(n):
+        parts = []
+        for _ in range(3):
+            o, u, v = rng.normal(size=3) * 3, rng.normal(size=3), rng.normal(size=3)
+            parts.append(o + np.outer(rng.uniform(-4, 4, n), u / np.linalg.norm(u)) + np.outer(rng.uniform(-4, 4, n), v / np.linalg.norm(v)))
+        return np.concatenate(parts)[rng.permutation(3 * n)[:n]]
+    def lines(n):
+        return np.concatenate([rng.normal(size=3) * 4 + np.outer(np.linspace(-3, 3, max(2, n // 3 + 1)), rng.normal(size=3)) for _ in range(3)])[:n]
+    import reference_kats as K
+    te, tp = (lines(n_e) if n_e else np.zeros((0, 3))), planes(n_p)
+    ax = rng.normal(size=3)
+    T = K.pose7(K.quat_angle_axis(rng.uniform(0, 0.03), ax / np.linalg.norm(ax)), rng.normal(size=3) * 0.03)
+    se = K.transform_points(T, te[rng.random(len(te)) < 0.9]) if len(te) else te
+    sp = K.transform_points(T, tp[rng.random(len(tp)) < 0.9])
+    return (np.ascontiguousarray(se + rng.normal(size=se.shape) * 0.002), np.ascontiguousarray(sp + rng.normal(size=sp.shape) * 0.002),
+            np.ascontiguousarray(te), np.ascontiguousarray(tp))
+
+
+def test_ragged_batch_equals_single_pair_calls(oracle):
+    """loamx_register_features_batch_dev with very different set sizes per pair (edge sets on both sides of the 512-point
+    brute-force threshold, planar sets from 50 to 25 000 points — on both sides of the 20 480-point index-build threshold —
+    in ONE batch): every pair's record equals what the single-pair entry point returns for it, bit for bit."""
+    rng = np.random.default_rng(99)
+    c = ctx()
+    sizes = [(40, 50), (700, 3000), (0, 900), (300, 25000), (520, 21000), (511, 20480), (3, 6000), (900, 150),
+             (100, 12000), (600, 22000), (60, 400), (513, 9000)]
+    scenes = [_scene(rng, ne, np_) for ne, np_ in sizes]
+    P = len(scenes)
+    es = max(max(len(s[0]), len(s[2])) for s in scenes)
+    ps = max(max(len(s[1]), len(s[3])) for s in scenes)
+    reg = capi.RegistrationParams()
+    reg.min_associations = 20
+    bufs = []
+    for k, stride in ((0, es), (1, ps), (2, es), (3, ps)):
+        pts = np.zeros((P, stride, 3))
+        cnt = np.zeros(P, np.uint32)
+        for p, s in enumerate(scenes):
+            pts[p, : len(s[k])] = s[k]
+            cnt[p] = len(s[k])
+        bufs.append((c.alloc(pts.nbytes).upload(pts.view(np.uint8).reshape(-1)), c.alloc(cnt.nbytes).upload(cnt.view(np.uint8))))
+    d_res = c.alloc(P * 64)
+    got = []
+    for _ in range(2):
+        c.register_features_batch_dev(P, bufs[0][0].ptr, bufs[0][1].ptr, bufs[1][0].ptr, bufs[1][1].ptr, bufs[2][0].ptr, bufs[2][1].ptr,
+                                      bufs[3][0].ptr, bufs[3][1].ptr, es, ps, None, reg, d_res.ptr)
+        c.synchronize()
+        got.append(d_res.download(np.uint8, P * 64).copy())
+    for b in bufs:
+        b[0].free(), b[1].free()
+    d_res.free()
+    assert np.array_equal(got[0], got[1])
+    res = got[0].view(capi.RESULT_DTYPE)
+    for p, (se, sp, te, tp) in enumerate(scenes):
+        pose, term, iters = c.register_features(se, sp, te, tp, reg=reg)
+        assert (res[p]["termination"], res[p]["iterations"]) == (term, iters), p
+        assert np.array_equal(res[p]["pose"], np.asarray(pose)), (p, sizes[p])
+    for p in (1, 5, 8):
+        oreg = oracle.RegParams()
+        oreg.min_associations = 20
+        po, to, io = oracle.register_features(*scenes[p], None, oreg)
+        assert (res[p]["termination"], res[p]["iterations"]) == (to, io), p
+        if to == capi.CONVERGED:
+            rot, trans = pose_diff(oracle, po, res[p]["pose"])
+            assert rot < 1e-5 and trans < 1e-5, (p, rot, trans)
