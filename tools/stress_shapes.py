@@ -40,22 +40,31 @@ for r in range(rounds):
             setattr(reg, k, v), setattr(oreg, k, v)
     d_xyz, d_res = c.alloc(P * 2 * N * 24), c.alloc(P * 64)
     c.synth_scan_pairs_dev(seed, first, P, H, W, 0.01, d_xyz.ptr)
+    f32 = bool(rng.integers(0, 4) == 0) and P * 2 * N * 24 < 4e8  # float-field scans: the FP32-input entry point
+    scans32 = None
+    if f32:
+        c.synchronize()
+        scans32 = d_xyz.download(np.float64, P * 2 * N * 3).astype(np.float32)
+        d_xyz.upload(scans32)
     out = []
     for _ in range(2):
-        c.register_scan_pairs_dev(d_xyz.ptr, P, lidar, fe, reg, d_res.ptr)
+        c.register_scan_pairs_dev(d_xyz.ptr, P, lidar, fe, reg, d_res.ptr, f32=f32)
         c.synchronize()
         out.append(d_res.download(np.uint8, P * 64).copy())
     same = np.array_equal(out[0], out[1])
     res = out[0].view(capi.RESULT_DTYPE)
     pr = int(rng.integers(0, P))
     A, B = capi.synth_scan_host(seed, first + pr, 0, H, W, 0.01), capi.synth_scan_host(seed, first + pr, 1, H, W, 0.01)
+    if f32:  # the oracle on the widened float scan (FieldAccessor widens float fields to double, common.h:55-60)
+        sc = scans32.reshape(P, 2, N, 3)
+        A, B = sc[pr, 0].astype(np.float64), sc[pr, 1].astype(np.float64)
     ea, pa = O.extract_features(A, H, W, 1.0, 120.0, ofe)
     eb, pb = O.extract_features(B, H, W, 1.0, 120.0, ofe)
     po, to, io = O.register_features(B[eb], B[pb], A[ea], A[pa], None, oreg)
     rot, trans = pose_diff(O, po, res[pr]["pose"])
     ok = same and (res[pr]["termination"], res[pr]["iterations"]) == (to, io) and ((rot < 1e-5 and trans < 1e-5) or to != 0)
     bad += 0 if ok else 1
-    print(f"{'ok ' if ok else 'BAD'} {H:3d} x {W:4d} x {P:3d} pairs (np {fe.neighbor_points} S {fe.number_sectors} k {reg.num_edge_neighbors}/{reg.num_plane_neighbors}): planar {len(pa)} / edge {len(ea)} features, repeat identical {same}, "
+    print(f"{'ok ' if ok else 'BAD'} {H:3d} x {W:4d} x {P:3d} pairs{' f32' if f32 else ''} (np {fe.neighbor_points} S {fe.number_sectors} k {reg.num_edge_neighbors}/{reg.num_plane_neighbors}): planar {len(pa)} / edge {len(ea)} features, repeat identical {same}, "
           f"pair {pr}: term {res[pr]['termination']}/{to} iters {res[pr]['iterations']}/{io} diff {rot:.1e} {trans:.1e}", flush=True)
     d_xyz.free()
     d_res.free()
