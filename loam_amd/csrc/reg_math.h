@@ -1101,6 +1101,9 @@ LOAMX_HD int knn_f32_round1_body(const GridDesc& g, const GridPoint* __restrict_
 #define LOAMX_LEAN_REASON(r) ((void)0)
 #endif
 constexpr int kLeanRowWords = 18;
+#ifndef LOAMX_LEAN_TMAX
+#define LOAMX_LEAN_TMAX 64
+#endif
 constexpr uint32_t kLeanMaxPoints = 65535u;  // positions are packed as 16-bit halves
 
 LOAMX_HD int knn_popcount64(uint64_t v) {
@@ -1109,6 +1112,91 @@ LOAMX_HD int knn_popcount64(uint64_t v) {
 #else
   return __builtin_popcountll(v);
 #endif
+}
+
+// What follows the walk of the 3x3x3 block, shared by the lean forms: is the search over (rigorous bound against the
+// distance to the block's faces), then the exact verification of the k selected candidates. The visited list (begin |
+// first batch << 16 per visited range) starts at word `vis_off` of the per-thread list.
+template <int KM>
+LOAMX_HD int knn_lean_finish(const GridDesc& g, const GridPoint* __restrict__ sp, Vec3 q, int k, double max_dist, double pass_max,
+                             double a, int32_t cx, int32_t cy, int32_t cz, const KnnKeys32<KM>& c, uint64_t started,
+                             const uint32_t* row_scratch, int row_stride, int vis_off, uint32_t pos[KM]) {
+  constexpr uint32_t imask = 0xFFu;
+  // ---- is the search over after the 3x3x3 block? (same test as knn_done, with the rigorous bound)
+  {
+    double guard = kDblMax;
+    const double m = 1e-9 * g.h;
+    const int32_t c3[3] = {cx, cy, cz}, n3[3] = {g.nx, g.ny, g.nz};
+    const double q3[3] = {q.x, q.y, q.z}, o3[3] = {g.ox, g.oy, g.oz};
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) {
+      if (c3[ax] - 1 > 0) {
+        const double d = (q3[ax] - (o3[ax] + (double)(c3[ax] - 1) * g.h)) * (1.0 - 1e-9) - m;
+        guard = d < guard ? d : guard;
+      }
+      if (c3[ax] + 1 < n3[ax] - 1) {
+        const double d = ((o3[ax] + (double)(c3[ax] + 2) * g.h) - q3[ax]) * (1.0 - 1e-9) - m;
+        guard = d < guard ? d : guard;
+      }
+    }
+    if (guard < 0.0) guard = 0.0;
+    const bool done = guard == kDblMax || knn_bound32(c, a, imask) < guard * guard || (max_dist > 0.0 && guard >= max_dist);
+    if (!done) { LOAMX_LEAN_REASON(1); return -1; }
+  }
+  // ---- exact verification of the k selected candidates. Three passes, each unconditional over the KM slots, so that
+  // the list reads, then the 2 * KM point loads, are all in flight together (as five branches they were five round trips)
+  int count = 0, kept = 0;
+  bool undecided = false, open = true;
+  double prev = -1.0, d5 = 0.0;
+  uint32_t vrow[KM];
+#pragma unroll
+  for (int i = 0; i < KM; i++) {
+    const uint32_t tb = (c.key[i] & imask) >> 2;
+    const int ord = knn_popcount64(started & ((2ull << tb) - 1ull)) - 1;  // the visited row this batch belongs to
+    vrow[i] = row_scratch[(vis_off + (ord < 0 ? 0 : (ord > 8 ? 8 : ord))) * row_stride];
+  }
+  GridPoint tp[KM];
+#pragma unroll
+  for (int i = 0; i < KM; i++) {
+    const uint32_t key = c.key[i];
+    const bool real = i >= KM - k && key != 0xFFFFFFFFu;
+    const uint32_t tb = (key & imask) >> 2, ii = key & 3u;
+    const uint32_t pp = real ? (vrow[i] & 0xFFFFu) + (tb - (vrow[i] >> 16)) * 4u + ii : 0u;
+    pos[i] = pp;
+    tp[i] = sp[pp < g.n_points ? pp : 0u];
+  }
+#pragma unroll
+  for (int i = 0; i < KM; i++) {
+    const uint32_t key = c.key[i];
+    const bool real = i >= KM - k && key != 0xFFFFFFFFu;
+    if (real) {
+      if (key >= 0x7F800000u) undecided = true;
+      const double dx = q.x - tp[i].x, dy = q.y - tp[i].y, dz = q.z - tp[i].z;
+      const double d2 = dx * dx + dy * dy + dz * dz;  // as knn_scan_batch
+      if (!(d2 > prev)) undecided = true;             // a tie or an inversion: the exact order is not this one
+      if (!(d2 <= kDblMax)) undecided = true;
+      prev = d2, d5 = d2;
+      count++;
+      if (open) {
+        if (d2 <= pass_max) kept++;
+        else open = false;
+      }
+    }
+  }
+  const uint32_t k6 = c.key[KM];
+  if (count == k && k6 != 0xFFFFFFFFu) {
+    const double t6 = (double)knn_bits_f32(k6 & ~imask);
+    // an upper bound of sqrt(d5) is enough (float square root, rounded up generously)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double sd5 = (double)(__fsqrt_rn((float)d5) * 1.000001f) + 1e-18;
+#else
+    const double sd5 = (double)(sqrtf((float)d5) * 1.000001f) + 1e-18;
+#endif
+    const double err = 2.0 * (3.4641016151377544 * a * sd5 + 3.0 * a * a + 2.384185791015625e-7 * d5);  // x2 safety
+    if (!(t6 > d5 + err)) undecided = true;
+  }
+  if (undecided) LOAMX_LEAN_REASON(2);
+  return undecided ? -1 : kept;
 }
 
 // one batch of four candidates in registers (n = 0: none)
@@ -1299,81 +1387,7 @@ LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cel
 #if defined(LOAMX_LEAN_UNPIPELINED)
   if (p < e || ri < nrow) return -2;  // the trip budget is used up with rows still to look at: the queue's business
 #endif
-  // ---- is the search over after the 3x3x3 block? (same test as knn_done, with the rigorous bound)
-  {
-    double guard = kDblMax;
-    const double m = 1e-9 * g.h;
-    const int32_t c3[3] = {cx, cy, cz}, n3[3] = {g.nx, g.ny, g.nz};
-    const double q3[3] = {q.x, q.y, q.z}, o3[3] = {g.ox, g.oy, g.oz};
-#pragma unroll
-    for (int ax = 0; ax < 3; ax++) {
-      if (c3[ax] - 1 > 0) {
-        const double d = (q3[ax] - (o3[ax] + (double)(c3[ax] - 1) * g.h)) * (1.0 - 1e-9) - m;
-        guard = d < guard ? d : guard;
-      }
-      if (c3[ax] + 1 < n3[ax] - 1) {
-        const double d = ((o3[ax] + (double)(c3[ax] + 2) * g.h) - q3[ax]) * (1.0 - 1e-9) - m;
-        guard = d < guard ? d : guard;
-      }
-    }
-    if (guard < 0.0) guard = 0.0;
-    const bool done = guard == kDblMax || knn_bound32(c, a, imask) < guard * guard || (max_dist > 0.0 && guard >= max_dist);
-    if (!done) { LOAMX_LEAN_REASON(1); return -1; }
-  }
-  // ---- exact verification of the k selected candidates. Three passes, each unconditional over the KM slots, so that
-  // the list reads, then the 2 * KM point loads, are all in flight together (as five branches they were five round trips)
-  int count = 0, kept = 0;
-  bool undecided = false, open = true;
-  double prev = -1.0, d5 = 0.0;
-  uint32_t vrow[KM];
-#pragma unroll
-  for (int i = 0; i < KM; i++) {
-    const uint32_t tb = (c.key[i] & imask) >> 2;
-    const int ord = knn_popcount64(started & ((2ull << tb) - 1ull)) - 1;  // the visited row this batch belongs to
-    vrow[i] = row_scratch[(ord < 0 ? 0 : (ord > 8 ? 8 : ord)) * row_stride];
-  }
-  GridPoint tp[KM];
-#pragma unroll
-  for (int i = 0; i < KM; i++) {
-    const uint32_t key = c.key[i];
-    const bool real = i >= KM - k && key != 0xFFFFFFFFu;
-    const uint32_t tb = (key & imask) >> 2, ii = key & 3u;
-    const uint32_t pp = real ? (vrow[i] & 0xFFFFu) + (tb - (vrow[i] >> 16)) * 4u + ii : 0u;
-    pos[i] = pp;
-    tp[i] = sp[pp < g.n_points ? pp : 0u];
-  }
-#pragma unroll
-  for (int i = 0; i < KM; i++) {
-    const uint32_t key = c.key[i];
-    const bool real = i >= KM - k && key != 0xFFFFFFFFu;
-    if (real) {
-      if (key >= 0x7F800000u) undecided = true;
-      const double dx = q.x - tp[i].x, dy = q.y - tp[i].y, dz = q.z - tp[i].z;
-      const double d2 = dx * dx + dy * dy + dz * dz;  // as knn_scan_batch
-      if (!(d2 > prev)) undecided = true;             // a tie or an inversion: the exact order is not this one
-      if (!(d2 <= kDblMax)) undecided = true;
-      prev = d2, d5 = d2;
-      count++;
-      if (open) {
-        if (d2 <= pass_max) kept++;
-        else open = false;
-      }
-    }
-  }
-  const uint32_t k6 = c.key[KM];
-  if (count == k && k6 != 0xFFFFFFFFu) {
-    const double t6 = (double)knn_bits_f32(k6 & ~imask);
-    // an upper bound of sqrt(d5) is enough (float square root, rounded up generously)
-#if defined(__HIP_DEVICE_COMPILE__)
-    const double sd5 = (double)(__fsqrt_rn((float)d5) * 1.000001f) + 1e-18;
-#else
-    const double sd5 = (double)(sqrtf((float)d5) * 1.000001f) + 1e-18;
-#endif
-    const double err = 2.0 * (3.4641016151377544 * a * sd5 + 3.0 * a * a + 2.384185791015625e-7 * d5);  // x2 safety
-    if (!(t6 > d5 + err)) undecided = true;
-  }
-  if (undecided) LOAMX_LEAN_REASON(2);
-  return undecided ? -1 : kept;
+  return knn_lean_finish<KM>(g, sp, q, k, max_dist, pass_max, a, cx, cy, cz, c, started, row_scratch, row_stride, 0, pos);
 }
 
 

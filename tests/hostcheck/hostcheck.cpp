@@ -469,8 +469,8 @@ void hostcheck_lean_stats(const double* pts, uint64_t n, const double* queries, 
     uint32_t rows[kLeanRowWords], pos[8];
     g_cand = 0, g_lean_trips = g_lean_nrow = g_lean_taken = g_lean_reason = 0;
     const Vec3 q = v3(queries[3 * i], queries[3 * i + 1], queries[3 * i + 2]);
-    const int r = knn_lean_round1<5>(G.g, G.cell_start.data(), G.sp.data(), G.rel.data(), (uint32_t)G.sp.size(), q, (int)k,
-                                     max_dist, pass, pos, rows, 1);
+    const int r = knn_search_f32_round1<5>(G.g, G.cell_start.data(), G.sp.data(), G.rel.data(), (uint32_t)G.sp.size(), q, (int)k,
+                                           max_dist, pass, pos, rows, 1);
     out[5 * i] = g_lean_trips, out[5 * i + 1] = g_lean_nrow, out[5 * i + 2] = g_lean_taken, out[5 * i + 3] = (uint32_t)g_cand;
     out[5 * i + 4] = (uint32_t)(r + 2) | (g_lean_reason << 8);
   }
