@@ -666,7 +666,14 @@ __global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_
   const GridDesc g = gs.desc[pair];
   const uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
   const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
-  for (uint32_t t = chunk0 * kRestThreads + threadIdx.x; t < queued; t += blocks_per_pair * kRestThreads) {
+  // Which queue entries this wavefront takes. A batch wants dense wavefronts (64 consecutive entries: the kernel runs next
+  // to the plane fit and should cost as few issue slots as possible); a handful of pairs leaves the chip empty, and then
+  // the latency of the slowest wavefront is the kernel's time: the entries are dealt out across ALL workgroups, one or
+  // two per wavefront (one 64 x 1024 pair: 480 entries on 276 wavefronts instead of 8 — 71 -> 25 us per launch).
+  const bool spread = B.n_pairs < 8 && (size_t)queued * 4 <= (size_t)blocks_per_pair * kRestThreads;
+  const uint32_t t0 = spread ? chunk0 + blocks_per_pair * threadIdx.x : chunk0 * kRestThreads + threadIdx.x;
+  const uint32_t dt = spread ? 0xFFFFFFFFu - t0 : blocks_per_pair * kRestThreads;  // (spread: one entry per lane)
+  for (uint32_t t = t0; t < queued; t += dt) {
     const uint32_t entry = rest[t], i = entry & 0x7FFFFFFFu;
     const size_t slot = pair * stride + t;  // (queue position, not query index)
     const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
@@ -1511,7 +1518,8 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
   if (be) {  // edge chains, whole
     LOAMX_ASSOC_K(LOAMX_ASSOC_A1, false, be, sa);
     LOAMX_ASSOC_K(LOAMX_ASSOC_A2, false, be, sa);
-    LOAMX_ASSOC_K(LOAMX_ASSOC_B, false, be, sa);
+    // (the brute-force kernel finishes every query itself: with no grid search in the batch nothing is ever queued)
+    if (B.knn_mode_edge != 2u) LOAMX_ASSOC_K(LOAMX_ASSOC_B, false, be, sa);
   }
   if (bp) {
     LOAMX_ASSOC_K(LOAMX_ASSOC_A1, true, bp, s);
@@ -1521,7 +1529,7 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
     hipStream_t sb = aux2 ? aux2 : aux;
     const bool fork2 = fork && hipEventRecord(ev_mid, s) == hipSuccess && hipStreamWaitEvent(sb, ev_mid, 0) == hipSuccess;
     LOAMX_ASSOC_K(LOAMX_ASSOC_A2, true, bp, s);
-    LOAMX_ASSOC_K(LOAMX_ASSOC_B, true, bp, (fork2 ? sb : s));
+    if (B.knn_mode_plane != 2u) LOAMX_ASSOC_K(LOAMX_ASSOC_B, true, bp, (fork2 ? sb : s));
     if (fork2 && aux2 && hipEventRecord(ev_join2, aux2) == hipSuccess) (void)hipStreamWaitEvent(s, ev_join2, 0);
   }
   if (fork && hipEventRecord(ev_join, aux) == hipSuccess) (void)hipStreamWaitEvent(s, ev_join, 0);
