@@ -161,3 +161,35 @@ def test_128_beam_batch_source_and_target_builds_do_not_share_scratch(oracle):
         assert (res[pr]["termination"], res[pr]["iterations"]) == (to, io), pr
         rot, trans = pose_diff(oracle, po, res[pr]["pose"])
         assert rot < 1e-5 and trans < 1e-5, (pr, rot, trans)
+
+
+def test_config5_scan_against_a_million_point_map(oracle):
+    """BASELINE configs[5] at its real size: a 128 x 2048 scan registered against a local map of > 1 M planar points
+    (the planar / edge features of ~27 scans of the scene in one frame), through the plain call and through the persistent
+    target index — bit-identical to each other, and within the 1e-5 bar of the CPU oracle (one oracle registration,
+    ~0.3 s). The feature sets of the map are extracted on the GPU (their index sequences are pinned elsewhere)."""
+    c = ctx()
+    H5, W5 = 128, 2048
+    lidar = capi.LidarParams(H5, W5, 1.0, 120.0)
+    fe = capi.FeatureExtractionParams()
+    src = capi.synth_scan_host(99, 0, 1, H5, W5, 0.01)
+    e5, p5 = c.extract_features(src, lidar, fe)
+    oe5, op5 = oracle.extract_features(src, H5, W5, 1.0, 120.0)
+    assert np.array_equal(e5, oe5) and np.array_equal(p5, op5)
+    maps_p, maps_e, k = [], [], 0
+    while sum(len(m) for m in maps_p) < 1_000_000:
+        s = capi.synth_scan_host(1000 + k, 0, 0, H5, W5, 0.01)
+        e, p = c.extract_features(s, lidar, fe)
+        maps_p.append(s[p]), maps_e.append(s[e])
+        k += 1
+    map_p, map_e = np.ascontiguousarray(np.concatenate(maps_p)), np.ascontiguousarray(np.concatenate(maps_e))
+    assert len(map_p) > 1_000_000
+    pose, term, iters = c.register_features(src[e5], src[p5], map_e, map_p)
+    idx = c.target_index(map_e, map_p)
+    pose_i, term_i, iters_i = c.register_features_indexed(idx, src[e5], src[p5])
+    assert (term_i, iters_i) == (term, iters) and np.array_equal(np.asarray(pose_i), np.asarray(pose))
+    po, to, io = oracle.register_features(src[oe5], src[op5], map_e, map_p)
+    assert (term, iters) == (to, io)
+    rot, trans = pose_diff(oracle, po, np.asarray(pose))
+    assert rot < 1e-5 and trans < 1e-5, (rot, trans)
+    print("config 5: %d map points, %d ICF iterations, SE(3) difference %.1e rad %.1e m" % (len(map_p), iters, rot, trans))
