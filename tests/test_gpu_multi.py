@@ -2,7 +2,10 @@
   * the RCCL gather behind the C ABI (loamx_comm_*, loamx_gather_results_dev), exercised with a 1-rank communicator;
   * the 8-shard x 1 024-pair plan of configs[3] run shard by shard on this GPU: the concatenation equals ONE
     8 192-pair call bit for bit (pairs are independent units: the sharding can not change a result);
-  * the 1 024-pair batch of configs[2] against the CPU oracle on a 64-pair sample."""
+  * the 1 024-pair batch of configs[2] against the CPU oracle on a 64-pair sample;
+  * configs[5] at its real size: a 128 x 2048 scan against a 1.02 M-point map, plain call and persistent index;
+  * the two routes of the LM loop kernel (moments / streaming) against each other and the oracle;
+  * a batch of 128-beam scans (feature sets above 20 480 points: the index builds that need scratch memory)."""
 import os
 
 import numpy as np
