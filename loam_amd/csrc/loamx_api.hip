@@ -645,20 +645,21 @@ int loamx_ctx_create(int device, loamx_ctx** out) {
   }
   ctx->stream = ctx->own_stream;
   // optional: without the auxiliary stream the edge and plane association chains simply run in sequence
-  // The auxiliary stream carries small, latency-bound kernels next to the big ones of the main stream: it gets the
-  // highest priority so that their workgroups are dispatched as soon as they are ready instead of after the main
-  // stream's kernel has handed out all of its own (measured: association 2.61 -> 2.57 ms).
+  // The auxiliary streams carry the small, latency-bound kernels next to the big ones of the main stream. Round 1 gave
+  // them the highest priority (their workgroups dispatched as soon as they are ready: association 2.61 -> 2.57 ms then);
+  // with the round-2 kernels it is the other way round (2.12 -> 2.09 ms at normal priority: the plane k-NN kernel is the
+  // critical path and loses less to its neighbours). LOAMX_AUX_HIGH_PRIO=1 restores the old arrangement.
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   if (!getenv("LOAMX_NO_AUX_STREAM") &&
-      hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, getenv("LOAMX_AUX_NORMAL_PRIO") ? prio_least : prio_greatest) == hipSuccess) {
+      hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, getenv("LOAMX_AUX_HIGH_PRIO") ? prio_greatest : prio_least) == hipSuccess) {
     if (hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_mid, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
       (void)hipStreamDestroy(ctx->aux_stream);
       ctx->aux_stream = nullptr;
     } else if (!getenv("LOAMX_NO_AUX2_STREAM") &&
-               hipStreamCreateWithPriority(&ctx->aux2_stream, hipStreamNonBlocking, getenv("LOAMX_AUX_NORMAL_PRIO") ? prio_least : prio_greatest) == hipSuccess) {
+               hipStreamCreateWithPriority(&ctx->aux2_stream, hipStreamNonBlocking, getenv("LOAMX_AUX_HIGH_PRIO") ? prio_greatest : prio_least) == hipSuccess) {
       if (hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming) != hipSuccess) {
         (void)hipStreamDestroy(ctx->aux2_stream);
         ctx->aux2_stream = nullptr;
