@@ -129,6 +129,14 @@ int loamx_ctx_synchronize(loamx_ctx* ctx);
  *   scan_fallbacks calls in which a scan line gave up its (bounded) wait for the lines before it and the features were
  *                  gathered by the fallback kernel instead — the results are the same */
 int loamx_ctx_extract_counters(loamx_ctx* ctx, uint64_t* tie_replays, uint64_t* scan_fallbacks);
+/* Debug / measurement switches of ONE context (no reference counterpart). loamx_ctx_create reads the environment
+ * variables LOAMX_<NAME> once as the defaults (set = 1); no entry point looks at the environment afterwards, and a
+ * switch only ever affects the context it was set on. None changes a result beyond the summation order of
+ * NO_MOMENTS. Names (DESIGN.md section 5 describes each): FORCE_TIE_REPLAY, FORCE_SCAN_GIVEUP, CURV_V1,
+ * NO_FUSED_COMPACT, NO_MIS_SELECT, FUSED_EXTRACT, NO_MOMENTS, NO_PACKED_GRID, NO_BIG_GRID, NO_GRID_SIDE,
+ * DEBUG_POISON, MAP_CELLS_LOG2 (a number: 0 = default). Unknown name: LOAMX_ERR_BAD_PARAM. */
+int loamx_ctx_set_option(loamx_ctx* ctx, const char* name, int value);
+int loamx_ctx_get_option(loamx_ctx* ctx, const char* name, int* value);
 
 /* ---- host entry points (one scan / one pair; H2D, kernels, D2H, synchronous) ------------------ */
 

@@ -49,11 +49,25 @@ def _obj_path(src):
 
 
 def build(force=False, verbose=False):
-    """One object per .hip source (compiled in parallel, only when the source or a header is newer), then the link."""
+    """One object per .hip source (compiled in parallel, only when the source or a header is newer), then the link.
+    Safe to call from several processes at once (the ranks of a multi-GPU launch on a fresh checkout): one holds the
+    lock and builds, the others wait and find the library up to date; the library appears by an atomic rename."""
     if not force and not needs_build():
         return LIB_PATH
-    from concurrent.futures import ThreadPoolExecutor
+    import fcntl
     os.makedirs(os.path.join(LIB_DIR, "obj"), exist_ok=True)
+    with open(os.path.join(LIB_DIR, "obj", ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():  # somebody else built it while this process waited
+                return LIB_PATH
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
+    from concurrent.futures import ThreadPoolExecutor
     extra = os.environ.get("LOAMX_EXTRA_FLAGS", "").split()  # experiments only, e.g. -DLOAMX_ASSOC_WAVES=6
     flags_tag = os.path.join(LIB_DIR, "obj", "flags.txt")
     flags_now = " ".join(FLAGS + extra)
@@ -73,13 +87,16 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         list(ex.map(compile_one, SOURCES))
     open(flags_tag, "w").write(flags_now)
-    # librccl: the gather of the result records in multi-GPU batch mode (loamx_gather_results_dev)
+    # (librccl — the gather of the result records in multi-GPU batch mode — is opened at run time by the loamx_comm_*
+    # entry points; the rpath lets that dlopen find ROCm's copy when the process has none mapped yet)
     rocm_lib = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
-    cmd = ([_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + [_obj_path(s) for s in SOURCES] +
-           ["-L" + rocm_lib, "-lrccl", "-Wl,-rpath," + rocm_lib])
+    tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+    cmd = ([_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", tmp] + [_obj_path(s) for s in SOURCES] +
+           ["-ldl", "-Wl,-rpath," + rocm_lib])
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 

@@ -86,6 +86,7 @@ EXPORTS = [
     "loamx_target_index_insert", "loamx_target_index_size",
     "loamx_shard_range", "loamx_comm_get_unique_id", "loamx_comm_create", "loamx_comm_wrap", "loamx_comm_destroy",
     "loamx_comm_info", "loamx_gather_results_dev", "loamx_comm_barrier", "loamx_ctx_extract_counters",
+    "loamx_ctx_set_option", "loamx_ctx_get_option",
 ]
 
 _lib = None
@@ -175,6 +176,8 @@ def load(build_if_missing=True):
     lib.loamx_gather_results_dev.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, vp]
     lib.loamx_comm_barrier.argtypes = [vp, vp, dp]
     lib.loamx_ctx_extract_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.loamx_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    lib.loamx_ctx_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
     _lib = lib
     return lib
 
@@ -325,6 +328,15 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.loamx_ctx_synchronize(self.h))
+
+    def set_option(self, name, value=1):
+        """debug / measurement switch of this context (include/loamx.h: loamx_ctx_set_option)"""
+        self._check(self.lib.loamx_ctx_set_option(self.h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_int(0)
+        self._check(self.lib.loamx_ctx_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
 
     def extract_counters(self):
         """(scan lines replayed in the reference's tie order, give-up fallbacks of the fused compaction), cumulative"""

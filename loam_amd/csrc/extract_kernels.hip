@@ -1072,7 +1072,7 @@ __global__ __launch_bounds__(256) void compact_kernel(const T* __restrict__ xyz,
 template <typename T>
 static void launch_curvature_valid_t(const T* d_xyz, const dim3& grid, const ExtractParams& P, double* d_curv, uint8_t* d_mask,
                                      hipStream_t s) {
-  if (P.np == 3 && !getenv("LOAMX_CURV_V1")) {  // the reference's default neighbor_points (features.h:40)
+  if (P.np == 3 && !(P.flags & kFlagCurvV1)) {  // the reference's default neighbor_points (features.h:40)
     const dim3 grid2(grid.x, (P.W + kCurvTilesPerGroup * kTile - 1) / (kCurvTilesPerGroup * kTile));
     launch_kernel((curvature_valid2_kernel<3, T>), grid2, dim3(kCurvThreads), 0, s, d_xyz, P, d_curv, d_mask);
     return;
@@ -1121,7 +1121,7 @@ bool launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, 
   const size_t n_lines = n_scans * P.H;
   if (n_lines == 0 || P.W == 0) return false;
   // the fused compaction keeps the per-sector counts of a line on the lanes of its wavefront
-  const bool fuse = fused && fused->line_tot && P.S <= 64 && !getenv("LOAMX_NO_FUSED_COMPACT");
+  const bool fuse = fused && fused->line_tot && P.S <= 64 && !(P.flags & kFlagNoFusedCompact);
   ExtractFused fz{};
   if (fused) fz = *fused;  // (line_tot / error carry the tie flags either way)
   fz.fuse = fuse ? 1u : 0u;
@@ -1132,7 +1132,7 @@ bool launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, 
   const uint32_t picks = (longest + R) / (R + 1);  // most picks a sector can yield
   const bool mis_ok = R >= 1 && R <= 4 && CH >= R && CH + 2 * R <= 64 &&
                       (picks <= 64 || (picks <= 128 && P.cap_edge <= 64 && P.cap_planar <= 64));
-  if (mis_ok && !getenv("LOAMX_NO_MIS_SELECT")) {
+  if (mis_ok && !(P.flags & kFlagNoMisSelect)) {
     switch (R) {
       case 1: launch_select_mis<1>(d_curv, d_mask, n_lines, P, st, fz, s); return fuse;
       case 2: launch_select_mis<2>(d_curv, d_mask, n_lines, P, st, fz, s); return fuse;
@@ -1157,11 +1157,11 @@ bool launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, 
 bool launch_extract_fused(const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, const ExtractStage& st,
                           const ExtractFused& fz_in, double* d_curv, uint8_t* d_mask, hipStream_t s) {
   const size_t n_lines = n_scans * P.H;
-  // Opt-in (LOAMX_FUSED_EXTRACT=1): measured on 2 048 scans of 64 x 1024, the fused kernel moves 7.9 GB instead of the
+  // Opt-in (context option FUSED_EXTRACT): measured on 2 048 scans of 64 x 1024, the fused kernel moves 7.9 GB instead of the
   // 10.3 GB of the two kernels (PMC FETCH_SIZE x 2 + WRITE_SIZE; 4.2 GB are algorithmic) but takes 2.92 ms against their
   // 0.94 + 1.86 ms: both phases are instruction-bound, so fusing them saves traffic, not time, and the gather of the
   // picked points still re-reads most of the scan (their lines have left the L2 by the time the selection is done).
-  if (n_lines == 0 || P.W == 0 || !getenv("LOAMX_FUSED_EXTRACT") || getenv("LOAMX_NO_FUSED_COMPACT") || getenv("LOAMX_NO_MIS_SELECT")) return false;
+  if (n_lines == 0 || P.W == 0 || !(P.flags & kFlagFusedExtract) || (P.flags & (kFlagNoFusedCompact | kFlagNoMisSelect))) return false;
   const int R = (int)P.np - 1, CH = ((int)P.W + 63) / 64;
   const uint32_t longest = P.W - (P.S - 1) * P.pps;
   const uint32_t picks = (longest + R) / (R + 1);

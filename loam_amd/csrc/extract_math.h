@@ -29,11 +29,16 @@ struct ExtractParams {
   uint32_t cap_planar;
   double min_range, max_range;
   double edge_thr, planar_thr, occ_thr, par_thr;
-  uint32_t flags;        // test switches, never set by the C ABI's callers: kFlagForceReplay, kFlagForceGiveUp
+  uint32_t flags;        // the context's test / measurement switches (loamx_ctx_set_option), never a parameter of the path
 };
 enum : uint32_t {
-  kFlagForceReplay = 1u,  // every scan line takes the tie path (std::sort replay) of the selection kernels
-  kFlagForceGiveUp = 2u   // the fused compaction's chained scan gives up at once (exercises the fallback)
+  kFlagForceReplay = 1u,     // every scan line takes the tie path (std::sort replay) of the selection kernels
+  kFlagForceGiveUp = 2u,     // the fused compaction's chained scan gives up at once (exercises the fallback)
+  // host-side routing only (the kernels never look at these)
+  kFlagCurvV1 = 4u,          // one-column curvature kernel instead of curvature_valid2_kernel<3>
+  kFlagNoFusedCompact = 8u,  // selection writes stage + counts only, compact_kernel gathers
+  kFlagNoMisSelect = 16u,    // arg-max fallback select_kernel for every scan
+  kFlagFusedExtract = 32u    // one-pass extract_fused_kernel where the parameters allow
 };
 
 // features-inl.h:66-67 / features.cpp:22: col < np || col >= W - np in size_t arithmetic.

@@ -10,7 +10,8 @@
 #include <string>
 #include <vector>
 
-#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library itself is opened on first use (struct Rccl below)
 
 #include "loamx_internal.h"
 #include "synth.h"
@@ -60,6 +61,11 @@ struct loamx_ctx {
   bool tail_fresh = false;          // ... and nothing has been enqueued on the stream since
   loamx_kernel_stat stats[LOAMX_K_COUNT] = {};
 
+  // debug / measurement switches (loamx_ctx_set_option; defaults from LOAMX_<NAME>, read once at creation)
+  uint32_t extract_flags = 0;  // kFlag* of extract_math.h
+  uint32_t reg_flags = 0;      // kRegFlag* of loamx_internal.h
+  int map_cells_log2 = 0;      // cell table of a map-sized persistent index (0: kGridMapCellsCap)
+
   unsigned long long sweep_slots_base[2] = {0, 0};
   unsigned long long features_base = 0;  // events[2] at the last loamx_ctx_reset_kernel_stats
   std::mutex mu;
@@ -91,6 +97,17 @@ const char* kKernelNames[LOAMX_K_COUNT] = {"curvature_valid_kernel", "select_ker
                                            "grid_build_kernel",      "associate_kernel", "sweep_kernel",
                                            "lm_kernels",             "moment_kernel",    "knn_plane_kernel",
                                            "extract_fused_kernel"};
+
+struct OptionName {
+  const char* name;
+  bool extract;  // bit of loamx_ctx::extract_flags, else of reg_flags
+  uint32_t bit;
+};
+const OptionName kOptionNames[] = {
+    {"FORCE_TIE_REPLAY", true, kFlagForceReplay}, {"FORCE_SCAN_GIVEUP", true, kFlagForceGiveUp}, {"CURV_V1", true, kFlagCurvV1},
+    {"NO_FUSED_COMPACT", true, kFlagNoFusedCompact}, {"NO_MIS_SELECT", true, kFlagNoMisSelect}, {"FUSED_EXTRACT", true, kFlagFusedExtract},
+    {"NO_MOMENTS", false, kRegFlagNoMoments}, {"NO_PACKED_GRID", false, kRegFlagNoPackedGrid}, {"NO_BIG_GRID", false, kRegFlagNoBigGrid},
+    {"NO_GRID_SIDE", false, kRegFlagNoGridSide}, {"DEBUG_POISON", false, kRegFlagPoison}};
 
 int fail(loamx_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->last_error = msg;
@@ -223,8 +240,7 @@ int make_extract_params(loamx_ctx* ctx, const loamx_lidar_params* lidar, const l
   P.min_range = lidar->min_range, P.max_range = lidar->max_range;
   P.edge_thr = fe->edge_feat_threshold, P.planar_thr = fe->planar_feat_threshold;
   P.occ_thr = fe->occlusion_thresh, P.par_thr = fe->parallel_thresh;
-  // test switches (tests/test_gpu_extract.py): results never depend on them
-  P.flags = (getenv("LOAMX_FORCE_TIE_REPLAY") ? kFlagForceReplay : 0u) | (getenv("LOAMX_FORCE_SCAN_GIVEUP") ? kFlagForceGiveUp : 0u);
+  P.flags = ctx ? ctx->extract_flags : 0u;  // the context's switches: results never depend on them
   return LOAMX_OK;
 }
 
@@ -247,7 +263,7 @@ int make_reg_config(loamx_ctx* ctx, const loamx_reg_params* r, RegConfig& C) {
   C.max_iterations = (uint32_t)r->max_iterations;
   C.rot_thresh = r->rotation_convergence_thresh, C.pos_thresh = r->position_convergence_thresh;
   C.min_associations = (uint32_t)(r->min_associations > 0xFFFFFFFFull ? 0xFFFFFFFFull : r->min_associations);
-  C.flags = getenv("LOAMX_NO_MOMENTS") ? kRegFlagNoMoments : 0u;
+  C.flags = ctx ? ctx->reg_flags : 0u;
   return LOAMX_OK;
 }
 
@@ -305,8 +321,9 @@ int extract_dev(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_scans, con
   const ExtractFused fz{wsp<unsigned long long>(ctx, WS_LINE_TOT), 0u, d_xyz, f32 ? 1u : 0u, d_edge_idx, d_n_edge, d_edge_xyz,
                         edge_capacity(P), d_planar_idx, d_n_planar, d_planar_xyz, planar_capacity(P), d_gave_up, d_events};
   {
-    // rows a5-a10 in one pass over the scan when the parameters allow (the reference's defaults do): 24 B/point read +
-    // (4 + 24) B per feature written; the features are counted on the device (events[2]) for the roofline figure
+    // rows a5-a10 in one pass over the scan — opt-in (context option FUSED_EXTRACT; the two kernels below are the default,
+    // see launch_extract_fused) and only where the parameters allow: 24 B/point read + (4 + 24) B per feature written;
+    // the features are counted on the device (events[2]) for the roofline figure
     TimedScope t(ctx, LOAMX_K_EXTRACT_FUSED, (double)n_scans * (double)N * (f32 ? 12.0 : 24.0), true);
     if (launch_extract_fused(d_xyz, f32, n_scans, P, st, fz, wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), ctx->stream)) {
       launch_replay(wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), n_scans, P, st, fz, ctx->stream);
@@ -450,8 +467,8 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   ENSURE(ctx, WS_SSORTED_E, np * es * sizeof(GridPoint));
   ENSURE(ctx, WS_SSORTED_P, np * ps * sizeof(GridPoint));
   ENSURE(ctx, WS_SORT_SCRATCH, np * (es > ps ? es : ps) * sizeof(GridPoint));
-  // (sets up to kGridSmallCap points are ordered in LDS and need no scratch)
-  ENSURE(ctx, WS_SORT_SCRATCH_SRC, (es > ps ? es : ps) > kGridSmallCap ? np * (es > ps ? es : ps) * sizeof(GridPoint) : sizeof(GridPoint));
+  // (sets the packed build takes are ordered in LDS and need no scratch: the predicate is the launcher's own)
+  ENSURE(ctx, WS_SORT_SCRATCH_SRC, grid_small(es > ps ? es : ps, C.flags) ? sizeof(GridPoint) : np * (es > ps ? es : ps) * sizeof(GridPoint));
   ENSURE(ctx, WS_ASSOC_E, 9 * np * es * sizeof(double));
   ENSURE(ctx, WS_ASSOC_P, 7 * np * ps * sizeof(double));
   ENSURE(ctx, WS_NN_E, (size_t)(1 + kMaxK) * np * es * sizeof(uint32_t));
@@ -479,9 +496,9 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
     untimed(ctx);
     if (fresh) HIP_TRY(ctx, hipMemsetAsync(ctx->ws[WS_COUNTERS].p, 0, 128, ctx->stream));
   }
-  if (getenv("LOAMX_DEBUG_POISON")) {  // debugging: every scratch buffer of the registration starts as 0xFF bytes
+  if (C.flags & kRegFlagPoison) {  // debugging: every scratch buffer of the registration starts as 0xFF bytes
     static const int kScratch[] = {WS_GRID_DESC_E, WS_GRID_DESC_P, WS_CELLS_E, WS_CELLS_P, WS_SORTED_E, WS_SORTED_P, WS_REL_E, WS_REL_P,
-                                   WS_SGRID_DESC_E, WS_SGRID_DESC_P, WS_SCELLS_E, WS_SCELLS_P, WS_SSORTED_E, WS_SSORTED_P, WS_SORT_SCRATCH,
+                                   WS_SGRID_DESC_E, WS_SGRID_DESC_P, WS_SCELLS_E, WS_SCELLS_P, WS_SSORTED_E, WS_SSORTED_P, WS_SORT_SCRATCH, WS_SORT_SCRATCH_SRC,
                                    WS_ASSOC_E, WS_ASSOC_P, WS_NN_E, WS_NN_P, WS_RNN_E, WS_RNN_P, WS_NEAREST_E, WS_NEAREST_P, WS_REST_E,
                                    WS_REST_P, WS_EXACT_E, WS_EXACT_P, WS_NASSOC, WS_STATE, WS_PARTIALS, WS_MOM_PARTIALS, WS_MOMENTS,
                                    WS_FLAGGED_LIST, WS_FLAGGED_COUNT};
@@ -542,7 +559,7 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
     // the source builds next to the target builds on the auxiliary stream: every workgroup of one build kernel is in
     // the same phase at the same time (reads, then writes), two different kernels side by side even the HBM demand
     // out (measured 1.19 -> 1.11 ms per step); not for a few pairs (fork / join latency)
-    const bool side = B.n_pairs >= 8 && !getenv("LOAMX_NO_GRID_SIDE") && ctx->aux_stream && !prebuilt &&
+    const bool side = B.n_pairs >= 8 && !(C.flags & kRegFlagNoGridSide) && ctx->aux_stream && !prebuilt &&
                       hipEventRecord(ctx->ev_fork, s) == hipSuccess && hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0) == hipSuccess;
     if (!prebuilt) launch_grid_build_targets(B, C, s);
     launch_grid_build_sources(B, C, side ? ctx->aux_stream : s);
@@ -644,6 +661,10 @@ int loamx_ctx_create(int device, loamx_ctx** out) {
     return LOAMX_ERR_HIP;
   }
   ctx->stream = ctx->own_stream;
+  // the switches' defaults: the environment, read here and nowhere else
+  for (const OptionName& o : kOptionNames)
+    if (getenv((std::string("LOAMX_") + o.name).c_str())) (o.extract ? ctx->extract_flags : ctx->reg_flags) |= o.bit;
+  if (const char* mc = getenv("LOAMX_MAP_CELLS_LOG2")) ctx->map_cells_log2 = atoi(mc);
   // optional: without the auxiliary stream the edge and plane association chains simply run in sequence
   // The auxiliary streams carry the small, latency-bound kernels next to the big ones of the main stream. Round 1 gave
   // them the highest priority (their workgroups dispatched as soon as they are ready: association 2.61 -> 2.57 ms then);
@@ -713,6 +734,37 @@ int loamx_ctx_synchronize(loamx_ctx* ctx) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return LOAMX_OK;
+}
+
+int loamx_ctx_set_option(loamx_ctx* ctx, const char* name, int value) {
+  if (!ctx || !name) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (!strcmp(name, "MAP_CELLS_LOG2")) {
+    ctx->map_cells_log2 = value;
+    return LOAMX_OK;
+  }
+  for (const OptionName& o : kOptionNames)
+    if (!strcmp(name, o.name)) {
+      uint32_t& w = o.extract ? ctx->extract_flags : ctx->reg_flags;
+      w = value ? (w | o.bit) : (w & ~o.bit);
+      return LOAMX_OK;
+    }
+  return fail(ctx, LOAMX_ERR_BAD_PARAM, std::string("unknown option ") + name);
+}
+
+int loamx_ctx_get_option(loamx_ctx* ctx, const char* name, int* value) {
+  if (!ctx || !name || !value) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (!strcmp(name, "MAP_CELLS_LOG2")) {
+    *value = ctx->map_cells_log2;
+    return LOAMX_OK;
+  }
+  for (const OptionName& o : kOptionNames)
+    if (!strcmp(name, o.name)) {
+      *value = ((o.extract ? ctx->extract_flags : ctx->reg_flags) & o.bit) ? 1 : 0;
+      return LOAMX_OK;
+    }
+  return fail(ctx, LOAMX_ERR_BAD_PARAM, std::string("unknown option ") + name);
 }
 
 int loamx_ctx_extract_counters(loamx_ctx* ctx, uint64_t* tie_replays, uint64_t* scan_fallbacks) {
@@ -999,6 +1051,7 @@ int index_build(loamx_ctx* ctx, loamx_target_index* idx) {
   HIP_TRY(ctx, hipMemcpyAsync(idx->counts, counts, sizeof(counts), hipMemcpyHostToDevice, s));
   RegConfig C{};
   C.r_edge = idx->radius[0], C.r_plane = idx->radius[1];
+  C.flags = ctx->reg_flags;
   RegBatch B{};
   B.n_pairs = 1, B.in_pitch = 1;
   B.edge_stride = idx->cap[0], B.planar_stride = idx->cap[1];
@@ -1008,8 +1061,8 @@ int index_build(loamx_ctx* ctx, loamx_target_index* idx) {
   // hundreds of points of a million-point map into every cell); tables and cursors grow with the set
   size_t scratch_need = kGridBigScratchBytes;
   for (int k = 0; k < 2; k++) {
-    const char* mc = getenv("LOAMX_MAP_CELLS_LOG2");  // experiment knob (16 = the scan-sized table)
-    idx->cells_cap[k] = idx->n[k] > 200000 ? (mc ? (1u << atoi(mc)) : kGridMapCellsCap) : 0u;
+    const int mc = ctx->map_cells_log2;  // experiment knob (16 = the scan-sized table)
+    idx->cells_cap[k] = idx->n[k] > 200000 ? (mc >= 8 && mc <= 24 ? (1u << mc) : kGridMapCellsCap) : 0u;
     if (idx->cells_cap[k] <= kGridCellsCap) idx->cells_cap[k] = 0u;
     const size_t cap = idx->cells_cap[k] ? idx->cells_cap[k] : kGridCellsCap;
     const size_t need = (cap + 1 + 4) * sizeof(uint32_t);  // (+4: the search reads four entries at a time)
@@ -1323,16 +1376,53 @@ struct loamx_comm {
 };
 
 namespace {
+// RCCL is opened when the first loamx_comm_* entry point runs: single-GPU users and the host entry points load
+// libloamx.so on a machine without librccl. (In a process that imported torch first, "librccl.so.1" resolves to the copy
+// torch already mapped: same SONAME.)
+struct Rccl {
+#define LOAMX_RCCL_FN(name) decltype(&::nccl##name) name = nullptr;
+  LOAMX_RCCL_FN(CommCount) LOAMX_RCCL_FN(CommUserRank) LOAMX_RCCL_FN(CommCuDevice) LOAMX_RCCL_FN(GetUniqueId)
+  LOAMX_RCCL_FN(CommInitRank) LOAMX_RCCL_FN(GetErrorString) LOAMX_RCCL_FN(CommDestroy) LOAMX_RCCL_FN(AllGather)
+  LOAMX_RCCL_FN(GroupStart) LOAMX_RCCL_FN(GroupEnd) LOAMX_RCCL_FN(Broadcast) LOAMX_RCCL_FN(AllReduce)
+#undef LOAMX_RCCL_FN
+  std::string error;
+  bool ok = false;
+  Rccl() {
+    void* h = nullptr;
+    for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+      if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) {
+      error = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?");
+      return;
+    }
+    bool all = true;
+#define LOAMX_RCCL_FN(name) all &= (name = reinterpret_cast<decltype(name)>(dlsym(h, "nccl" #name))) != nullptr;
+    LOAMX_RCCL_FN(CommCount) LOAMX_RCCL_FN(CommUserRank) LOAMX_RCCL_FN(CommCuDevice) LOAMX_RCCL_FN(GetUniqueId)
+    LOAMX_RCCL_FN(CommInitRank) LOAMX_RCCL_FN(GetErrorString) LOAMX_RCCL_FN(CommDestroy) LOAMX_RCCL_FN(AllGather)
+    LOAMX_RCCL_FN(GroupStart) LOAMX_RCCL_FN(GroupEnd) LOAMX_RCCL_FN(Broadcast) LOAMX_RCCL_FN(AllReduce)
+#undef LOAMX_RCCL_FN
+    ok = all;
+    if (!ok) error = "librccl lacks an expected ncclXxx symbol";
+  }
+};
+const Rccl& rccl() {
+  static const Rccl r;
+  return r;
+}
+#define RCCL_NEED(ctx)                                                          \
+  do {                                                                          \
+    if (!rccl().ok) return fail(ctx, LOAMX_ERR_COMM, rccl().error);             \
+  } while (0)
 #define NCCL_TRY(ctx, expr)                                                                        \
   do {                                                                                             \
     ncclResult_t r_ = (expr);                                                                      \
-    if (r_ != ncclSuccess) return fail(ctx, LOAMX_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(r_)); \
+    if (r_ != ncclSuccess) return fail(ctx, LOAMX_ERR_COMM, std::string(#expr) + ": " + rccl().GetErrorString(r_)); \
   } while (0)
 
 int comm_finish_init(loamx_ctx* ctx, loamx_comm* c) {
-  NCCL_TRY(ctx, ncclCommCount(c->comm, &c->world));
-  NCCL_TRY(ctx, ncclCommUserRank(c->comm, &c->rank));
-  NCCL_TRY(ctx, ncclCommCuDevice(c->comm, &c->device));
+  NCCL_TRY(ctx, rccl().CommCount(c->comm, &c->world));
+  NCCL_TRY(ctx, rccl().CommUserRank(c->comm, &c->rank));
+  NCCL_TRY(ctx, rccl().CommCuDevice(c->comm, &c->device));
   if (c->device != ctx->device) return fail(ctx, LOAMX_ERR_BAD_PARAM, "communicator and context live on different devices");
   HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&c->d_scalar), 2 * sizeof(double)));
   return LOAMX_OK;
@@ -1351,8 +1441,9 @@ void loamx_shard_range(size_t total_pairs, int world_size, int rank, size_t* fir
 int loamx_comm_get_unique_id(unsigned char id_out[LOAMX_COMM_ID_BYTES]) {
   static_assert(LOAMX_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
   if (!id_out) return LOAMX_ERR_BAD_PARAM;
+  if (!rccl().ok) return LOAMX_ERR_COMM;
   ncclUniqueId id;
-  if (ncclGetUniqueId(&id) != ncclSuccess) return LOAMX_ERR_COMM;
+  if (rccl().GetUniqueId(&id) != ncclSuccess) return LOAMX_ERR_COMM;
   memcpy(id_out, id.internal, NCCL_UNIQUE_ID_BYTES);
   return LOAMX_OK;
 }
@@ -1362,15 +1453,16 @@ int loamx_comm_create(loamx_ctx* ctx, const unsigned char id[LOAMX_COMM_ID_BYTES
   *out = nullptr;
   std::lock_guard<std::mutex> lock(ctx->mu);
   if (world_size < 1 || rank < 0 || rank >= world_size) return fail(ctx, LOAMX_ERR_BAD_PARAM, "bad world size / rank");
+  RCCL_NEED(ctx);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   ncclUniqueId uid;
   memcpy(uid.internal, id, NCCL_UNIQUE_ID_BYTES);
   loamx_comm* c = new loamx_comm;
   c->owned = true;
-  ncclResult_t r = ncclCommInitRank(&c->comm, world_size, uid, rank);
+  ncclResult_t r = rccl().CommInitRank(&c->comm, world_size, uid, rank);
   if (r != ncclSuccess) {
     delete c;
-    return fail(ctx, LOAMX_ERR_COMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    return fail(ctx, LOAMX_ERR_COMM, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
   }
   int rc = comm_finish_init(ctx, c);
   if (rc != LOAMX_OK) {
@@ -1385,6 +1477,7 @@ int loamx_comm_wrap(loamx_ctx* ctx, void* nccl_comm, loamx_comm** out) {
   if (!ctx || !nccl_comm || !out) return LOAMX_ERR_BAD_PARAM;
   *out = nullptr;
   std::lock_guard<std::mutex> lock(ctx->mu);
+  RCCL_NEED(ctx);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   loamx_comm* c = new loamx_comm;
   c->comm = static_cast<ncclComm_t>(nccl_comm), c->owned = false;
@@ -1401,7 +1494,7 @@ void loamx_comm_destroy(loamx_comm* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->d_scalar) (void)hipFree(c->d_scalar);
-  if (c->owned && c->comm) (void)ncclCommDestroy(c->comm);
+  if (c->owned && c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
   delete c;
 }
 
@@ -1430,23 +1523,23 @@ int loamx_gather_results_dev(loamx_ctx* ctx, loamx_comm* c, const loamx_reg_resu
     return LOAMX_OK;
   }
   if (total_pairs % (size_t)c->world == 0) {  // equal shards: one all-gather of n_local * 64 bytes per rank
-    NCCL_TRY(ctx, ncclAllGather(d_local, d_all, n_local * sizeof(loamx_reg_result), ncclChar, c->comm, s));
+    NCCL_TRY(ctx, rccl().AllGather(d_local, d_all, n_local * sizeof(loamx_reg_result), ncclChar, c->comm, s));
     return LOAMX_OK;
   }
   // uneven shards (sizes differ by one): every rank broadcasts its block to its place, as one grouped operation
-  NCCL_TRY(ctx, ncclGroupStart());
+  NCCL_TRY(ctx, rccl().GroupStart());
   for (int r = 0; r < c->world; r++) {
     size_t f = 0, n = 0;
     loamx_shard_range(total_pairs, c->world, r, &f, &n);
     if (n == 0) continue;
-    ncclResult_t rr = ncclBroadcast(r == c->rank ? static_cast<const void*>(d_local) : static_cast<const void*>(d_all + f), d_all + f,
+    ncclResult_t rr = rccl().Broadcast(r == c->rank ? static_cast<const void*>(d_local) : static_cast<const void*>(d_all + f), d_all + f,
                                     n * sizeof(loamx_reg_result), ncclChar, r, c->comm, s);
     if (rr != ncclSuccess) {
-      (void)ncclGroupEnd();
-      return fail(ctx, LOAMX_ERR_COMM, std::string("ncclBroadcast: ") + ncclGetErrorString(rr));
+      (void)rccl().GroupEnd();
+      return fail(ctx, LOAMX_ERR_COMM, std::string("ncclBroadcast: ") + rccl().GetErrorString(rr));
     }
   }
-  NCCL_TRY(ctx, ncclGroupEnd());
+  NCCL_TRY(ctx, rccl().GroupEnd());
   return LOAMX_OK;
 }
 
@@ -1458,7 +1551,7 @@ int loamx_comm_barrier(loamx_ctx* ctx, loamx_comm* c, double* max_value) {
   hipStream_t s = ctx->stream;
   const double v = max_value ? *max_value : 0.0;
   HIP_TRY(ctx, hipMemcpyAsync(c->d_scalar, &v, sizeof(double), hipMemcpyHostToDevice, s));
-  if (c->world > 1) NCCL_TRY(ctx, ncclAllReduce(c->d_scalar, c->d_scalar + 1, 1, ncclDouble, ncclMax, c->comm, s));
+  if (c->world > 1) NCCL_TRY(ctx, rccl().AllReduce(c->d_scalar, c->d_scalar + 1, 1, ncclDouble, ncclMax, c->comm, s));
   else HIP_TRY(ctx, hipMemcpyAsync(c->d_scalar + 1, c->d_scalar, sizeof(double), hipMemcpyDeviceToDevice, s));
   double o = 0.0;
   HIP_TRY(ctx, hipMemcpyAsync(&o, c->d_scalar + 1, sizeof(double), hipMemcpyDeviceToHost, s));

@@ -103,9 +103,13 @@ struct RegConfig {
   uint32_t max_iterations;
   double rot_thresh, pos_thresh;
   uint32_t min_associations;
-  uint32_t flags;  // debug: bit 0 = never use the moments (LOAMX_NO_MOMENTS=1: every evaluation streams the records)
+  uint32_t flags;  // the context's switches (loamx_ctx_set_option): kRegFlag*
 };
-constexpr uint32_t kRegFlagNoMoments = 1u;
+constexpr uint32_t kRegFlagNoMoments = 1u;     // never use the moments: every evaluation streams the records
+constexpr uint32_t kRegFlagNoPackedGrid = 2u;  // scan-sized sets through the single-workgroup index build with the 32-bit table
+constexpr uint32_t kRegFlagNoBigGrid = 4u;     // map-sized sets through the single-workgroup build as well
+constexpr uint32_t kRegFlagNoGridSide = 8u;    // source index builds behind the target builds on the context stream
+constexpr uint32_t kRegFlagPoison = 16u;       // registration scratch starts as 0xFF bytes
 
 // One target feature set's spatial index (device pointers into the workspace)
 struct GridSet {
@@ -208,6 +212,9 @@ constexpr size_t kGridBigScratchBytes = 64 + (size_t)kGridCellsCap * sizeof(uint
 constexpr uint32_t kGridSmallCap = 20480;  // sets up to this size are indexed by the packed single-workgroup build (no scratch)
 constexpr uint32_t kBruteMax = 512;  // target sets up to this size are searched by associate_knn_brute_kernel
 constexpr uint32_t kGridMapCellsCap = 1u << 18;
+// scan-sized sets (the capacity bounds the count) take the packed cell table + LDS lists and need no scratch copy;
+// the workspace is sized with the same predicate the launcher routes by
+inline bool grid_small(size_t stride, uint32_t reg_flags) { return stride <= kGridSmallCap && !(reg_flags & kRegFlagNoPackedGrid); }
 void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_grid_build_sources(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_state_init(const RegBatch& B, const RegConfig& C, hipStream_t s);

@@ -1374,11 +1374,9 @@ inline unsigned per_pair_grid(size_t n_pairs) { return (unsigned)((n_pairs + 63)
 
 }  // namespace
 
-// scan-sized sets (the capacity bounds the count) take the packed cell table + LDS lists
-static bool grid_small(size_t stride) { return stride <= kGridSmallCap && !getenv("LOAMX_NO_PACKED_GRID"); }
 // map-sized target sets: the multi-workgroup build (needs kBigScratchBytes of scratch per pair)
-static bool grid_big(size_t stride, const GridPoint* scratch) {
-  return !grid_small(stride) && scratch != nullptr && stride * sizeof(GridPoint) >= kBigScratchBytes && !getenv("LOAMX_NO_BIG_GRID");
+static bool grid_big(size_t stride, const GridPoint* scratch, uint32_t flags) {
+  return !grid_small(stride, flags) && scratch != nullptr && stride * sizeof(GridPoint) >= kBigScratchBytes && !(flags & kRegFlagNoBigGrid);
 }  // (a caller that sets GridSet::cells_cap provides 64 + 4 * cells_cap bytes of scratch and one pair)
 static void launch_grid_build_big(size_t n_pairs, const double* pts, const uint32_t* n_pts, size_t stride, uint32_t in_pitch,
                                   double max_dist, const GridSet& gs, GridPoint* scratch, hipStream_t s) {
@@ -1407,7 +1405,7 @@ static void debug_ptr(const char* what, const void* p, size_t need) {
 
 template <bool ORDERED>
 static void launch_grid_build(size_t n_pairs, const double* pts, const uint32_t* n_pts, size_t stride, uint32_t in_pitch,
-                              double max_dist, const GridSet& gs, GridPoint* scratch, hipStream_t s) {
+                              double max_dist, const GridSet& gs, GridPoint* scratch, uint32_t flags, hipStream_t s) {
   if (g_debug_sync) {
     fprintf(stderr, "[loamx]   grid build ORDERED=%d n_pairs %zu stride %zu in_pitch %u gs.stride %zu\n", (int)ORDERED, n_pairs, stride, in_pitch, gs.stride);
     debug_ptr("pts", pts, n_pairs * in_pitch * stride * 24);
@@ -1418,11 +1416,11 @@ static void launch_grid_build(size_t n_pairs, const double* pts, const uint32_t*
     if (gs.rel) debug_ptr("rel", gs.rel, n_pairs * 3 * gs.stride * 4);
     if (scratch) debug_ptr("scratch", scratch, n_pairs * gs.stride * sizeof(GridPoint));
   }
-  if (!ORDERED && grid_big(stride, scratch)) {
+  if (!ORDERED && grid_big(stride, scratch, flags)) {
     launch_grid_build_big(n_pairs, pts, n_pts, stride, in_pitch, max_dist, gs, scratch, s);
     return;
   }
-  if (grid_small(stride))
+  if (grid_small(stride, flags))
     launch_kernel((grid_build_kernel<ORDERED, true>), dim3((unsigned)n_pairs), dim3(kBuildThreads), 0, s, pts, n_pts, stride,
                        in_pitch, max_dist, gs, scratch);
   else
@@ -1432,8 +1430,8 @@ static void launch_grid_build(size_t n_pairs, const double* pts, const uint32_t*
 
 void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   if (B.n_pairs == 0) return;
-  launch_grid_build<false>(B.n_pairs, B.tgt_edge, B.n_tgt_edge, B.edge_stride, B.in_pitch, C.r_edge, B.grid_edge, B.sort_scratch, s);
-  launch_grid_build<false>(B.n_pairs, B.tgt_planar, B.n_tgt_planar, B.planar_stride, B.in_pitch, C.r_plane, B.grid_plane, B.sort_scratch, s);
+  launch_grid_build<false>(B.n_pairs, B.tgt_edge, B.n_tgt_edge, B.edge_stride, B.in_pitch, C.r_edge, B.grid_edge, B.sort_scratch, C.flags, s);
+  launch_grid_build<false>(B.n_pairs, B.tgt_planar, B.n_tgt_planar, B.planar_stride, B.in_pitch, C.r_plane, B.grid_plane, B.sort_scratch, C.flags, s);
 }
 
 // source sets: only the cell-sorted (Morton) order is used
@@ -1442,12 +1440,12 @@ void launch_grid_build_sources(const RegBatch& B, const RegConfig& C, hipStream_
   // (the scratch copy is shared by the two source sets: build + rank of one complete before the next one's build starts.
   // It is NOT the target builds' scratch: those run on another stream at the same time, and the multi-workgroup build of a
   // target set above kGridSmallCap points keeps its box keys and cursors there)
-  launch_grid_build<true>(B.n_pairs, B.src_edge, B.n_src_edge, B.edge_stride, B.in_pitch, C.r_edge, B.src_grid_edge, B.sort_scratch_src, s);
-  if (B.edge_stride && !grid_small(B.edge_stride))
+  launch_grid_build<true>(B.n_pairs, B.src_edge, B.n_src_edge, B.edge_stride, B.in_pitch, C.r_edge, B.src_grid_edge, B.sort_scratch_src, C.flags, s);
+  if (B.edge_stride && !grid_small(B.edge_stride, C.flags))
     launch_kernel(grid_rank_kernel, dim3((unsigned)((B.edge_stride + kRankThreads - 1) / kRankThreads), (unsigned)B.n_pairs),
                        dim3(kRankThreads), 0, s, B.n_src_edge, B.edge_stride, B.in_pitch, B.src_grid_edge, B.sort_scratch_src);
-  launch_grid_build<true>(B.n_pairs, B.src_planar, B.n_src_planar, B.planar_stride, B.in_pitch, C.r_plane, B.src_grid_plane, B.sort_scratch_src, s);
-  if (B.planar_stride && !grid_small(B.planar_stride))
+  launch_grid_build<true>(B.n_pairs, B.src_planar, B.n_src_planar, B.planar_stride, B.in_pitch, C.r_plane, B.src_grid_plane, B.sort_scratch_src, C.flags, s);
+  if (B.planar_stride && !grid_small(B.planar_stride, C.flags))
     launch_kernel(grid_rank_kernel, dim3((unsigned)((B.planar_stride + kRankThreads - 1) / kRankThreads), (unsigned)B.n_pairs),
                        dim3(kRankThreads), 0, s, B.n_src_planar, B.planar_stride, B.in_pitch, B.src_grid_plane,
                        B.sort_scratch_src);

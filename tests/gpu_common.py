@@ -1,4 +1,6 @@
 """Shared helpers of the -m gpu parity tests."""
+import contextlib
+
 import numpy as np
 
 from loam_amd import capi
@@ -11,6 +13,18 @@ def ctx():
     if _ctx is None:
         _ctx = capi.Context(0)
     return _ctx
+
+
+@contextlib.contextmanager
+def option(name, value=1, c=None):
+    """a debug switch of the shared context (loamx_ctx_set_option) for the duration of a with-block"""
+    c = c or ctx()
+    old = c.get_option(name)
+    c.set_option(name, value)
+    try:
+        yield
+    finally:
+        c.set_option(name, old)
 
 
 def pose_diff(O, a, b):

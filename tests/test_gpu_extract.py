@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import reference_kats as K
-from gpu_common import ctx, to_capi_fe
+from gpu_common import ctx, option, to_capi_fe
 from loam_amd import capi
 
 pytestmark = pytest.mark.gpu
@@ -75,7 +75,7 @@ def test_dropouts_and_out_of_range(oracle):
 
 
 @pytest.mark.parametrize("H,W", [(32, 512), (8, 2048), (64, 1024)])  # 2048 columns: more than 64 picks per sector, two per lane
-def test_tie_policy_noise_free(oracle, H, W, monkeypatch):
+def test_tie_policy_noise_free(oracle, H, W):
     """Row a7: noise-free scans hold exact curvature ties (356 on a 64 x 1024 scan); where a tie can decide
     a pick or the output order the kernels replay the scan line in the order libstdc++'s std::sort gives the
     reference (features-inl.h:38), so the index sequences are the oracle's std::sort ones — not the stable order."""
@@ -91,9 +91,8 @@ def test_tie_policy_noise_free(oracle, H, W, monkeypatch):
     if not (np.array_equal(oe, se) and np.array_equal(op, sp)):
         assert not (np.array_equal(e, se) and np.array_equal(p, sp))
     # ... and the arg-max fallback kernel detects and replays them too
-    monkeypatch.setenv("LOAMX_NO_MIS_SELECT", "1")
-    e2, p2 = ctx().extract_features(xyz, capi.LidarParams(H, W, 1.0, 120.0))
-    monkeypatch.delenv("LOAMX_NO_MIS_SELECT")
+    with option("NO_MIS_SELECT"):
+        e2, p2 = ctx().extract_features(xyz, capi.LidarParams(H, W, 1.0, 120.0))
     assert np.array_equal(e2, oe) and np.array_equal(p2, op)
     assert ctx().extract_counters()[0] - r0 > replayed
 
@@ -111,7 +110,7 @@ def test_quantised_scan_ties_in_reference_order(oracle, params):
     assert np.array_equal(e, oe) and np.array_equal(p, op)
 
 
-def test_forced_replay_and_forced_fallback_change_nothing(oracle, monkeypatch):
+def test_forced_replay_and_forced_fallback_change_nothing(oracle):
     """The two rare paths on ordinary (tie-free) input: every line through the std::sort replay
     (LOAMX_FORCE_TIE_REPLAY), and every scan line after the first giving up its wait so that the fallback kernel
     gathers the features (LOAMX_FORCE_SCAN_GIVEUP): same sequences, no error, events counted."""
@@ -123,14 +122,13 @@ def test_forced_replay_and_forced_fallback_change_nothing(oracle, monkeypatch):
     e, p = ctx().extract_features(xyz, lidar)
     assert np.array_equal(e, oe) and np.array_equal(p, op)
     assert ctx().extract_counters() == (r0, f0)  # noisy scan: neither path ran
-    monkeypatch.setenv("LOAMX_FORCE_TIE_REPLAY", "1")
-    e, p = ctx().extract_features(xyz, lidar)
-    monkeypatch.delenv("LOAMX_FORCE_TIE_REPLAY")
+    with option("FORCE_TIE_REPLAY"):
+        e, p = ctx().extract_features(xyz, lidar)
     assert np.array_equal(e, oe) and np.array_equal(p, op)
     assert ctx().extract_counters()[0] == r0 + H
     f0 = ctx().extract_counters()[1]  # (tied lines also hand their scan to the fallback compaction)
-    monkeypatch.setenv("LOAMX_FORCE_SCAN_GIVEUP", "1")
-    e, p = ctx().extract_features(xyz, lidar)
+    with option("FORCE_SCAN_GIVEUP"):
+        e, p = ctx().extract_features(xyz, lidar)
     assert np.array_equal(e, oe) and np.array_equal(p, op)
     assert ctx().extract_counters()[1] == f0 + 1
     # the batch entry point with point copies, asynchronously: still the oracle's, and the flag does not stick
@@ -143,11 +141,10 @@ def test_forced_replay_and_forced_fallback_change_nothing(oracle, monkeypatch):
     d_ei, d_pi, d_ne, d_np = c.alloc(ns * ecap * 4), c.alloc(ns * pcap * 4), c.alloc(ns * 4), c.alloc(ns * 4)
     d_ex, d_px = c.alloc(ns * ecap * 24), c.alloc(ns * pcap * 24)
     for forced in (True, False):
-        if not forced:
-            monkeypatch.delenv("LOAMX_FORCE_SCAN_GIVEUP")
         f1 = c.extract_counters()[1]
-        c.extract_features_batch_dev(d_xyz.ptr, ns, lidar, fe, d_ei.ptr, d_ne.ptr, d_ex.ptr, d_pi.ptr, d_np.ptr, d_px.ptr)
-        c.synchronize()
+        with option("FORCE_SCAN_GIVEUP", 1 if forced else 0):
+            c.extract_features_batch_dev(d_xyz.ptr, ns, lidar, fe, d_ei.ptr, d_ne.ptr, d_ex.ptr, d_pi.ptr, d_np.ptr, d_px.ptr)
+            c.synchronize()
         assert c.extract_counters()[1] == f1 + (1 if forced else 0)
         ne, npl = d_ne.download(np.uint32, ns), d_np.download(np.uint32, ns)
         pi = d_pi.download(np.uint32, ns * pcap).reshape(ns, pcap)
@@ -240,7 +237,7 @@ def test_fp32_scan_pairs_equal_fp64_pipeline_on_widened_scans():
         buf.free()
 
 
-def test_fused_and_unfused_compaction_agree(oracle, monkeypatch):
+def test_fused_and_unfused_compaction_agree(oracle):
     """The selection kernel writes the final feature arrays itself (chained scan over the lines of a scan) when
     number_sectors <= 64; otherwise, and with LOAMX_NO_FUSED_COMPACT=1, compact_kernel does. All three routes
     must give the oracle's sequences."""
@@ -251,11 +248,9 @@ def test_fused_and_unfused_compaction_agree(oracle, monkeypatch):
         ofe = oracle.FeParams(*params)
         fe = capi.FeatureExtractionParams(*params)
         se, sp = oracle.extract_features(xyz, H, W, 1.0, 120.0, ofe)
-        monkeypatch.delenv("LOAMX_NO_FUSED_COMPACT", raising=False)
         e1, p1 = ctx().extract_features(xyz, lidar, fe)
-        monkeypatch.setenv("LOAMX_NO_FUSED_COMPACT", "1")
-        e2, p2 = ctx().extract_features(xyz, lidar, fe)
-        monkeypatch.delenv("LOAMX_NO_FUSED_COMPACT", raising=False)
+        with option("NO_FUSED_COMPACT"):
+            e2, p2 = ctx().extract_features(xyz, lidar, fe)
         assert np.array_equal(e1, se) and np.array_equal(p1, sp), params
         assert np.array_equal(e2, se) and np.array_equal(p2, sp), params
 
@@ -289,7 +284,7 @@ def test_batch_extract_many_scans_fused_offsets(oracle):
         b.free()
 
 
-def test_fused_extraction_kernel_equals_the_separate_kernels(oracle, monkeypatch):
+def test_fused_extraction_kernel_equals_the_separate_kernels(oracle):
     """extract_fused_kernel (LOAMX_FUSED_EXTRACT=1: curvature + validity + selection + compaction in one pass over the
     scan) against the oracle and against the default two-kernel path: indices, counts and point copies, double and
     float input, with ties (replayed from the workspace copy the fused kernel leaves for tied lines) and without."""
@@ -305,15 +300,12 @@ def test_fused_extraction_kernel_equals_the_separate_kernels(oracle, monkeypatch
         d_xyz = c.alloc(data.nbytes).upload(data)
         out = {}
         for fused in (True, False):
-            if fused:
-                monkeypatch.setenv("LOAMX_FUSED_EXTRACT", "1")
-            else:
-                monkeypatch.delenv("LOAMX_FUSED_EXTRACT", raising=False)
             d_ei, d_pi, d_ne, d_np = c.alloc(ns * ecap * 4), c.alloc(ns * pcap * 4), c.alloc(ns * 4), c.alloc(ns * 4)
             d_ex, d_px = c.alloc(ns * ecap * 24), c.alloc(ns * pcap * 24)
             r0 = c.extract_counters()[0]
-            c.extract_features_batch_dev(d_xyz.ptr, ns, lidar, fe, d_ei.ptr, d_ne.ptr, d_ex.ptr, d_pi.ptr, d_np.ptr, d_px.ptr, f32=f32)
-            c.synchronize()
+            with option("FUSED_EXTRACT", 1 if fused else 0):
+                c.extract_features_batch_dev(d_xyz.ptr, ns, lidar, fe, d_ei.ptr, d_ne.ptr, d_ex.ptr, d_pi.ptr, d_np.ptr, d_px.ptr, f32=f32)
+                c.synchronize()
             assert c.extract_counters()[0] > r0  # the noise-free scan has tied lines
             ne, npl = d_ne.download(np.uint32, ns), d_np.download(np.uint32, ns)
             ei = d_ei.download(np.uint32, ns * ecap).reshape(ns, ecap)
@@ -330,6 +322,59 @@ def test_fused_extraction_kernel_equals_the_separate_kernels(oracle, monkeypatch
                 e, p, xe, xp = out[fused][s]
                 assert np.array_equal(e, oe) and np.array_equal(p, op), (f32, fused, s)
                 assert np.array_equal(xe, wide[s][oe]) and np.array_equal(xp, wide[s][op])
+
+
+def test_fused_extraction_with_the_rare_paths_forced(oracle):
+    """the one-pass kernel's own tie dump (curvature / mask written out for replay_kernel) and its give-up
+    handling only run when somebody opts in. FUSED_EXTRACT with every line replayed, and with every line after the first
+    giving up its wait: the oracle's sequences and point copies, events counted."""
+    H, W, ns = 32, 1024, 3
+    c = ctx()
+    lidar, fe = capi.LidarParams(H, W, 1.0, 120.0), capi.FeatureExtractionParams()
+    scans = np.stack([capi.synth_scan_host(400 + s, 0, s & 1, H, W, 0.01) for s in range(ns)])
+    d_xyz = c.alloc(scans.nbytes).upload(scans)
+    ecap, pcap = c.edge_capacity(lidar, fe), c.planar_capacity(lidar, fe)
+    d_ei, d_pi, d_ne, d_np = c.alloc(ns * ecap * 4), c.alloc(ns * pcap * 4), c.alloc(ns * 4), c.alloc(ns * 4)
+    d_ex, d_px = c.alloc(ns * ecap * 24), c.alloc(ns * pcap * 24)
+    for forced in ("FORCE_TIE_REPLAY", "FORCE_SCAN_GIVEUP"):
+        r0, f0 = c.extract_counters()
+        with option("FUSED_EXTRACT"), option(forced):
+            c.extract_features_batch_dev(d_xyz.ptr, ns, lidar, fe, d_ei.ptr, d_ne.ptr, d_ex.ptr, d_pi.ptr, d_np.ptr, d_px.ptr)
+            c.synchronize()
+        r1, f1 = c.extract_counters()
+        assert (r1 - r0 == ns * H) if forced == "FORCE_TIE_REPLAY" else (f1 - f0 == 1)
+        ne, npl = d_ne.download(np.uint32, ns), d_np.download(np.uint32, ns)
+        ei = d_ei.download(np.uint32, ns * ecap).reshape(ns, ecap)
+        pi = d_pi.download(np.uint32, ns * pcap).reshape(ns, pcap)
+        ex = d_ex.download(np.float64, ns * ecap * 3).reshape(ns, ecap, 3)
+        px = d_px.download(np.float64, ns * pcap * 3).reshape(ns, pcap, 3)
+        for s in range(ns):
+            oe, op = oracle.extract_features(scans[s], H, W, 1.0, 120.0)
+            assert np.array_equal(ei[s, :ne[s]], oe) and np.array_equal(pi[s, :npl[s]], op), (forced, s)
+            assert np.array_equal(ex[s, :ne[s]], scans[s][oe]) and np.array_equal(px[s, :npl[s]], scans[s][op])
+    for b_ in (d_xyz, d_ei, d_pi, d_ne, d_np, d_ex, d_px):
+        b_.free()
+
+
+def test_context_options_are_per_context_and_named():
+    """loamx_ctx_set_option: unknown names are refused, a switch lives on the context it was set on, and the
+    environment is not consulted after loamx_ctx_create."""
+    import os
+    c = ctx()
+    with pytest.raises(capi.LoamxError):
+        c.set_option("NO_SUCH_SWITCH", 1)
+    assert c.get_option("NO_MOMENTS") == 0
+    os.environ["LOAMX_NO_MOMENTS"] = "1"
+    try:
+        assert c.get_option("NO_MOMENTS") == 0  # (read once, at creation)
+        other = capi.Context(0)
+        assert other.get_option("NO_MOMENTS") == 1  # (the default of a context created now)
+        other.set_option("NO_MOMENTS", 0)
+        other.set_option("NO_PACKED_GRID", 1)
+        assert c.get_option("NO_PACKED_GRID") == 0
+        other.close()
+    finally:
+        del os.environ["LOAMX_NO_MOMENTS"]
 
 
 @pytest.mark.parametrize("seed", range(80))

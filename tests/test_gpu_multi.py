@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from gpu_common import ctx, pose_diff
+from gpu_common import ctx, option, pose_diff
 from loam_amd import capi
 
 pytestmark = pytest.mark.gpu
@@ -25,6 +25,25 @@ def _run(c, d_xyz_ptr, n_pairs, d_res):
     c.register_scan_pairs_dev(d_xyz_ptr, n_pairs, lidar, capi.FeatureExtractionParams(), capi.RegistrationParams(), d_res.ptr)
     c.synchronize()
     return d_res.download(np.uint8, n_pairs * 64).copy()
+
+
+def test_unpacked_index_build_with_poisoned_scratch():
+    """with the packed index build switched off, the ordered source builds scatter into their own
+    scratch copy — which the workspace sized for the packed route only (one GridPoint). The workspace is sized with the
+    launcher's predicate now; this runs the default 64 x 1024 batch through the unpacked builds with every scratch
+    buffer poisoned and wants the packed route's bits back."""
+    c = capi.Context(0)  # (its own workspace: sized by this route, not by whatever ran before)
+    P = 24
+    d_xyz, d_res = c.alloc(P * 2 * N * 24), c.alloc(P * 64)
+    c.synth_scan_pairs_dev(SEED, 900, P, H, W, 0.01, d_xyz.ptr)
+    with option("NO_PACKED_GRID", 1, c), option("DEBUG_POISON", 1, c):
+        slow = _run(c, d_xyz.ptr, P, d_res)
+    ref = _run(c, d_xyz.ptr, P, d_res)
+    d_xyz.free()
+    d_res.free()
+    c.close()
+    assert np.array_equal(slow, ref)
+    assert (ref.view(capi.RESULT_DTYPE)["termination"] == capi.CONVERGED).all()
 
 
 def test_rccl_gather_behind_the_c_abi_one_rank():
@@ -99,7 +118,7 @@ def test_eight_shard_plan_equals_one_8192_pair_call():
     d_res.free()
 
 
-def test_lm_loop_streaming_path_agrees_with_the_moment_path(oracle, monkeypatch):
+def test_lm_loop_streaming_path_agrees_with_the_moment_path(oracle):
     """From the second ICF iteration on one wavefront per pair runs the whole LM solve (lm_pair_loop_kernel): off the
     plane moments, or — when a candidate leaves their validity bound — by streaming the pair's records itself. The bench
     workload never takes the second route; LOAMX_NO_MOMENTS=1 forces it for every evaluation. Both routes must tell the
@@ -110,9 +129,8 @@ def test_lm_loop_streaming_path_agrees_with_the_moment_path(oracle, monkeypatch)
     d_xyz, d_res = c.alloc(P * 2 * N * 24), c.alloc(P * 64)
     c.synth_scan_pairs_dev(SEED, 300, P, H, W, 0.01, d_xyz.ptr)
     ref = _run(c, d_xyz.ptr, P, d_res).view(capi.RESULT_DTYPE)
-    monkeypatch.setenv("LOAMX_NO_MOMENTS", "1")
-    forced = _run(c, d_xyz.ptr, P, d_res).view(capi.RESULT_DTYPE)
-    monkeypatch.delenv("LOAMX_NO_MOMENTS")
+    with option("NO_MOMENTS"):
+        forced = _run(c, d_xyz.ptr, P, d_res).view(capi.RESULT_DTYPE)
     again = _run(c, d_xyz.ptr, P, d_res).view(capi.RESULT_DTYPE)
     d_xyz.free()
     d_res.free()
