@@ -38,13 +38,17 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E peak (6.3 TB/s achievable)
-# vector-instruction issue peak: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md,
-# "Wave scheduling": SIMD-32, a wave issues each VALU instruction over 2 cycles) = 1228.8 G wave-instructions / s
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 2
+# vector-instruction issue peak: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction = 614.4 G
+# wave-instructions / s. MEASURED on this part (tools/probes/lds_unaligned.hip, profiles/r03_probe_lds_valu.txt): streams
+# of independent v_med3_u32 / v_and_or_b32 / v_pk_fma_f32 / v_fma_f64 — the k-NN kernel's own mix — issue one
+# instruction per 4.1-4.3 cycles per SIMD with 4-8 wavefronts resident (5.3-5.5 with one). The guide's "2 cycles
+# (SIMD-32)" did not show for any of them, so round 2's figure (priced against 2 cycles) was half the real fraction.
+VALU_CYCLES_PER_INST = 4
+VALU_PEAK_GINST = 256 * 4 * 2.4 / VALU_CYCLES_PER_INST
 SEED = 20240311
 H, W = 64, 1024
 SIGMA = 0.01
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
 
 
 def parse_args():
@@ -66,6 +70,8 @@ def parse_args():
 def fan_out(args):
     """--gpus N without a launcher: start the N ranks under torch.distributed.run as a child process. Nothing in this
     process has imported torch or touched HIP yet, and this process never re-execs itself."""
+    from loam_amd import build as B
+    B.build()  # hipcc only (no GPU call): the ranks then find the library up to date instead of all building it at once
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -321,8 +327,8 @@ def main():
                                 "valu_instructions_per_launch": insts, "avg_launch_ms": kern["knn_plane_kernel"]["avg_ms"]}
                         if "SQ_THREAD_CYCLES_VALU" in ctr[knn] and "SQ_ACTIVE_INST_VALU" in ctr[knn] and ctr[knn]["SQ_ACTIVE_INST_VALU"] > 0:
                             comp["active_lane_fraction"] = round(ctr[knn]["SQ_THREAD_CYCLES_VALU"] / (64.0 * ctr[knn]["SQ_ACTIVE_INST_VALU"]), 4)
-                            comp["note"] = ("peak = 2 cycles per wave64 instruction (packed FP32 rate); an unpacked 32-bit instruction occupies "
-                                            "its SIMD for 4 cycles, i.e. twice this fraction of the issue slots")
+                            comp["note"] = ("peak = one wave64 vector instruction per 4 cycles per SIMD, measured with the kernel's own "
+                                            "instruction mix (profiles/r03_probe_lds_valu.txt: 4.1-4.3 cycles at 4-8 wavefronts per SIMD)")
                         if ctr[knn].get("TA_BUSY_avr") and ctr[knn].get("GRBM_GUI_ACTIVE"):
                             # second limiter of the same kernel: the texture addressers (per-lane 16-byte gathers of the
                             # candidate batches). TA_BUSY_avr = busy cycles averaged over the TAs, GRBM_GUI_ACTIVE is

@@ -1,11 +1,14 @@
 /** @brief Geometry types of the loam API (drop-in for the reference's loam/include/loam/geometry.h).
  * Pose3d is a plain value type (quaternion + translation); its algebra is a handful of flops and
  * stays on the host exactly like the reference's (loam/src/geometry.cpp:10-29). The line / plane
- * fits of registration run inside the HIP association kernel.
+ * fits of registration run inside the HIP association kernel; geometry_internal::fitLine / fitPlane
+ * (reference geometry.h:102, :123) call the same device functions through loamx_fit_lines / loamx_fit_planes.
  */
 #pragma once
 #include <cmath>
+#include <limits>
 #include <utility>
+#include <vector>
 
 #include "common.h"
 
@@ -69,6 +72,44 @@ struct Plane {
   const double d;
   Plane(Vector3d normal, double d) : normal(normal), d(d) {}
 };
+
+/// K x 3 point matrix as the fits take it: Eigen::MatrixXd when Eigen is installed (the reference's parameter type),
+/// otherwise any container of Vector3d. Both are packed row-major for the C ABI.
+inline std::vector<double> packRows(const std::vector<Vector3d>& points) {
+  std::vector<double> xyz(points.size() * 3);
+  for (size_t i = 0; i < points.size(); i++) xyz[3 * i] = points[i](0), xyz[3 * i + 1] = points[i](1), xyz[3 * i + 2] = points[i](2);
+  return xyz;
+}
+#if LOAM_HAVE_EIGEN
+inline std::vector<double> packRows(const Eigen::MatrixXd& points) {
+  std::vector<double> xyz((size_t)points.rows() * 3);
+  for (Eigen::Index i = 0; i < points.rows(); i++) xyz[3 * i] = points(i, 0), xyz[3 * i + 1] = points(i, 1), xyz[3 * i + 2] = points(i, 2);
+  return xyz;
+}
+#endif
+
+/** @brief Fits a line to K >= 2 points by PCA (reference geometry.h:102, geometry.cpp:42-59): the line through the
+ * centroid along the eigenvector of the largest eigenvalue, as Line(centre + 0.1 dir, centre - 0.1 dir), and the
+ * condition number the reference returns — std::numeric_limits<double>::max() always (geometry.cpp:55-56).
+ * Runs on the device (loamx_fit_lines); K <= 32. */
+template <typename Points>
+std::pair<Line, double> fitLine(const Points& points) {
+  const std::vector<double> xyz = packRows(points);
+  double line[6], cond = std::numeric_limits<double>::max();
+  gpu::check(gpu::defaultContext(), loamx_fit_lines(gpu::defaultContext(), xyz.data(), 1, xyz.size() / 3, line, &cond));
+  return std::make_pair(Line(Vector3d(line[0], line[1], line[2]), Vector3d(line[3], line[4], line[5])), cond);
+}
+
+/** @brief Fits a plane to K >= 3 points: least squares of points * [a b c]^T = 1 by column-pivoted Householder QR,
+ * normal = abc / |abc|, d = 1 / |abc|; second = the signed mean of points * normal - d (reference geometry.h:123,
+ * geometry.cpp:62-73). Runs on the device (loamx_fit_planes); K <= 32. */
+template <typename Points>
+std::pair<Plane, double> fitPlane(const Points& points) {
+  const std::vector<double> xyz = packRows(points);
+  double plane[4], avg = 0.0;
+  gpu::check(gpu::defaultContext(), loamx_fit_planes(gpu::defaultContext(), xyz.data(), 1, xyz.size() / 3, plane, &avg));
+  return std::make_pair(Plane(Vector3d(plane[0], plane[1], plane[2]), plane[3]), avg);
+}
 
 /// Distance between a point and the line through a and b (reference geometry-inl.h:21-27)
 template <typename Vec>

@@ -193,6 +193,48 @@ int loamx_register_features_indexed(loamx_ctx* ctx, const loamx_target_index* in
                                     const double init_pose[7], const loamx_reg_params* reg, loamx_reg_result* result,
                                     loamx_reg_detail* detail);
 
+/* ---- rows a16-a19 one by one (round 3): the reference's internal functions behind registerFeatures, callable from the
+ * host. Same device functions the association kernels run; used by the header shim's geometry_internal / kdtree_internal
+ * namespaces and by the parity tests that compare neighbour lists and fits with the oracle directly. ------------------ */
+
+/* geometry_internal::fitLine (geometry.h:102, geometry.cpp:42-59) for n_sets point sets of k points each
+ * (points: n_sets x k x 3 doubles, 2 <= k <= 32). lines_out: n_sets x 6 = {a, b} with a = centre + 0.1 dir,
+ * b = centre - 0.1 dir; cond_out (may be NULL): the condition number the reference returns, i.e. DBL_MAX always
+ * (geometry.cpp:55-56 computes the ratio and drops it). */
+int loamx_fit_lines(loamx_ctx* ctx, const double* points, size_t n_sets, size_t k, double* lines_out, double* cond_out);
+/* geometry_internal::fitPlane (geometry.h:123, geometry.cpp:62-73), 3 <= k <= 32. planes_out: n_sets x 4 = {normal, d};
+ * avg_dist_out (may be NULL): the signed mean of P n - d. */
+int loamx_fit_planes(loamx_ctx* ctx, const double* points, size_t n_sets, size_t k, double* planes_out, double* avg_dist_out);
+/* kdtree_internal::knnSearch (kdtree.h:49, kdtree.cpp:10-28) for n_queries points against one set of a target index
+ * (which_set: 0 = its edge points, 1 = its planar points; the index plays the role of the reference's KDTree):
+ * exact k nearest (k <= 8), ascending, then the strict radius filter (max_dist <= 0: none). indices_out:
+ * n_queries x k indices into the array the index was built from (0xFFFFFFFF past the count); counts_out: n_queries. */
+int loamx_knn_search(loamx_ctx* ctx, const loamx_target_index* index, int which_set, const double* queries, size_t n_queries,
+                     size_t k, double max_dist, uint32_t* indices_out, uint32_t* counts_out);
+/* registration_internal::associateEdges / associatePlanes (registration.h:205-222, registration.cpp:23-103) at a given
+ * estimate: ONE association pass of the registration kernels themselves (index builds, round-1 k-NN, queue chain,
+ * fits), read out per source feature instead of being handed to the solver. Any pointer may be NULL (skipped).
+ *   *_nn_count  n_src          neighbours that passed the radius filter (kdtree.cpp:25)
+ *   *_nn_idx    n_src x k      their indices in the target array, ascending distance (0xFFFFFFFF past the count)
+ *   *_valid     n_src          1: the reference would add a residual block for this point (all guards passed)
+ *   *_moved     n_src x 3      pose.act(source point) (registration.cpp:34 / :75)
+ *   edge_lines  n_src x 6      fitted line {a, b};  plane_planes  n_src x 4  {normal, d}   (when >= min_*_fit_points) */
+typedef struct {
+  uint32_t* edge_nn_count;
+  uint32_t* edge_nn_idx;
+  uint8_t* edge_valid;
+  double* edge_moved;
+  double* edge_lines;
+  uint32_t* plane_nn_count;
+  uint32_t* plane_nn_idx;
+  uint8_t* plane_valid;
+  double* plane_moved;
+  double* plane_planes;
+} loamx_assoc_dump;
+int loamx_associate(loamx_ctx* ctx, const double* src_edge, size_t n_src_edge, const double* src_planar, size_t n_src_planar,
+                    const double* tgt_edge, size_t n_tgt_edge, const double* tgt_planar, size_t n_tgt_planar,
+                    const double pose[7], const loamx_reg_params* reg, loamx_assoc_dump* out);
+
 /* ---- device-resident batch entry points (asynchronous on the context stream) ------------------ */
 
 /* Feature buffers of scan s live at base + s * stride with

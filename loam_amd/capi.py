@@ -71,6 +71,12 @@ class KernelStat(C.Structure):
 
 RESULT_DTYPE = np.dtype([("pose", np.float64, 7), ("termination", np.uint32), ("iterations", np.uint32)])
 
+class AssocDump(C.Structure):
+    """loamx_assoc_dump (include/loamx.h)"""
+    _fields_ = [(n, C.c_void_p) for n in ("edge_nn_count", "edge_nn_idx", "edge_valid", "edge_moved", "edge_lines",
+                                          "plane_nn_count", "plane_nn_idx", "plane_valid", "plane_moved", "plane_planes")]
+
+
 EXPORTS = [
     "loamx_default_fe_params", "loamx_default_reg_params", "loamx_status_string", "loamx_last_error",
     "loamx_ctx_create", "loamx_ctx_destroy", "loamx_ctx_set_stream", "loamx_ctx_synchronize",
@@ -87,6 +93,7 @@ EXPORTS = [
     "loamx_shard_range", "loamx_comm_get_unique_id", "loamx_comm_create", "loamx_comm_wrap", "loamx_comm_destroy",
     "loamx_comm_info", "loamx_gather_results_dev", "loamx_comm_barrier", "loamx_ctx_extract_counters",
     "loamx_ctx_set_option", "loamx_ctx_get_option",
+    "loamx_fit_lines", "loamx_fit_planes", "loamx_knn_search", "loamx_associate",
 ]
 
 _lib = None
@@ -176,6 +183,11 @@ def load(build_if_missing=True):
     lib.loamx_gather_results_dev.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, vp]
     lib.loamx_comm_barrier.argtypes = [vp, vp, dp]
     lib.loamx_ctx_extract_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.loamx_fit_lines.argtypes = [vp, dp, C.c_size_t, C.c_size_t, dp, dp]
+    lib.loamx_fit_planes.argtypes = [vp, dp, C.c_size_t, C.c_size_t, dp, dp]
+    lib.loamx_knn_search.argtypes = [vp, vp, C.c_int, dp, C.c_size_t, C.c_size_t, C.c_double, vp, vp]
+    lib.loamx_associate.argtypes = [vp, dp, C.c_size_t, dp, C.c_size_t, dp, C.c_size_t, dp, C.c_size_t, dp,
+                                    C.POINTER(RegistrationParams), C.POINTER(AssocDump)]
     lib.loamx_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     lib.loamx_ctx_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
     _lib = lib
@@ -411,6 +423,51 @@ class Context:
                                  for i in range(detail.n_iter_info)])
             return pose, res.termination, res.iterations, d
         return pose, res.termination, res.iterations
+
+    # ---- rows a16-a19 one by one (geometry_internal / kdtree_internal / registration_internal of the reference) ----
+    def fit_lines(self, points):
+        """geometry_internal::fitLine over (n_sets, k, 3) points -> (a (n,3), b (n,3), cond (n,))"""
+        pts = np.ascontiguousarray(points, dtype=np.float64)
+        n, k = pts.shape[0], pts.shape[1]
+        out, cond = np.zeros((n, 6)), np.zeros(n)
+        self._check(self.lib.loamx_fit_lines(self.h, _dp(pts), n, k, _dp(out), _dp(cond)))
+        return out[:, :3].copy(), out[:, 3:].copy(), cond
+
+    def fit_planes(self, points):
+        """geometry_internal::fitPlane over (n_sets, k, 3) points -> (normal (n,3), d (n,), avg signed distance (n,))"""
+        pts = np.ascontiguousarray(points, dtype=np.float64)
+        n, k = pts.shape[0], pts.shape[1]
+        out, avg = np.zeros((n, 4)), np.zeros(n)
+        self._check(self.lib.loamx_fit_planes(self.h, _dp(pts), n, k, _dp(out), _dp(avg)))
+        return out[:, :3].copy(), out[:, 3].copy(), avg
+
+    def knn_search(self, index, which_set, queries, k, max_dist=-1.0):
+        """kdtree_internal::knnSearch for every query against one set of a target index -> list of index arrays"""
+        q = _pts(queries)
+        idx, cnt = np.zeros((len(q), max(k, 1)), dtype=np.uint32), np.zeros(len(q), dtype=np.uint32)
+        self._check(self.lib.loamx_knn_search(self.h, index, which_set, _dp(q), len(q), k, float(max_dist), idx.ctypes.data, cnt.ctypes.data))
+        return [idx[i, :cnt[i]].copy() for i in range(len(q))]
+
+    def associate(self, src_edge, src_planar, tgt_edge, tgt_planar, pose=None, reg=None):
+        """One association pass of the registration kernels at `pose` (registration.cpp:23-103), per source feature:
+        dict(edge=..., plane=...) of dict(nn (list of index arrays), valid, moved, prim)."""
+        reg = reg or RegistrationParams()
+        arrs = [_pts(a) for a in (src_edge, src_planar, tgt_edge, tgt_planar)]
+        pose = np.ascontiguousarray([0, 0, 0, 1, 0, 0, 0] if pose is None else pose, dtype=np.float64)
+        n, k, pw = [len(arrs[0]), len(arrs[1])], [int(reg.num_edge_neighbors), int(reg.num_plane_neighbors)], [6, 4]
+        bufs = []
+        for kind in range(2):
+            bufs.append(dict(cnt=np.zeros(n[kind], dtype=np.uint32), idx=np.full((n[kind], max(k[kind], 1)), 0xFFFFFFFF, dtype=np.uint32),
+                             valid=np.zeros(n[kind], dtype=np.uint8), moved=np.zeros((n[kind], 3)), prim=np.zeros((n[kind], pw[kind]))))
+        d = AssocDump(*[b[f].ctypes.data for b in bufs for f in ("cnt", "idx", "valid", "moved", "prim")])
+        self._check(self.lib.loamx_associate(self.h, _dp(arrs[0]), n[0], _dp(arrs[1]), n[1], _dp(arrs[2]), len(arrs[2]), _dp(arrs[3]),
+                                             len(arrs[3]), _dp(pose), C.byref(reg), C.byref(d)))
+        out = {}
+        for kind, name in enumerate(("edge", "plane")):
+            b = bufs[kind]
+            out[name] = dict(nn=[b["idx"][i, :b["cnt"][i]].copy() for i in range(n[kind])], valid=b["valid"].astype(bool),
+                             moved=b["moved"], prim=b["prim"])
+        return out
 
     # ---- persistent target index (scan-to-map) -----------------------------------------------------------
     def target_index(self, tgt_edge, tgt_planar, reg=None):

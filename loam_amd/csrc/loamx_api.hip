@@ -25,7 +25,7 @@ enum WsId {
   WS_EDGE_IDX, WS_PLANAR_IDX, WS_N_EDGE, WS_N_PLANAR, WS_EDGE_XYZ, WS_PLANAR_XYZ,
   WS_GRID_DESC_E, WS_GRID_DESC_P, WS_CELLS_E, WS_CELLS_P, WS_SORTED_E, WS_SORTED_P, WS_REL_E, WS_REL_P,
   WS_SGRID_DESC_E, WS_SGRID_DESC_P, WS_SCELLS_E, WS_SCELLS_P, WS_SSORTED_E, WS_SSORTED_P, WS_SORT_SCRATCH, WS_SORT_SCRATCH_SRC, WS_ASSOC_E, WS_ASSOC_P, WS_NN_E, WS_NN_P, WS_RNN_E, WS_RNN_P, WS_NEAREST_E, WS_NEAREST_P, WS_REST_E, WS_REST_P, WS_EXACT_E, WS_EXACT_P, WS_NASSOC, WS_STATE, WS_PARTIALS, WS_MOM_PARTIALS, WS_MOMENTS, WS_FLAGGED_LIST, WS_FLAGGED_COUNT, WS_LINE_TOT, WS_EXTRACT_EVENTS,
-  WS_COUNTERS, WS_ITERINFO, WS_SRC_E, WS_SRC_P, WS_TGT_E, WS_TGT_P, WS_FCOUNTS, WS_RESULTS, WS_INIT,
+  WS_COUNTERS, WS_ITERINFO, WS_DUMP_E, WS_DUMP_P, WS_FIT_IN, WS_FIT_OUT, WS_SRC_E, WS_SRC_P, WS_TGT_E, WS_TGT_P, WS_FCOUNTS, WS_RESULTS, WS_INIT,
   WS_COUNT
 };
 
@@ -375,7 +375,8 @@ typedef int (*AfterAssocHook)(loamx_ctx*, const RegBatch&, uint32_t it, void* us
 
 // the launch sequence of one ICF iteration on ctx->stream (+ the auxiliary streams); `it` only selects between the
 // first iteration's sequence (no moment pass) and the later ones'
-int enqueue_icf_iteration(loamx_ctx* ctx, const RegBatch& B, const RegConfig& C, uint32_t it, AfterAssocHook hook, void* hook_user) {
+// the association kernels of one ICF iteration (all feature kinds, all chains), timed as LOAMX_K_ASSOC
+int enqueue_association(loamx_ctx* ctx, const RegBatch& B, const RegConfig& C) {
   hipStream_t s = ctx->stream;
     {
       TimedScope t(ctx, LOAMX_K_ASSOC, 0.0);
@@ -399,6 +400,15 @@ int enqueue_icf_iteration(loamx_ctx* ctx, const RegBatch& B, const RegConfig& C,
       }
     }
     CHECK_LAUNCH(ctx, "associate_kernel");
+  return LOAMX_OK;
+}
+
+int enqueue_icf_iteration(loamx_ctx* ctx, const RegBatch& B, const RegConfig& C, uint32_t it, AfterAssocHook hook, void* hook_user) {
+  hipStream_t s = ctx->stream;
+    {
+      const int rc_assoc = enqueue_association(ctx, B, C);
+      if (rc_assoc != LOAMX_OK) return rc_assoc;
+    }
 #ifdef LOAMX_NN_SAME_STATS
     debug_nn_same(B, it, s);
 #endif
@@ -440,8 +450,11 @@ int enqueue_icf_iteration(loamx_ctx* ctx, const RegBatch& B, const RegConfig& C,
   return LOAMX_OK;
 }
 
+// dump != nullptr (loamx_associate): index builds + ONE association pass at the initial estimate, read out into the
+// host arrays of *dump (one pair); no solve, d_results untouched
 int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_reg_result* d_results, bool want_iter_info,
-                 AfterAssocHook hook, void* hook_user, const loamx_target_index* prebuilt = nullptr) {
+                 AfterAssocHook hook, void* hook_user, const loamx_target_index* prebuilt = nullptr, const loamx_assoc_dump* dump = nullptr,
+                 size_t dump_n_se = 0, size_t dump_n_sp = 0) {
   if (in.n_pairs == 0) return LOAMX_OK;
   untimed(ctx);
   if (in.n_pairs > 0x7FFFFFFFull / 128) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "too many pairs in one call");
@@ -574,6 +587,38 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
     if (prebuilt) tmax[0] = tmin[0] = (uint32_t)prebuilt->n[0], tmax[1] = tmin[1] = (uint32_t)prebuilt->n[1];
     uint32_t* mode[2] = {&B.knn_mode_edge, &B.knn_mode_plane};
     for (int k = 0; k < 2; k++) *mode[k] = tmin[k] > tmax[k] ? 0u : (tmin[k] > kBruteMax ? 1u : (tmax[k] <= kBruteMax ? 2u : 0u));
+  }
+  if (dump) {
+    if (np != 1) return fail(ctx, LOAMX_ERR_BAD_PARAM, "association dump: one pair at a time");
+    int rc_a = enqueue_association(ctx, B, C);
+    if (rc_a != LOAMX_OK) return rc_a;
+    untimed(ctx);
+    const size_t n[2] = {dump_n_se, dump_n_sp}, kq[2] = {(size_t)C.k_edge, (size_t)C.k_plane}, pw[2] = {6, 4};
+    AssocDumpSet D[2] = {};
+    for (int kind = 0; kind < 2; kind++) {
+      const size_t bytes = n[kind] * (24 + 8 * pw[kind] + 4 + 4 * kq[kind] + 1) + 64;
+      ENSURE(ctx, kind ? WS_DUMP_P : WS_DUMP_E, bytes);
+      unsigned char* base = wsp<unsigned char>(ctx, kind ? WS_DUMP_P : WS_DUMP_E);
+      HIP_TRY(ctx, hipMemsetAsync(base, 0, bytes, s));  // (features beyond the capacity, if any, read as "no neighbours")
+      D[kind].moved = reinterpret_cast<double*>(base);
+      D[kind].prim = D[kind].moved + 3 * n[kind];
+      D[kind].nn_count = reinterpret_cast<uint32_t*>(D[kind].prim + pw[kind] * n[kind]);
+      D[kind].nn_idx = D[kind].nn_count + n[kind];
+      D[kind].valid = reinterpret_cast<uint8_t*>(D[kind].nn_idx + kq[kind] * n[kind]);
+      if (n[kind] == 0) D[kind].nn_count = nullptr;
+    }
+    launch_assoc_dump(B, C, D[0], D[1], s);
+    CHECK_LAUNCH(ctx, "assoc_dump_kernel");
+    struct Out { void* host; const void* dev; size_t bytes; };
+    const Out outs[10] = {
+        {dump->edge_nn_count, D[0].nn_count, 4 * n[0]}, {dump->edge_nn_idx, D[0].nn_idx, 4 * kq[0] * n[0]}, {dump->edge_valid, D[0].valid, n[0]},
+        {dump->edge_moved, D[0].moved, 24 * n[0]}, {dump->edge_lines, D[0].prim, 48 * n[0]},
+        {dump->plane_nn_count, D[1].nn_count, 4 * n[1]}, {dump->plane_nn_idx, D[1].nn_idx, 4 * kq[1] * n[1]}, {dump->plane_valid, D[1].valid, n[1]},
+        {dump->plane_moved, D[1].moved, 24 * n[1]}, {dump->plane_planes, D[1].prim, 32 * n[1]}};
+    for (const Out& o : outs)
+      if (o.host && o.bytes && o.dev) HIP_TRY(ctx, hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return LOAMX_OK;
   }
   // (Replaying an ICF iteration as a hipGraph was measured in round 2 — captured once, cached, ~110 kernel nodes over
   // three streams: 13.6 vs 13.1 ms per 1 024-pair step and 1.06 vs 1.07 ms for one pair. The GPU-side turnaround of
@@ -931,11 +976,12 @@ int detail_hook(loamx_ctx* ctx, const RegBatch& B, uint32_t it, void* user) {
 static int register_features_impl(loamx_ctx* ctx, const loamx_target_index* index, const double* src_edge, size_t n_se,
                                   const double* src_planar, size_t n_sp, const double* tgt_edge, size_t n_te,
                                   const double* tgt_planar, size_t n_tp, const double init_pose[7],
-                                  const loamx_reg_params* reg, loamx_reg_result* result, loamx_reg_detail* detail) {
+                                  const loamx_reg_params* reg, loamx_reg_result* result, loamx_reg_detail* detail,
+                                  const loamx_assoc_dump* dump = nullptr) {
   if (!ctx) return LOAMX_ERR_BAD_PARAM;
   std::lock_guard<std::mutex> lock(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (!result || !init_pose) return fail(ctx, LOAMX_ERR_BAD_PARAM, "null argument");
+  if ((!result && !dump) || !init_pose) return fail(ctx, LOAMX_ERR_BAD_PARAM, "null argument");
   RegConfig C;
   int rc = make_reg_config(ctx, reg, C);
   if (rc != LOAMX_OK) return rc;
@@ -973,8 +1019,8 @@ static int register_features_impl(loamx_ctx* ctx, const loamx_target_index* inde
   DetailHook hook{detail, n_se, n_sp};
   if (detail) detail->n_iter_info = 0;
   rc = register_dev(ctx, in, C, wsp<loamx_reg_result>(ctx, WS_RESULTS), detail && detail->iter_info,
-                    detail ? detail_hook : nullptr, &hook, index);
-  if (rc != LOAMX_OK) return rc;
+                    detail ? detail_hook : nullptr, &hook, index, dump, n_se, n_sp);
+  if (rc != LOAMX_OK || dump) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(result, ctx->ws[WS_RESULTS].p, sizeof(loamx_reg_result), hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
   if (detail && detail->iter_info && result->iterations) {
@@ -999,6 +1045,78 @@ int loamx_register_features_indexed(loamx_ctx* ctx, const loamx_target_index* in
   if (!index) return LOAMX_ERR_BAD_PARAM;
   return register_features_impl(ctx, index, src_edge, n_se, src_planar, n_sp, nullptr, 0, nullptr, 0, init_pose, reg, result,
                                 detail);
+}
+
+/* ---- rows a16-a19 one by one ------------------------------------------------------------------------------ */
+int loamx_associate(loamx_ctx* ctx, const double* src_edge, size_t n_se, const double* src_planar, size_t n_sp, const double* tgt_edge,
+                    size_t n_te, const double* tgt_planar, size_t n_tp, const double pose[7], const loamx_reg_params* reg,
+                    loamx_assoc_dump* out) {
+  if (!out) return LOAMX_ERR_BAD_PARAM;
+  return register_features_impl(ctx, nullptr, src_edge, n_se, src_planar, n_sp, tgt_edge, n_te, tgt_planar, n_tp, pose, reg, nullptr,
+                                nullptr, out);
+}
+
+static int fit_sets(loamx_ctx* ctx, bool plane, const double* points, size_t n_sets, size_t k, double* prim_out, double* aux_out) {
+  if (!ctx) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (n_sets == 0) return LOAMX_OK;
+  if (!points || !prim_out) return fail(ctx, LOAMX_ERR_BAD_PARAM, "null argument");
+  if (k < (plane ? 3u : 2u)) return fail(ctx, LOAMX_ERR_BAD_PARAM, plane ? "fitPlane needs k >= 3 points" : "fitLine needs k >= 2 points");
+  if (k > (size_t)kFitMaxK) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "point sets of more than 32 points are not supported by the fit kernels");
+  if (n_sets > 0x7FFFFFFFull / 64) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "too many point sets in one call");
+  const size_t pw = plane ? 4 : 6;
+  untimed(ctx);
+  ENSURE(ctx, WS_FIT_IN, n_sets * k * 24);
+  ENSURE(ctx, WS_FIT_OUT, n_sets * (pw + 1) * sizeof(double));
+  double* d_prim = wsp<double>(ctx, WS_FIT_OUT);
+  double* d_aux = d_prim + n_sets * pw;
+  hipStream_t s = ctx->stream;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_FIT_IN].p, points, n_sets * k * 24, hipMemcpyHostToDevice, s));
+  launch_fit_sets(plane, wsp<double>(ctx, WS_FIT_IN), n_sets, (int)k, d_prim, d_aux, s);
+  CHECK_LAUNCH(ctx, "fit_sets_kernel");
+  HIP_TRY(ctx, hipMemcpyAsync(prim_out, d_prim, n_sets * pw * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (aux_out) HIP_TRY(ctx, hipMemcpyAsync(aux_out, d_aux, n_sets * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return LOAMX_OK;
+}
+
+int loamx_fit_lines(loamx_ctx* ctx, const double* points, size_t n_sets, size_t k, double* lines_out, double* cond_out) {
+  return fit_sets(ctx, false, points, n_sets, k, lines_out, cond_out);
+}
+int loamx_fit_planes(loamx_ctx* ctx, const double* points, size_t n_sets, size_t k, double* planes_out, double* avg_dist_out) {
+  return fit_sets(ctx, true, points, n_sets, k, planes_out, avg_dist_out);
+}
+
+int loamx_knn_search(loamx_ctx* ctx, const loamx_target_index* index, int which_set, const double* queries, size_t n_queries, size_t k,
+                     double max_dist, uint32_t* indices_out, uint32_t* counts_out) {
+  if (!ctx || !index) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (which_set != 0 && which_set != 1) return fail(ctx, LOAMX_ERR_BAD_PARAM, "which_set: 0 = edge points, 1 = planar points");
+  if (n_queries == 0) return LOAMX_OK;
+  if (!queries || !indices_out || !counts_out) return fail(ctx, LOAMX_ERR_BAD_PARAM, "null argument");
+  if (k == 0) {
+    memset(counts_out, 0, n_queries * sizeof(uint32_t));
+    return LOAMX_OK;
+  }
+  if (k > (size_t)kMaxK) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "k > 8 neighbours not supported by the search kernels");
+  if (n_queries > 0x7FFFFFFFull / 64) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "too many queries in one call");
+  untimed(ctx);
+  ENSURE(ctx, WS_FIT_IN, n_queries * 24);
+  ENSURE(ctx, WS_FIT_OUT, n_queries * (k + 1) * sizeof(uint32_t));
+  uint32_t* d_idx = wsp<uint32_t>(ctx, WS_FIT_OUT);
+  uint32_t* d_cnt = d_idx + n_queries * k;
+  hipStream_t s = ctx->stream;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_FIT_IN].p, queries, n_queries * 24, hipMemcpyHostToDevice, s));
+  const int w = which_set;
+  const GridSet gs{index->desc[w], index->cells[w], index->sorted[w], index->cap[w] + kGridPad, index->rel[w], index->cells_cap[w]};
+  launch_knn_queries(gs, wsp<double>(ctx, WS_FIT_IN), n_queries, (int)k, max_dist, d_idx, d_cnt, s);
+  CHECK_LAUNCH(ctx, "knn_queries_kernel");
+  HIP_TRY(ctx, hipMemcpyAsync(indices_out, d_idx, n_queries * k * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(counts_out, d_cnt, n_queries * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return LOAMX_OK;
 }
 
 /* ---- persistent target index ---------------------------------------------------------------------------- */

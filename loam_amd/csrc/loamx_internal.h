@@ -233,6 +233,20 @@ void launch_moments(const RegBatch& B, hipStream_t s);
 void launch_outer_update(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_write_results(const RegBatch& B, loamx_reg_result* d_results, hipStream_t s);
 
+// direct read-outs of rows a16-a19 (loamx_fit_lines / _planes, loamx_knn_search, loamx_associate)
+constexpr int kFitMaxK = 32;  // point sets of the host-callable fits (the association kernels keep <= kMaxK neighbours)
+struct AssocDumpSet {  // device arrays of one feature kind, indexed by the caller's source index
+  uint32_t* nn_count;  // [n_src]
+  uint32_t* nn_idx;    // [n_src][k]
+  uint8_t* valid;      // [n_src]
+  double* moved;       // [n_src][3]
+  double* prim;        // [n_src][6] line a, b | [n_src][4] plane normal, d
+};
+void launch_fit_sets(bool plane, const double* d_pts, size_t n_sets, int k, double* d_prim, double* d_aux, hipStream_t s);
+void launch_knn_queries(const GridSet& gs, const double* d_q, size_t n_q, int k, double max_dist, uint32_t* d_idx, uint32_t* d_count,
+                        hipStream_t s);
+void launch_assoc_dump(const RegBatch& B, const RegConfig& C, const AssocDumpSet& edge, const AssocDumpSet& plane, hipStream_t s);
+
 /* ---- synthetic generator (synth_kernels.hip) --------------------------------------------------- */
 void launch_synth_pairs(uint64_t seed, uint64_t first_pair, size_t n_pairs, uint32_t H, uint32_t W, double sigma,
                         double* d_xyz, hipStream_t s);

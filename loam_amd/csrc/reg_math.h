@@ -548,9 +548,13 @@ LOAMX_HD void knn_general_round(const GridDesc& g, const uint32_t* __restrict__ 
 #if defined(LOAMX_KNN_STATS)
   g_general++;
 #endif
-  int32_t dz = -w, dy = -w;
+  // rows of the cube that exist: a query far outside the grid (w = thousands of cells) must not walk (2 w + 1)^2 row
+  // positions to find the handful inside it
+  const int32_t dy_lo = -w > -cy ? -w : -cy, dy_hi = w < g.ny - 1 - cy ? w : g.ny - 1 - cy;
+  const int32_t dz_lo = -w > -cz ? -w : -cz, dz_hi = w < g.nz - 1 - cz ? w : g.nz - 1 - cz;
+  int32_t dz = dz_lo, dy = dy_lo;
   int sg = 0;
-  bool more = true;
+  bool more = dy_lo <= dy_hi && dz_lo <= dz_hi;
   // squared slab distances of the current row (dy, dz) and of the two end cells cx -+ w: recomputed only
   // when the cursor moves to another row, so that a row out of reach costs a handful of instructions
   double sz2 = slab_dist(q.z, g.oz, g.h, cz + dz), sy2 = slab_dist(q.y, g.oy, g.h, cy + dy);
@@ -596,9 +600,9 @@ LOAMX_HD void knn_general_round(const GridDesc& g, const uint32_t* __restrict__ 
       }
       if (++sg >= nseg) {
         sg = 0;
-        if (++dy > w) {
-          dy = -w;
-          if (++dz > w) more = false;
+        if (++dy > dy_hi) {
+          dy = dy_lo;
+          if (++dz > dz_hi) more = false;
           sz2 = slab_dist(q.z, g.oz, g.h, cz + dz);
           sz2 *= sz2;
         }

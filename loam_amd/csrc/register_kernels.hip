@@ -1372,7 +1372,152 @@ __global__ void write_results_kernel(RegBatch B, loamx_reg_result* __restrict__ 
 
 inline unsigned per_pair_grid(size_t n_pairs) { return (unsigned)((n_pairs + 63) / 64); }
 
+/* ------------------------------------------------------------------------------------------------
+ * Direct read-outs (round 3): the device functions of rows a16-a18 behind host-callable entry points, for the
+ * internal namespaces of the header shim (geometry_internal::fitLine / fitPlane, kdtree_internal::knnSearch) and for
+ * parity tests that compare neighbour lists and fits with the oracle one by one instead of through the poses.
+ * ---------------------------------------------------------------------------------------------- */
+// geometry.cpp:42-73 on n_sets point sets of k points each (k x 3 row-major): the fit_line / fit_plane the association
+// kernels call. prim_out: 6 (a, b) or 4 (normal, d) doubles per set; aux_out: condition number (always DBL_MAX,
+// SURVEY Q6) or the signed mean distance.
+template <bool PLANE, int KM>
+__global__ __launch_bounds__(64) void fit_sets_kernel(const double* __restrict__ pts, size_t n_sets, int k, double* __restrict__ prim_out,
+                                                      double* __restrict__ aux_out) {
+  const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (s >= n_sets) return;
+  Vec3 nb[KM];
+#pragma unroll
+  for (int j = 0; j < KM; j++) {
+    const size_t at = (s * (size_t)k + (size_t)(j < k ? j : 0)) * 3;
+    nb[j] = j < k ? v3(pts[at], pts[at + 1], pts[at + 2]) : v3(0, 0, 0);
+  }
+  if (PLANE) {
+    Vec3 nrm;
+    double d;
+    aux_out[s] = fit_plane<KM>(nb, k, nrm, d);
+    prim_out[4 * s] = nrm.x, prim_out[4 * s + 1] = nrm.y, prim_out[4 * s + 2] = nrm.z, prim_out[4 * s + 3] = d;
+  } else {
+    Vec3 a, b;
+    fit_line<KM>(nb, k, a, b);
+    aux_out[s] = kDblMax;  // geometry.cpp:55-56: the ratio is computed and dropped
+    prim_out[6 * s] = a.x, prim_out[6 * s + 1] = a.y, prim_out[6 * s + 2] = a.z;
+    prim_out[6 * s + 3] = b.x, prim_out[6 * s + 4] = b.y, prim_out[6 * s + 5] = b.z;
+  }
+}
+
+// kdtree.cpp:10-28 for a batch of queries against one indexed set (pair 0 of gs): the complete search of the queue
+// kernels (keyed collector over all rounds, exact collector for what the keys leave undecided). idx_out: k entries per
+// query (indices into the caller's point array, ascending distance; 0xFFFFFFFF past the count).
+template <int KM>
+__global__ __launch_bounds__(64) void knn_queries_kernel(GridSet gs, const double* __restrict__ q, size_t n_q, int k, double max_dist,
+                                                         double pass_max, uint32_t* __restrict__ idx_out, uint32_t* __restrict__ count_out) {
+  __shared__ uint32_t s_rows[kLeanRowWords * 64];
+  const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n_q) return;
+  const GridDesc g = gs.desc[0];
+  uint32_t pos[KM];
+  const int kk = k < KM ? k : KM;
+  const Vec3 p = v3(q[3 * i], q[3 * i + 1], q[3 * i + 2]);
+  int kept;
+  if (g.n_points <= kBruteMax) {
+    // (sets this small are searched exhaustively by the association kernels too, and the index build leaves their cell
+    // table unwritten: grid_build_kernel)
+    KnnResult<KM> r;
+    knn_init(r);
+    brute_scan_tile(r, kk, p, gs.sorted, 0u, g.n_points);  // (the set has kGridPad spare entries behind it)
+    kept = knn_finish(r, kk, max_dist);
+#pragma unroll
+    for (int j = 0; j < KM; j++) pos[j] = 0;
+#pragma unroll
+    for (int j = 0; j < KM; j++)
+      if (j < kk) pos[(KM - kk) + j] = r.pos[j];
+  } else {
+    kept = knn_search_positions<KM>(g, gs.cell_start, gs.sorted, p, kk, max_dist, pass_max, pos, s_rows + threadIdx.x, 64);
+  }
+  count_out[i] = (uint32_t)kept;
+#pragma unroll
+  for (int j = 0; j < KM; j++)
+    if (j < kk) idx_out[i * (size_t)k + j] = j < kept ? gs.sorted[pos[(KM - kk) + j]].orig : 0xFFFFFFFFu;
+  for (int j = KM; j < k; j++) idx_out[i * (size_t)k + j] = 0xFFFFFFFFu;
+}
+
+// One association pass of pair 0 as the association kernels left it (launch_associate): per source feature, by the
+// CALLER's index: neighbour count and target indices in ascending order, the moved point, the fitted primitive, valid.
+// Threads [0, n_src) read the round-1 results, threads [n_src, n_src + queued) the queue's.
+template <bool PLANE, int KM>
+__global__ __launch_bounds__(256) void assoc_dump_kernel(RegBatch B, RegConfig C, AssocDumpSet D) {
+  const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
+  const uint32_t n_raw = PLANE ? B.n_src_planar[0] : B.n_src_edge[0];
+  const uint32_t n_src = n_raw < stride ? n_raw : (uint32_t)stride;
+  const uint32_t queued = B.assoc.n_assoc[PLANE ? 3 : 2];
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_src + queued) return;
+  const GridSet& gs = PLANE ? B.grid_plane : B.grid_edge;
+  const GridSet& src_gs = PLANE ? B.src_grid_plane : B.src_grid_edge;
+  const uint32_t* __restrict__ nn = PLANE ? B.assoc.nn_plane : B.assoc.nn_edge;
+  const uint32_t* __restrict__ rnn = PLANE ? B.assoc.rnn_plane : B.assoc.rnn_edge;
+  const uint32_t* __restrict__ rest = PLANE ? B.assoc.rest_plane : B.assoc.rest_edge;
+  uint32_t i, at;
+  const uint32_t* __restrict__ src;
+  if (t < n_src) {
+    i = t, at = t, src = nn;
+    if (nn[t] == 0xFFFFFFFFu) return;  // queued: written from the queue's results below
+  } else {
+    at = t - n_src, i = rest[at] & 0x7FFFFFFFu, src = rnn;
+  }
+  const uint32_t orig = src_gs.sorted[i].orig;
+  const int kq = PLANE ? C.k_plane : C.k_edge, kk = kq < KM ? kq : KM, shift = KM - kk;
+  const uint32_t kept = src[at];
+  D.nn_count[orig] = kept;
+  for (int j = 0; j < kk; j++) {
+    const uint32_t pos = src[(size_t)(1 + shift + j) * stride + at];
+    D.nn_idx[(size_t)orig * (size_t)kq + j] = (uint32_t)j < kept && pos < gs.stride ? gs.sorted[pos].orig : 0xFFFFFFFFu;
+  }
+  const double* __restrict__ rec = PLANE ? B.assoc.plane : B.assoc.edge;
+  const double f0 = rec[i];
+  D.valid[orig] = f0 == f0 ? 1 : 0;
+  // (an invalid slot holds NaN in field 0: the moved point's x is recomputed from the source point)
+  const GridPoint sq = src_gs.sorted[i];
+  const Vec3 p = pose_act(B.state[0].est, v3(sq.x, sq.y, sq.z));
+  D.moved[3 * (size_t)orig] = p.x, D.moved[3 * (size_t)orig + 1] = rec[stride + i], D.moved[3 * (size_t)orig + 2] = rec[2 * stride + i];
+  for (int f = 0; f < (PLANE ? 4 : 6); f++) D.prim[(size_t)orig * (PLANE ? 4 : 6) + f] = rec[(size_t)(3 + f) * stride + i];
+}
+
 }  // namespace
+
+void launch_fit_sets(bool plane, const double* d_pts, size_t n_sets, int k, double* d_prim, double* d_aux, hipStream_t s) {
+  if (n_sets == 0) return;
+  const dim3 grid((unsigned)((n_sets + 63) / 64));
+  if (k <= 8) {
+    if (plane) launch_kernel((fit_sets_kernel<true, 8>), grid, dim3(64), 0, s, d_pts, n_sets, k, d_prim, d_aux);
+    else launch_kernel((fit_sets_kernel<false, 8>), grid, dim3(64), 0, s, d_pts, n_sets, k, d_prim, d_aux);
+  } else {
+    if (plane) launch_kernel((fit_sets_kernel<true, kFitMaxK>), grid, dim3(64), 0, s, d_pts, n_sets, k, d_prim, d_aux);
+    else launch_kernel((fit_sets_kernel<false, kFitMaxK>), grid, dim3(64), 0, s, d_pts, n_sets, k, d_prim, d_aux);
+  }
+}
+
+void launch_knn_queries(const GridSet& gs, const double* d_q, size_t n_q, int k, double max_dist, uint32_t* d_idx, uint32_t* d_count,
+                        hipStream_t s) {
+  if (n_q == 0) return;
+  const dim3 grid((unsigned)((n_q + 63) / 64));
+  const double pass_max = knn_radius_pass_max(max_dist);
+  if (k <= 5) launch_kernel((knn_queries_kernel<5>), grid, dim3(64), 0, s, gs, d_q, n_q, k, max_dist, pass_max, d_idx, d_count);
+  else launch_kernel((knn_queries_kernel<8>), grid, dim3(64), 0, s, gs, d_q, n_q, k, max_dist, pass_max, d_idx, d_count);
+}
+
+void launch_assoc_dump(const RegBatch& B, const RegConfig& C, const AssocDumpSet& edge, const AssocDumpSet& plane, hipStream_t s) {
+  // (both queues can be as long as the sets: threads for n_src + queued)
+  const dim3 ge((unsigned)((2 * B.edge_stride + 255) / 256)), gp((unsigned)((2 * B.planar_stride + 255) / 256));
+  if (edge.nn_count) {
+    if (C.k_edge <= 5) launch_kernel((assoc_dump_kernel<false, 5>), ge, dim3(256), 0, s, B, C, edge);
+    else launch_kernel((assoc_dump_kernel<false, 8>), ge, dim3(256), 0, s, B, C, edge);
+  }
+  if (plane.nn_count) {
+    if (C.k_plane <= 5) launch_kernel((assoc_dump_kernel<true, 5>), gp, dim3(256), 0, s, B, C, plane);
+    else launch_kernel((assoc_dump_kernel<true, 8>), gp, dim3(256), 0, s, B, C, plane);
+  }
+}
 
 // map-sized target sets: the multi-workgroup build (needs kBigScratchBytes of scratch per pair)
 static bool grid_big(size_t stride, const GridPoint* scratch, uint32_t flags) {

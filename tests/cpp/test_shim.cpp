@@ -3,8 +3,10 @@
 // headers in include/loam/, i.e. through the C ABI on the MI355X. Same inputs, same expected values,
 // same tolerances; a tiny CHECK macro stands in for gtest (not installed in this image).
 // Built and run by tests/test_gpu_cpp_shim.py (needs a GPU).
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <limits>
 #include <memory>
 #include <vector>
 
@@ -276,7 +278,61 @@ static void test_registration() {
   }
 }
 
+// geometry_internal::fitLine / fitPlane (reference geometry.h:102, :123) and kdtree_internal::KDTree / knnSearch
+// (kdtree.h:24-49) through the shim: the reference's tests never call them directly, so the expectations here are
+// analytic (points on a known line / plane) and a brute-force search.
+static void test_internal_namespaces() {
+  {
+    std::vector<Vector3d> pts;
+    const Vector3d o(1.0, -2.0, 0.5), dir(2.0 / 3.0, -1.0 / 3.0, 2.0 / 3.0);
+    for (double t : {-0.4, -0.1, 0.0, 0.3, 0.7}) pts.push_back(o + dir * t);
+    const auto [line, cond] = geometry_internal::fitLine(pts);
+    CHECK(cond == std::numeric_limits<double>::max());  // geometry.cpp:55-56: always DBL_MAX
+    const Vector3d d = line.a - line.b;
+    CHECK_NEAR(d.norm(), 0.2, 1e-12);  // centre +- 0.1 dir (geometry.cpp:53)
+    CHECK_NEAR(std::fabs(d.dot(dir)) / d.norm(), 1.0, 1e-12);
+    for (const auto& p : pts) CHECK_NEAR(geometry_internal::pointToLineDistance(p, line.a, line.b), 0.0, 1e-12);
+  }
+  {
+    std::vector<Vector3d> pts;
+    const Vector3d n(0.6, 0.0, 0.8);  // plane n.p = 2.5
+    for (double u : {-1.0, 0.2, 0.9})
+      for (double v : {-0.5, 0.6}) pts.push_back(n * 2.5 + Vector3d(0.8, 0, -0.6) * u + Vector3d(0, 1, 0) * v);
+    pts.resize(5);
+    const auto [plane, avg] = geometry_internal::fitPlane(pts);
+    CHECK_NEAR(plane.d, 2.5, 1e-12);
+    for (int i = 0; i < 3; i++) CHECK_NEAR(plane.normal(i), n(i), 1e-12);
+    CHECK_NEAR(avg, 0.0, 1e-12);
+  }
+  {
+    std::vector<Vector3d> data;
+    unsigned s = 12345;
+    auto rnd = [&] { s = s * 1664525u + 1013904223u; return (double)(s >> 8) / 16777216.0 * 10.0 - 5.0; };
+    for (int i = 0; i < 3000; i++) data.push_back(Vector3d(rnd(), rnd(), rnd()));
+    kdtree_internal::KDTreeDataAdaptor adaptor(data);
+    kdtree_internal::KDTree tree(3, adaptor, kdtree_internal::KDTreeParams(20));  // registration-inl.h:20-23
+    for (int q = 0; q < 50; q++) {
+      const Vector3d query(rnd(), rnd(), rnd());
+      for (double radius : {-1.0, 0.6}) {
+        const std::vector<size_t> got = kdtree_internal::knnSearch(tree, query, 5, radius);
+        std::vector<std::pair<double, size_t>> all;
+        for (size_t i = 0; i < data.size(); i++) all.emplace_back((data[i] - query).squaredNorm(), i);
+        std::sort(all.begin(), all.end());
+        size_t want = 0;
+        while (want < 5 && (radius <= 0 || std::sqrt(all[want].first) < radius)) want++;
+        CHECK(got.size() == want);
+        for (size_t j = 0; j < got.size() && j < want; j++) CHECK(got[j] == all[j].second);
+      }
+    }
+    std::vector<Vector3d> none;
+    kdtree_internal::KDTreeDataAdaptor empty_adaptor(none);
+    kdtree_internal::KDTree empty(3, empty_adaptor, kdtree_internal::KDTreeParams(20));
+    CHECK(kdtree_internal::knnSearch(empty, Vector3d(0, 0, 0), 5, 1.0).empty());
+  }
+}
+
 int main() {
+  test_internal_namespaces();
   test_curvature();
   test_valid_points();
   test_float_points();

@@ -1,0 +1,209 @@
+"""GPU parity, rows a16-a19 ONE BY ONE: the neighbour lists of knnSearch (order included), the
+lines of fitLine and the planes of fitPlane as the association kernels produce them, against the oracle's own
+functions — not through valid-sets and poses. Entry points: loamx_associate (one association pass of the registration
+kernels, read out per source feature), loamx_knn_search, loamx_fit_lines, loamx_fit_planes (include/loamx.h).
+Reference: kdtree.cpp:10-28, geometry.cpp:42-73, registration.cpp:23-103."""
+import numpy as np
+import pytest
+
+import reference_kats as K
+from gpu_common import ctx
+from loam_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+IDENT = np.array([0, 0, 0, 1.0, 0, 0, 0])
+
+
+def line_tol(pts):
+    """what two correct eigen-solvers may differ by on this point set: rounding x conditioning of the top eigenvector"""
+    c = pts - pts.mean(axis=0)
+    w = np.linalg.eigvalsh(c.T @ c)
+    gap = max(w[2] - w[1], 1e-300)
+    return 1e-12 + 4e-16 * max(w[2], 1e-300) / gap * (1.0 + np.abs(pts).max())
+
+
+def check_kind(oracle, name, dump, src, tgt, pose, is_plane, oreg, ties=False):
+    d = dump["plane" if is_plane else "edge"]
+    k = oreg.num_plane_neighbors if is_plane else oreg.num_edge_neighbors
+    radius = oreg.max_plane_neighbor_dist if is_plane else oreg.max_edge_neighbor_dist
+    if len(src) == 0:
+        return 0
+    if len(tgt) == 0:
+        assert not d["valid"].any() and all(len(x) == 0 for x in d["nn"])
+        return 0
+    valid, nearest, moved, prims = oracle.associate(src, tgt, pose, is_plane, oreg)
+    assert np.array_equal(d["valid"], valid), name
+    assert np.abs(d["moved"] - moved).max() <= 1e-12 * (1.0 + np.abs(moved).max()), name
+    tree = oracle.KDTree(tgt)
+    checked = 0
+    for i in range(len(src)):
+        want = tree.knn(moved[i], k, radius)
+        got = d["nn"][i]
+        assert len(got) == len(want), (name, i)
+        if not np.array_equal(got, want.astype(np.uint32)):
+            # equal distances (lattice scenes): nanoflann's order among ties is its traversal order;
+            # the distances themselves must be the same numbers in the same order
+            assert ties, (name, i, got, want)
+            dg = ((tgt[got] - moved[i]) ** 2).sum(axis=1)
+            dw = ((tgt[want.astype(np.int64)] - moved[i]) ** 2).sum(axis=1)
+            assert np.array_equal(dg, dw), (name, i)
+            continue
+        if valid[i]:
+            assert got[0] == nearest[i]
+            err = np.abs(d["prim"][i] - prims[i]).max()
+            if err > 1e-12:  # (the conditioning of the point set, computed only when the plain bar is missed)
+                nb = tgt[got]
+                if is_plane:
+                    assert err <= 1e-12 * (1.0 + np.linalg.cond(nb) ** 2 * 1e-3), (name, i)
+                else:
+                    a, b, oa, ob = d["prim"][i, :3], d["prim"][i, 3:], prims[i, :3], prims[i, 3:]
+                    flip = max(np.abs(a - ob).max(), np.abs(b - oa).max())  # (the direction's sign: the residual is symmetric in a, b)
+                    assert min(err, flip) <= line_tol(nb), (name, i, err, flip)
+            checked += 1
+    return checked
+
+
+@pytest.mark.parametrize("H,W,seed,pair", [(64, 1024, 20240311, 0), (64, 1024, 7, 1), (32, 512, 3, 2)])
+def test_associate_lists_and_fits_on_scan_pairs(oracle, H, W, seed, pair):
+    """the bench workload's pairs: every plane / edge query's neighbour list in order, every line and plane"""
+    A = capi.synth_scan_host(seed, pair, 0, H, W, 0.01)
+    B = capi.synth_scan_host(seed, pair, 1, H, W, 0.01)
+    ea, pa = oracle.extract_features(A, H, W, 1.0, 120.0)
+    eb, pb = oracle.extract_features(B, H, W, 1.0, 120.0)
+    oreg = oracle.RegParams()
+    # at the identity (first ICF iteration) and at the oracle's estimate after one iteration (second iteration's input)
+    _, _, _, info = oracle.register_features(B[eb], B[pb], A[ea], A[pa], want_info=True)
+    est1 = oracle.pose_compose(np.array(list(info[0].update)), IDENT)
+    for pose in (IDENT, est1):
+        dump = ctx().associate(B[eb], B[pb], A[ea], A[pa], pose)
+        ne = check_kind(oracle, "edge", dump, B[eb], A[ea], pose, False, oreg)
+        npl = check_kind(oracle, "plane", dump, B[pb], A[pa], pose, True, oreg)
+        assert ne > 50 and npl > 2000
+
+
+def test_associate_on_the_reference_scene_with_ties(oracle):
+    """tests/test_registration.cpp:8-56: regular 0.05 m grids, every query has equidistant neighbours"""
+    tgt_e, tgt_p = K.registration_scene()
+    case = K.REGISTRATION_CASES[1]
+    src_e = K.transform_points(case["source_T_target"], tgt_e)
+    src_p = K.transform_points(case["source_T_target"], tgt_p)
+    pose = IDENT if case["init"] is None else np.asarray(case["init"], dtype=np.float64)
+    dump = ctx().associate(src_e, src_p, tgt_e, tgt_p, pose)
+    oreg = oracle.RegParams()
+    check_kind(oracle, "edge", dump, src_e, tgt_e, pose, False, oreg, ties=True)
+    check_kind(oracle, "plane", dump, src_p, tgt_p, pose, True, oreg, ties=True)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_associate_fuzz_lists_and_fits(oracle, seed):
+    """random clouds (planes, lines, blobs, sparse shells, anisotropic lattices), random k and radii, sets on both sides
+    of the brute-force / grid / queue thresholds"""
+    rng = np.random.default_rng(7000 + seed)
+
+    def cloud(n):
+        kind = rng.integers(0, 5)
+        if kind == 0:
+            o, u, v = rng.normal(size=3) * 3, rng.normal(size=3), rng.normal(size=3)
+            pts = o + np.outer(rng.uniform(-4, 4, n), u / np.linalg.norm(u)) + np.outer(rng.uniform(-4, 4, n), v / np.linalg.norm(v))
+            pts += rng.normal(size=pts.shape) * 0.01
+        elif kind == 1:
+            pts = np.concatenate([rng.normal(size=3) * 4 + np.outer(np.linspace(-3, 3, max(2, n // 3)), rng.normal(size=3)) for _ in range(3)])[:n]
+            pts = pts + rng.normal(size=pts.shape) * 0.004
+        elif kind == 2:
+            pts = rng.normal(size=(n, 3)) * rng.uniform(0.3, 5.0)
+        elif kind == 3:
+            d = rng.normal(size=(n, 3))
+            pts = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(5, 30)
+            pts[: n // 10] = rng.normal(size=(n // 10, 3)) * 0.2 + 100.0
+        else:
+            g = int(round(n ** (1 / 3))) + 1
+            pts = np.stack(np.meshgrid(np.arange(g) * 0.25, np.arange(g) * 0.27, np.arange(g) * 0.31), -1).reshape(-1, 3)[:n]
+        return np.ascontiguousarray(pts + rng.normal(size=3)), kind == 4
+
+    n_e, n_p = int(rng.choice([0, 3, 7, 60, 400, 700])), int(rng.choice([4, 9, 150, 2000, 6000]))
+    (tgt_e, tie_e), (tgt_p, tie_p) = (cloud(n_e) if n_e else (np.zeros((0, 3)), False)), cloud(n_p)
+    ax = rng.normal(size=3)
+    T = K.pose7(K.quat_angle_axis(rng.uniform(0, 0.05), ax / np.linalg.norm(ax)), rng.normal(size=3) * 0.05)
+    src_e = K.transform_points(T, tgt_e[rng.random(len(tgt_e)) < 0.8]) if len(tgt_e) else tgt_e
+    src_p = K.transform_points(T, tgt_p[rng.random(len(tgt_p)) < 0.8])
+    src_e = src_e + rng.normal(size=src_e.shape) * 0.003
+    src_p = src_p + rng.normal(size=src_p.shape) * 0.003
+    reg, oreg = capi.RegistrationParams(), oracle.RegParams()
+    reg.num_edge_neighbors = oreg.num_edge_neighbors = int(rng.choice([2, 3, 5, 8]))
+    reg.num_plane_neighbors = oreg.num_plane_neighbors = int(rng.choice([4, 5, 7, 8]))
+    reg.min_line_fit_points = oreg.min_line_fit_points = int(rng.choice([2, 3]))
+    reg.max_plane_neighbor_dist = oreg.max_plane_neighbor_dist = float(rng.choice([0.5, 2.0, -1.0]))
+    reg.max_edge_neighbor_dist = oreg.max_edge_neighbor_dist = float(rng.choice([0.3, 1.0, -1.0]))
+    pose = K.pose7(K.quat_angle_axis(rng.uniform(0, 0.02), ax / np.linalg.norm(ax)), rng.normal(size=3) * 0.02)
+    dump = ctx().associate(src_e, src_p, tgt_e, tgt_p, pose, reg)
+    check_kind(oracle, f"edge {seed}", dump, src_e, tgt_e, pose, False, oreg, ties=tie_e)
+    check_kind(oracle, f"plane {seed}", dump, src_p, tgt_p, pose, True, oreg, ties=tie_p)
+
+
+def test_fit_entry_points_against_the_oracle(oracle):
+    """geometry_internal::fitLine / fitPlane (geometry.h:102, :123) through loamx_fit_lines / loamx_fit_planes: every k
+    the reference accepts up to 32, including the k > 8 route the association kernels never take"""
+    rng = np.random.default_rng(11)
+    for k in (2, 3, 4, 5, 8, 9, 20, 32):
+        n = 200
+        o = rng.normal(size=(n, 1, 3)) * 5
+        u = rng.normal(size=(n, 1, 3))
+        line_pts = o + rng.uniform(-1, 1, (n, k, 1)) * u / np.linalg.norm(u, axis=2, keepdims=True) + rng.normal(size=(n, k, 3)) * 0.01
+        a, b, cond = ctx().fit_lines(line_pts)
+        assert (cond == np.finfo(np.float64).max).all()  # geometry.cpp:55-56
+        for i in range(n):
+            oa, ob, oc = oracle.fit_line(line_pts[i])
+            tol = line_tol(line_pts[i])
+            assert min(max(np.abs(a[i] - oa).max(), np.abs(b[i] - ob).max()), max(np.abs(a[i] - ob).max(), np.abs(b[i] - oa).max())) <= tol, (k, i)
+        if k < 3:
+            continue
+        v = rng.normal(size=(n, 1, 3))
+        plane_pts = o + rng.uniform(-1, 1, (n, k, 1)) * u + rng.uniform(-1, 1, (n, k, 1)) * v + rng.normal(size=(n, k, 3)) * 0.005
+        nrm, d, avg = ctx().fit_planes(plane_pts)
+        for i in range(n):
+            on, od, oavg = oracle.fit_plane(plane_pts[i])
+            tol = 1e-12 * (1.0 + np.linalg.cond(plane_pts[i]) ** 2 * 1e-3)
+            assert np.abs(nrm[i] - on).max() <= tol and abs(d[i] - od) <= tol * (1 + abs(od)) and abs(avg[i] - oavg) <= tol, (k, i)
+    with pytest.raises(capi.LoamxError):
+        ctx().fit_lines(np.zeros((1, 1, 3)))
+    with pytest.raises(capi.LoamxError):
+        ctx().fit_planes(np.zeros((1, 33, 3)))
+
+
+def test_fit_line_entry_point_on_degenerate_lattices(oracle):
+    """neighbours on a lattice: covariance exactly diagonal with two EQUAL eigenvalues — "the" direction is the one
+    Eigen's selection sort leaves last (oracle symeig3 / reg_math.h fit_line)"""
+    for s in ([0.25, 0.0, 0.0], [0.0, 0.5, 0.0], [0.0, 0.0, 0.125]):
+        for t in ([0.25, 0.0, 0.0], [0.0, 0.5, 0.0], [0.0, 0.0, 0.125]):
+            pts = np.array([[0, 0, 0], s, [-x for x in s], t, [-x for x in t]], dtype=np.float64) + 2.0
+            a, b, _ = ctx().fit_lines(pts[None])
+            oa, ob, _ = oracle.fit_line(pts)
+            assert (np.array_equal(a[0], oa) and np.array_equal(b[0], ob)) or (np.array_equal(a[0], ob) and np.array_equal(b[0], oa)), (s, t)
+
+
+def test_knn_entry_point_against_the_oracle_tree(oracle):
+    """kdtree_internal::knnSearch (kdtree.h:49) through loamx_knn_search on a target index: index lists in order for
+    k = 1..8, with and without the radius, queries inside, outside and far from the set; the empty set"""
+    rng = np.random.default_rng(3)
+    c = ctx()
+    for n, scale in ((37, 1.0), (600, 3.0), (30000, 8.0)):
+        pts = rng.normal(size=(n, 3)) * scale
+        index = c.target_index(pts[: n // 3], pts)  # edge set = a third of the points, planar set = all of them
+        tree_p, tree_e = oracle.KDTree(pts), oracle.KDTree(pts[: n // 3])
+        q = np.concatenate([pts[rng.integers(0, n, 150)] + rng.normal(size=(150, 3)) * 0.05, rng.normal(size=(40, 3)) * scale * 3,
+                            np.array([[1e3, -1e3, 5e2]])])
+        for k in (1, 3, 5, 8):
+            for radius in (-1.0, 0.4 * scale, 0.02):
+                got = c.knn_search(index, 1, q, k, radius)
+                for i in range(len(q)):
+                    assert np.array_equal(got[i], tree_p.knn(q[i], k, radius).astype(np.uint32)), (n, k, radius, i)
+        got = c.knn_search(index, 0, q, 5, -1.0)
+        for i in range(len(q)):
+            assert np.array_equal(got[i], tree_e.knn(q[i], 5, -1.0).astype(np.uint32))
+        c.target_index_destroy(index)
+    index = c.target_index(np.zeros((0, 3)), np.zeros((0, 3)))
+    assert all(len(x) == 0 for x in c.knn_search(index, 1, rng.normal(size=(5, 3)), 5))  # tests/test_registration.cpp:177-199
+    with pytest.raises(capi.LoamxError):
+        c.knn_search(index, 1, np.zeros((1, 3)), 9)
+    c.target_index_destroy(index)
