@@ -56,7 +56,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=1024, help="scan pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=1024, help="scan pairs per GPU per step (weak scaling: the default)")
+    ap.add_argument("--total-pairs", type=int, default=0,
+                    help="fixed TOTAL pairs per step, sharded over the ranks by loamx_shard_range (strong scaling: BASELINE "
+                         "configs[3] = 8192 over 1/2/4/8 GPUs); shards may be uneven (grouped ncclBroadcast path)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="pairs timed on the CPU oracle, all threads (default: ~3 s of wall time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-stats", action="store_true", help="skip the extra timed-kernels pass (roofline / kernel table)")
@@ -174,13 +177,17 @@ def main():
     lidar = capi.LidarParams(H, W, 1.0, 120.0)  # reference README.md:45
     fe, reg = capi.FeatureExtractionParams(), capi.RegistrationParams()
 
-    P = args.pairs
     N = H * W
-    first_pair, n_mine = capi.shard_range(world * P, world, rank)  # rank r owns pairs [r*P, (r+1)*P)
-    assert n_mine == P
+    strong = args.total_pairs > 0
+    total_per_step = args.total_pairs if strong else world * args.pairs
+    first_pair, P = capi.shard_range(total_per_step, world, rank)  # rank r owns pairs [first_pair, first_pair + P)
+    if not strong:
+        assert P == args.pairs
+    if P == 0:
+        raise SystemExit(f"bench.py: rank {rank} would own no pair of {total_per_step}")
     xyz = torch.empty(P * 2 * N * 3, dtype=torch.float64, device=dev)  # inputs resident in HBM
     results = torch.zeros(P * 64, dtype=torch.uint8, device=dev)
-    all_results = torch.zeros(world * P * 64, dtype=torch.uint8, device=dev) if world > 1 else results
+    all_results = torch.zeros(total_per_step * 64, dtype=torch.uint8, device=dev) if world > 1 else results
     torch.cuda.synchronize()
     ctx.synth_scan_pairs_dev(args.seed, first_pair, P, H, W, SIGMA, xyz.data_ptr())
     ctx.synchronize()
@@ -198,10 +205,10 @@ def main():
     def step():
         ctx.register_scan_pairs_dev(xyz.data_ptr(), P, lidar, fe, reg, results.data_ptr(), f32=f32)
         if comm is not None:  # the only collective: 64-byte result records, RCCL over xGMI on the context's stream
-            comm.gather_results_dev(results.data_ptr(), P, world * P, all_results.data_ptr())
+            comm.gather_results_dev(results.data_ptr(), P, total_per_step, all_results.data_ptr())
         elif world > 1:  # single-GPU rehearsal: through the host
             ctx.synchronize()
-            all_results.copy_(D.gather_results(results.cpu(), world * P))
+            all_results.copy_(D.gather_results(results.cpu(), total_per_step))
 
     def barrier():
         ctx.synchronize()
@@ -236,7 +243,7 @@ def main():
         ctx.enable_kernel_timing(False)
 
     res_all = all_results.cpu().numpy().view(capi.RESULT_DTYPE)
-    res = res_all[rank * P:(rank + 1) * P]
+    res = res_all[first_pair:first_pair + P]
     ranks = None
     if world > 1:
         # what the collective saw: every rank contributes one record {rank, device}; gathered through the same entry point
@@ -254,26 +261,27 @@ def main():
             ok = comm.barrier(0.0 if own else 1.0) == 0.0
             ranks = {"world_size": world, "rccl_comm_nranks": info["world_size"], "collective": "RCCL ncclAllGather behind the C ABI (loamx_gather_results_dev)",
                      "gathered_rank_ids": [int(x) for x in got["termination"]], "gathered_devices": [int(x) for x in got["iterations"]],
-                     "records_gathered_per_step": world * P, "every_rank_holds_its_block": bool(ok)}
+                     "records_gathered_per_step": total_per_step, "every_rank_holds_its_block": bool(ok)}
         else:
             got = D.gather_results(torch.from_numpy(proof.view(np.uint8).copy()), world).numpy().view(capi.RESULT_DTYPE)
             ranks = {"world_size": world, "rccl_comm_nranks": None, "collective": "gloo all_gather through host memory (LOAMX_BENCH_SHARE_GPU=1 "
                      "rehearsal: all ranks share device 0, which RCCL refuses)", "gathered_rank_ids": [int(x) for x in got["termination"]],
-                     "gathered_devices": [int(x) for x in got["iterations"]], "records_gathered_per_step": world * P,
+                     "gathered_devices": [int(x) for x in got["iterations"]], "records_gathered_per_step": total_per_step,
                      "every_rank_holds_its_block": own}
 
-    total_pairs = n_gpus * P * args.steps
+    total_pairs = total_per_step * args.steps
     value = total_pairs / elapsed
 
     if rank == 0:
         out = {
             "metric": "scan-pair registrations/sec (64x1024 Ouster)", "value": round(value, 2), "unit": "pairs/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"batch of {P} independent 64x1024 scan pairs per GPU (BASELINE configs[2]/[3]); "
+            "config": {"workload": (f"batch of {total_per_step} independent 64x1024 scan pairs sharded over {n_gpus} GPU(s) (BASELINE configs[3]); "
+                                    if strong else f"batch of {P} independent 64x1024 scan pairs per GPU (BASELINE configs[2]/[3]); ") +
                                    "step = extractFeatures x2 + registerFeatures per pair, inputs resident in HBM",
-                       "pairs_per_gpu": P, "scan": "64x1024", "sharding": "by pair id, no data-path collective",
+                       "pairs_per_gpu": P, "total_pairs_per_step": total_per_step, "scan": "64x1024", "sharding": "by pair id, no data-path collective",
                        "seed": args.seed, "range_noise_sigma_m": SIGMA, "input_scalar": args.input,
                        "arithmetic": "f64 (float input is widened on load)"},
         }

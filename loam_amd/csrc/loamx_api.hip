@@ -376,7 +376,7 @@ typedef int (*AfterAssocHook)(loamx_ctx*, const RegBatch&, uint32_t it, void* us
 // the launch sequence of one ICF iteration on ctx->stream (+ the auxiliary streams); `it` only selects between the
 // first iteration's sequence (no moment pass) and the later ones'
 // the association kernels of one ICF iteration (all feature kinds, all chains), timed as LOAMX_K_ASSOC
-int enqueue_association(loamx_ctx* ctx, const RegBatch& B, const RegConfig& C) {
+int enqueue_association(loamx_ctx* ctx, const RegBatch& B, const RegConfig& C, uint32_t what = kAssocEdges | kAssocPlanes) {
   hipStream_t s = ctx->stream;
     {
       TimedScope t(ctx, LOAMX_K_ASSOC, 0.0);
@@ -393,7 +393,7 @@ int enqueue_association(loamx_ctx* ctx, const RegBatch& B, const RegConfig& C) {
         knn_ls = LaunchScope{knn.e0, knn.e1, true};
       }
       launch_associate(B, C, s, side ? ctx->aux_stream : nullptr, side ? ctx->aux2_stream : nullptr, ctx->ev_fork, ctx->ev_mid, ctx->ev_join,
-                       ctx->ev_join2, ctx->timing ? &knn_ls : nullptr);
+                       ctx->ev_join2, ctx->timing ? &knn_ls : nullptr, what);
       if (ctx->timing) {
         if (knn_ls.first) ctx->event_pool.push_back(knn.e0), ctx->event_pool.push_back(knn.e1);  // (kernel not launched)
         else ctx->pending.push_back(knn);
@@ -571,7 +571,10 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
     TimedScope t(ctx, LOAMX_K_GRID, 0.0);
     // the source builds next to the target builds on the auxiliary stream: every workgroup of one build kernel is in
     // the same phase at the same time (reads, then writes), two different kernels side by side even the HBM demand
-    // out (measured 1.19 -> 1.11 ms per step); not for a few pairs (fork / join latency)
+    // out (measured 1.19 -> 1.11 ms per step); not for a few pairs (fork / join latency).
+    // (Round 3: the first ICF iteration's edge chains right behind the edge builds on the auxiliary stream, i.e. next to
+    // the planar index builds instead of next to the plane k-NN kernel: 11.60 / 11.72 vs 11.65 / 11.53 ms per step —
+    // what the k-NN kernel gains the HBM-bound builds lose. Not kept.)
     const bool side = B.n_pairs >= 8 && !(C.flags & kRegFlagNoGridSide) && ctx->aux_stream && !prebuilt &&
                       hipEventRecord(ctx->ev_fork, s) == hipSuccess && hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0) == hipSuccess;
     if (!prebuilt) launch_grid_build_targets(B, C, s);
@@ -725,7 +728,7 @@ int loamx_ctx_create(int device, loamx_ctx** out) {
       (void)hipStreamDestroy(ctx->aux_stream);
       ctx->aux_stream = nullptr;
     } else if (!getenv("LOAMX_NO_AUX2_STREAM") &&
-               hipStreamCreateWithPriority(&ctx->aux2_stream, hipStreamNonBlocking, getenv("LOAMX_AUX_HIGH_PRIO") ? prio_greatest : prio_least) == hipSuccess) {
+               hipStreamCreateWithPriority(&ctx->aux2_stream, hipStreamNonBlocking, (getenv("LOAMX_AUX_HIGH_PRIO") || getenv("LOAMX_AUX2_HIGH_PRIO")) ? prio_greatest : prio_least) == hipSuccess) {
       if (hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming) != hipSuccess) {
         (void)hipStreamDestroy(ctx->aux2_stream);
         ctx->aux2_stream = nullptr;

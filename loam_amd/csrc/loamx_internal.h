@@ -217,11 +217,15 @@ constexpr uint32_t kGridMapCellsCap = 1u << 18;
 inline bool grid_small(size_t stride, uint32_t reg_flags) { return stride <= kGridSmallCap && !(reg_flags & kRegFlagNoPackedGrid); }
 void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_grid_build_sources(const RegBatch& B, const RegConfig& C, hipStream_t s);
+void launch_grid_build_target(const RegBatch& B, const RegConfig& C, bool plane, hipStream_t s);  // one feature kind
+void launch_grid_build_source(const RegBatch& B, const RegConfig& C, bool plane, hipStream_t s);
 void launch_state_init(const RegBatch& B, const RegConfig& C, hipStream_t s);
 // aux == nullptr: everything on s; aux2 == nullptr: the plane queue chain follows the edge chain on aux
 // knn_scope != nullptr: the plane round-1 k-NN kernel is launched with that timing scope attached
+constexpr uint32_t kAssocEdges = 1u, kAssocPlanes = 2u;
 void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipStream_t aux, hipStream_t aux2, hipEvent_t ev_fork,
-                      hipEvent_t ev_mid, hipEvent_t ev_join, hipEvent_t ev_join2, LaunchScope* knn_scope = nullptr);
+                      hipEvent_t ev_mid, hipEvent_t ev_join, hipEvent_t ev_join2, LaunchScope* knn_scope = nullptr,
+                      uint32_t what = kAssocEdges | kAssocPlanes);
 #ifdef LOAMX_NN_SAME_STATS
 void debug_nn_same(const RegBatch& B, uint32_t it, hipStream_t s);
 #endif

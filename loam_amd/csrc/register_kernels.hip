@@ -1573,27 +1573,34 @@ static void launch_grid_build(size_t n_pairs, const double* pts, const uint32_t*
                        in_pitch, max_dist, gs, scratch);
 }
 
-void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_t s) {
+void launch_grid_build_target(const RegBatch& B, const RegConfig& C, bool plane, hipStream_t s) {
   if (B.n_pairs == 0) return;
-  launch_grid_build<false>(B.n_pairs, B.tgt_edge, B.n_tgt_edge, B.edge_stride, B.in_pitch, C.r_edge, B.grid_edge, B.sort_scratch, C.flags, s);
-  launch_grid_build<false>(B.n_pairs, B.tgt_planar, B.n_tgt_planar, B.planar_stride, B.in_pitch, C.r_plane, B.grid_plane, B.sort_scratch, C.flags, s);
+  if (plane) launch_grid_build<false>(B.n_pairs, B.tgt_planar, B.n_tgt_planar, B.planar_stride, B.in_pitch, C.r_plane, B.grid_plane, B.sort_scratch, C.flags, s);
+  else launch_grid_build<false>(B.n_pairs, B.tgt_edge, B.n_tgt_edge, B.edge_stride, B.in_pitch, C.r_edge, B.grid_edge, B.sort_scratch, C.flags, s);
+}
+void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_t s) {
+  launch_grid_build_target(B, C, false, s);
+  launch_grid_build_target(B, C, true, s);
 }
 
 // source sets: only the cell-sorted (Morton) order is used
-void launch_grid_build_sources(const RegBatch& B, const RegConfig& C, hipStream_t s) {
+// (the scratch copy is shared by the two source sets: build + rank of one complete before the next one's build starts — both
+// on ONE stream. It is NOT the target builds' scratch: those run on another stream at the same time, and the multi-workgroup
+// build of a target set above kGridSmallCap points keeps its box keys and cursors there)
+void launch_grid_build_source(const RegBatch& B, const RegConfig& C, bool plane, hipStream_t s) {
   if (B.n_pairs == 0) return;
-  // (the scratch copy is shared by the two source sets: build + rank of one complete before the next one's build starts.
-  // It is NOT the target builds' scratch: those run on another stream at the same time, and the multi-workgroup build of a
-  // target set above kGridSmallCap points keeps its box keys and cursors there)
-  launch_grid_build<true>(B.n_pairs, B.src_edge, B.n_src_edge, B.edge_stride, B.in_pitch, C.r_edge, B.src_grid_edge, B.sort_scratch_src, C.flags, s);
-  if (B.edge_stride && !grid_small(B.edge_stride, C.flags))
-    launch_kernel(grid_rank_kernel, dim3((unsigned)((B.edge_stride + kRankThreads - 1) / kRankThreads), (unsigned)B.n_pairs),
-                       dim3(kRankThreads), 0, s, B.n_src_edge, B.edge_stride, B.in_pitch, B.src_grid_edge, B.sort_scratch_src);
-  launch_grid_build<true>(B.n_pairs, B.src_planar, B.n_src_planar, B.planar_stride, B.in_pitch, C.r_plane, B.src_grid_plane, B.sort_scratch_src, C.flags, s);
-  if (B.planar_stride && !grid_small(B.planar_stride, C.flags))
-    launch_kernel(grid_rank_kernel, dim3((unsigned)((B.planar_stride + kRankThreads - 1) / kRankThreads), (unsigned)B.n_pairs),
-                       dim3(kRankThreads), 0, s, B.n_src_planar, B.planar_stride, B.in_pitch, B.src_grid_plane,
-                       B.sort_scratch_src);
+  const size_t stride = plane ? B.planar_stride : B.edge_stride;
+  const uint32_t* n_src = plane ? B.n_src_planar : B.n_src_edge;
+  const GridSet& gs = plane ? B.src_grid_plane : B.src_grid_edge;
+  launch_grid_build<true>(B.n_pairs, plane ? B.src_planar : B.src_edge, n_src, stride, B.in_pitch, plane ? C.r_plane : C.r_edge, gs,
+                          B.sort_scratch_src, C.flags, s);
+  if (stride && !grid_small(stride, C.flags))
+    launch_kernel(grid_rank_kernel, dim3((unsigned)((stride + kRankThreads - 1) / kRankThreads), (unsigned)B.n_pairs), dim3(kRankThreads), 0, s,
+                  n_src, stride, B.in_pitch, gs, B.sort_scratch_src);
+}
+void launch_grid_build_sources(const RegBatch& B, const RegConfig& C, hipStream_t s) {
+  launch_grid_build_source(B, C, false, s);
+  launch_grid_build_source(B, C, true, s);
 }
 
 void launch_state_init(const RegBatch& B, const RegConfig& C, hipStream_t s) {
@@ -1612,8 +1619,10 @@ static uint32_t rest_blocks(size_t n_pairs, uint32_t nblk) {
   if (want < LOAMX_REST_BLOCKS) want = LOAMX_REST_BLOCKS;
   return want < cover ? want : cover;
 }
+// what: bit 0 = the edge chains, bit 1 = the plane chains (the first ICF iteration's edge chains can run early, next to the
+// planar index builds: launch_associate(..., kAssocEdges) on the stream that built the edge sets, then kAssocPlanes)
 void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipStream_t aux, hipStream_t aux2, hipEvent_t ev_fork,
-                      hipEvent_t ev_mid, hipEvent_t ev_join, hipEvent_t ev_join2, LaunchScope* knn_scope) {
+                      hipEvent_t ev_mid, hipEvent_t ev_join, hipEvent_t ev_join2, LaunchScope* knn_scope, uint32_t what) {
   if (B.n_pairs == 0) return;
   const uint32_t be = B.assoc_blocks_edge != 0xFFFFFFFFu ? B.assoc_blocks_edge : (uint32_t)((B.edge_stride + kAssocThreads - 1) / kAssocThreads);
   const uint32_t bp = B.assoc_blocks_plane != 0xFFFFFFFFu ? B.assoc_blocks_plane : (uint32_t)((B.planar_stride + kAssocThreads - 1) / kAssocThreads);
@@ -1655,22 +1664,25 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
     if ((PL ? C.k_plane : C.k_edge) <= 5) STEP(PL, 5, nblk, st); \
     else STEP(PL, 8, nblk, st);                          \
   } while (0)
-  const bool fork = aux != nullptr && hipEventRecord(ev_fork, s) == hipSuccess &&
+  const bool edges = (what & kAssocEdges) != 0u && be != 0u, planes = (what & kAssocPlanes) != 0u && bp != 0u;
+  // (edges alone: on the caller's stream, nothing to run them next to)
+  const bool use_aux = aux != nullptr && planes;  // the side streams only make sense next to the plane chain
+  const bool fork = use_aux && (edges || !aux2) && hipEventRecord(ev_fork, s) == hipSuccess &&
                     hipStreamWaitEvent(aux, ev_fork, 0) == hipSuccess;
   hipStream_t sa = fork ? aux : s;
-  if (be) {  // edge chains, whole
+  if (edges) {  // edge chains, whole
     LOAMX_ASSOC_K(LOAMX_ASSOC_A1, false, be, sa);
     LOAMX_ASSOC_K(LOAMX_ASSOC_A2, false, be, sa);
     // (the brute-force kernel finishes every query itself: with no grid search in the batch nothing is ever queued)
     if (B.knn_mode_edge != 2u) LOAMX_ASSOC_K(LOAMX_ASSOC_B, false, be, sa);
   }
-  if (bp) {
+  if (planes) {
     LOAMX_ASSOC_K(LOAMX_ASSOC_A1, true, bp, s);
     // the plane queue chain starts when the plane round-1 kernel is done: on its own stream when there is one
     // (behind the edge chain on aux it started only after the plane fit: the edge kernels' many empty workgroups
     // wait for slots next to the plane kernels)
     hipStream_t sb = aux2 ? aux2 : aux;
-    const bool fork2 = fork && hipEventRecord(ev_mid, s) == hipSuccess && hipStreamWaitEvent(sb, ev_mid, 0) == hipSuccess;
+    const bool fork2 = use_aux && (aux2 || fork) && hipEventRecord(ev_mid, s) == hipSuccess && hipStreamWaitEvent(sb, ev_mid, 0) == hipSuccess;
     LOAMX_ASSOC_K(LOAMX_ASSOC_A2, true, bp, s);
     if (B.knn_mode_plane != 2u) LOAMX_ASSOC_K(LOAMX_ASSOC_B, true, bp, (fork2 ? sb : s));
     if (fork2 && aux2 && hipEventRecord(ev_join2, aux2) == hipSuccess) (void)hipStreamWaitEvent(s, ev_join2, 0);

@@ -68,3 +68,25 @@ def test_two_ranks_really_start_and_fail_loudly_without_a_gpu():
                          capture_output=True, text=True, timeout=300)
     assert out.returncode != 0
     assert out.stderr.count("no CPU fallback") >= 1  # the ranks refuse to measure anything without the HIP path
+
+
+def test_multi_gpu_selfcheck_plan_and_loud_failure():
+    """tools/multi_gpu_selfcheck.py: the shard plan needs no GPU (uneven totals take the grouped-broadcast path), and the
+    tool refuses to report anything without one."""
+    tool = os.path.join(ROOT, "tools", "multi_gpu_selfcheck.py")
+    out = subprocess.run([sys.executable, tool, "--plan", "--gpus", "8", "--total-pairs", "8191"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    plan = json.loads(out.stdout.strip().splitlines()[-1])
+    assert plan["covers_everything"] and plan["collective"].startswith("grouped ncclBroadcast")
+    assert [s["count"] for s in plan["shards"]] == [1024] * 7 + [1023]
+    out = subprocess.run([sys.executable, tool, "--plan", "--gpus", "8", "--total-pairs", "8192"], capture_output=True, text=True, timeout=120)
+    assert json.loads(out.stdout.strip().splitlines()[-1])["collective"] == "ncclAllGather"
+    if not torch.cuda.is_available():
+        out = subprocess.run([sys.executable, tool, "--gpus", "2"], capture_output=True, text=True, timeout=300)
+        assert out.returncode != 0
+
+
+def test_total_pairs_flag_shards_a_fixed_total():
+    """bench.py --total-pairs T (strong scaling): the help text names it and the launcher passes it through to the ranks"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert "--total-pairs" in out.stdout
