@@ -179,12 +179,18 @@ int loamx_target_index_create(loamx_ctx* ctx, const double* tgt_edge, size_t n_t
                               size_t n_tgt_planar, const loamx_reg_params* reg, loamx_target_index** out);
 void loamx_target_index_destroy(loamx_ctx* ctx, loamx_target_index* index);
 /* Appends points to the index (a map that grows scan by scan). The new points take the indices that follow the
- * existing ones, and the index afterwards is exactly the one loamx_target_index_create builds over the
- * concatenated sets: registrations against it return the same bits. The points stay resident on the device
- * (amortised-doubling buffers); the cell structure is rebuilt over all of them on the device, so an insert
- * costs one upload of the NEW points plus one index build (4-5 ms per million points on MI355X). */
+ * existing ones, and every search and registration against the index afterwards returns what it would against an
+ * index created over the concatenated sets, bit for bit (the searches are exact: their result does not depend on
+ * the cell structure). Cost: one upload of the NEW points, then per feature kind either
+ *   - a merge into the existing grid (map-sized kinds: counts and scatter of the new points, one table scan and one
+ *     streaming copy of the cell-sorted arrays into their twin buffers: ~0.1 ms per million resident points), or
+ *   - a rebuild of that kind (scan-sized kinds: one workgroup; any kind when a new point lies outside its grid, when
+ *     the kind has doubled since its grid was chosen — the cell edge follows the density — or when its buffers grew).
+ * Amortised over a map grown scan by scan the rebuilds are O(log n) events. */
 int loamx_target_index_insert(loamx_ctx* ctx, loamx_target_index* index, const double* edge, size_t n_edge,
                               const double* planar, size_t n_planar);
+/* how the index has been maintained so far: full (re)builds of a feature kind's grid / merges into an existing one */
+int loamx_target_index_stats(const loamx_target_index* index, uint64_t* full_builds, uint64_t* merges);
 /* number of edge / planar points in the index (either pointer may be NULL) */
 int loamx_target_index_size(const loamx_target_index* index, size_t* n_edge, size_t* n_planar);
 /* same contract as loamx_register_features, target taken from the index */

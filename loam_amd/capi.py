@@ -93,7 +93,7 @@ EXPORTS = [
     "loamx_shard_range", "loamx_comm_get_unique_id", "loamx_comm_create", "loamx_comm_wrap", "loamx_comm_destroy",
     "loamx_comm_info", "loamx_gather_results_dev", "loamx_comm_barrier", "loamx_ctx_extract_counters",
     "loamx_ctx_set_option", "loamx_ctx_get_option",
-    "loamx_fit_lines", "loamx_fit_planes", "loamx_knn_search", "loamx_associate",
+    "loamx_fit_lines", "loamx_fit_planes", "loamx_knn_search", "loamx_associate", "loamx_target_index_stats",
 ]
 
 _lib = None
@@ -141,6 +141,7 @@ def load(build_if_missing=True):
     lib.loamx_target_index_create.argtypes = [vp, dp, C.c_size_t, dp, C.c_size_t, C.POINTER(RegistrationParams), C.POINTER(vp)]
     lib.loamx_target_index_insert.argtypes = [vp, vp, dp, C.c_size_t, dp, C.c_size_t]
     lib.loamx_target_index_size.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lib.loamx_target_index_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.loamx_target_index_destroy.argtypes = [vp, vp]
     lib.loamx_target_index_destroy.restype = None
     lib.loamx_register_features_indexed.argtypes = [vp, vp, dp, C.c_size_t, dp, C.c_size_t, dp, C.POINTER(RegistrationParams),
@@ -486,6 +487,12 @@ class Context:
         ne, npl = C.c_size_t(0), C.c_size_t(0)
         self._check(self.lib.loamx_target_index_size(index, C.byref(ne), C.byref(npl)))
         return ne.value, npl.value
+
+    def target_index_stats(self, index):
+        """(full builds of a feature kind's grid, merges into an existing grid) so far"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.lib.loamx_target_index_stats(index, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def target_index_destroy(self, index):
         self.lib.loamx_target_index_destroy(self.h, index)

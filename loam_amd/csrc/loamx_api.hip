@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -84,6 +85,12 @@ struct loamx_target_index {
   void* scratch = nullptr;                      // box keys + cursors of the multi-workgroup build
   uint32_t cells_cap[2] = {0, 0};               // 0: kGridCellsCap; map-sized sets own a larger cell table
   size_t cells_alloc[2] = {0, 0}, scratch_alloc = 0;
+  // incremental insert (index_merge): twin buffers of sorted / rel, the set size at the last full build of the kind
+  // (a kind that has doubled since is rebuilt: its cell edge is chosen for the density it had then), event counters
+  GridPoint* sorted2[2] = {nullptr, nullptr};
+  float* rel2[2] = {nullptr, nullptr};
+  size_t n_at_build[2] = {0, 0};
+  uint64_t full_builds = 0, merges = 0;
 };
 
 namespace loamx {
@@ -1131,6 +1138,8 @@ void index_free(loamx_target_index* idx) {
     if (idx->sorted[k]) (void)hipFree(idx->sorted[k]);
     if (idx->rel[k]) (void)hipFree(idx->rel[k]);
     if (idx->pts[k]) (void)hipFree(idx->pts[k]);
+    if (idx->sorted2[k]) (void)hipFree(idx->sorted2[k]);
+    if (idx->rel2[k]) (void)hipFree(idx->rel2[k]);
   }
   if (idx->counts) (void)hipFree(idx->counts);
   if (idx->scratch) (void)hipFree(idx->scratch);
@@ -1161,12 +1170,17 @@ int index_reserve(loamx_ctx* ctx, loamx_target_index* idx, int k, size_t extra) 
   if (idx->pts[k]) (void)hipFree(idx->pts[k]);
   if (idx->sorted[k]) (void)hipFree(idx->sorted[k]);
   if (idx->rel[k]) (void)hipFree(idx->rel[k]);
+  if (idx->sorted2[k]) (void)hipFree(idx->sorted2[k]);  // (the twins are made again, at the new capacity, by the next merge)
+  if (idx->rel2[k]) (void)hipFree(idx->rel2[k]);
+  idx->sorted2[k] = nullptr, idx->rel2[k] = nullptr;
   idx->pts[k] = pts, idx->sorted[k] = sorted, idx->rel[k] = rel, idx->cap[k] = cap;
+  idx->n_at_build[k] = 0;  // (the cell-sorted arrays are gone: this kind is rebuilt)
   return LOAMX_OK;
 }
 
-// (Re)builds both grids from idx->pts: the index of a point set does not depend on how it was grown.
-int index_build(loamx_ctx* ctx, loamx_target_index* idx) {
+// (Re)builds the grids of the kinds in `kinds` (bit 0 edge, bit 1 planar) from idx->pts: cell edge, dimensions and order
+// chosen afresh for the set as it is now.
+int index_build(loamx_ctx* ctx, loamx_target_index* idx, unsigned kinds = 3u) {
   hipStream_t s = ctx->stream;
   const uint32_t counts[2] = {(uint32_t)idx->n[0], (uint32_t)idx->n[1]};
   HIP_TRY(ctx, hipMemcpyAsync(idx->counts, counts, sizeof(counts), hipMemcpyHostToDevice, s));
@@ -1182,6 +1196,7 @@ int index_build(loamx_ctx* ctx, loamx_target_index* idx) {
   // hundreds of points of a million-point map into every cell); tables and cursors grow with the set
   size_t scratch_need = kGridBigScratchBytes;
   for (int k = 0; k < 2; k++) {
+    if (!(kinds & (1u << k))) continue;
     const int mc = ctx->map_cells_log2;  // experiment knob (16 = the scan-sized table)
     idx->cells_cap[k] = idx->n[k] > 200000 ? (mc >= 8 && mc <= 24 ? (1u << mc) : kGridMapCellsCap) : 0u;
     if (idx->cells_cap[k] <= kGridCellsCap) idx->cells_cap[k] = 0u;
@@ -1194,7 +1209,7 @@ int index_build(loamx_ctx* ctx, loamx_target_index* idx) {
       HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&idx->cells[k]), need));
       idx->cells_alloc[k] = need;
     }
-    if (64 + cap * sizeof(uint32_t) > scratch_need) scratch_need = 64 + cap * sizeof(uint32_t);
+    if (64 + (cap + cap / 4096 + 8) * sizeof(uint32_t) > scratch_need) scratch_need = 64 + (cap + cap / 4096 + 8) * sizeof(uint32_t);  // (box keys, cursors, tile sums)
   }
   if (idx->scratch_alloc < scratch_need) {
     HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -1209,12 +1224,25 @@ int index_build(loamx_ctx* ctx, loamx_target_index* idx) {
   untimed(ctx);
   {
     TimedScope t(ctx, LOAMX_K_GRID, 0.0);
-    launch_grid_build_targets(B, C, s);
+    for (int k = 0; k < 2; k++)
+      if (kinds & (1u << k)) launch_grid_build_target(B, C, k == 1, s);
   }
   int rc = check_launch(ctx, "grid_build_kernel");
   if (rc != LOAMX_OK) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(s));
+  for (int k = 0; k < 2; k++)
+    if (kinds & (1u << k)) idx->n_at_build[k] = idx->n[k];
+  idx->full_builds++;
   return LOAMX_OK;
+}
+
+// May kind k take `add` more points by a merge into its existing grid (index_insert_* kernels)? Map-sized sets only (a
+// scan-sized set is rebuilt by one workgroup in ~0.1 ms), while the set has not doubled since its grid was chosen (the
+// cell edge follows the density) and stays on the same side of the map-table threshold.
+bool index_can_merge(const loamx_target_index* idx, int k, size_t add) {
+  const size_t n_old = idx->n[k], n_new = n_old + add;
+  return idx->n_at_build[k] > kGridSmallCap && n_old >= idx->n_at_build[k] && n_new <= 2 * idx->n_at_build[k] && n_new <= idx->cap[k] &&
+         (n_new > 200000) == (idx->cells_cap[k] != 0u);
 }
 
 int index_append(loamx_ctx* ctx, loamx_target_index* idx, const double* edge, size_t n_e, const double* planar, size_t n_p) {
@@ -1228,11 +1256,73 @@ int index_append(loamx_ctx* ctx, loamx_target_index* idx, const double* edge, si
     int rc = index_reserve(ctx, idx, k, add[k]);
     if (rc != LOAMX_OK) return rc;
   }
+  hipStream_t s = ctx->stream;
+  const size_t n_old[2] = {idx->n[0], idx->n[1]};
+  unsigned rebuild = 0u;
+  bool merge[2] = {false, false};
   for (int k = 0; k < 2; k++) {
-    if (add[k]) HIP_TRY(ctx, hipMemcpyAsync(idx->pts[k] + idx->n[k] * 3, host[k], add[k] * 24, hipMemcpyHostToDevice, ctx->stream));
+    if (add[k]) HIP_TRY(ctx, hipMemcpyAsync(idx->pts[k] + idx->n[k] * 3, host[k], add[k] * 24, hipMemcpyHostToDevice, s));
+    merge[k] = add[k] != 0 && index_can_merge(idx, k, add[k]);
+    if (!merge[k] && (add[k] != 0 || idx->n_at_build[k] != idx->n[k] || idx->full_builds == 0)) rebuild |= 1u << k;
     idx->n[k] += add[k];
   }
-  return index_build(ctx, idx);
+  // ---- merges: count the new points per cell (and learn whether they all lie inside the grid), then move + scatter
+  uint32_t* ws[2] = {nullptr, nullptr};
+  for (int k = 0; k < 2; k++) {
+    if (!merge[k]) continue;
+    const size_t cells = idx->cells_cap[k] ? idx->cells_cap[k] : kGridCellsCap;
+    const size_t need = index_insert_ws_bytes(cells, add[k]);
+    // (the two kinds share idx->scratch: the planar kind's part sits behind the edge kind's)
+    const size_t off = k == 1 && merge[0] ? ((index_insert_ws_bytes(idx->cells_cap[0] ? idx->cells_cap[0] : kGridCellsCap, add[0]) + 255) & ~(size_t)255) : 0;
+    if (idx->scratch_alloc < off + need) {
+      HIP_TRY(ctx, hipStreamSynchronize(s));
+      void* bigger = nullptr;
+      HIP_TRY(ctx, hipMalloc(&bigger, 2 * (off + need)));
+      if (idx->scratch) (void)hipFree(idx->scratch);
+      idx->scratch = bigger, idx->scratch_alloc = 2 * (off + need);
+      if (k == 1 && merge[0]) {  // (the edge kind's counts were in the old block: once more)
+        const GridSet gs0{idx->desc[0], idx->cells[0], idx->sorted[0], idx->cap[0] + kGridPad, idx->rel[0], idx->cells_cap[0]};
+        ws[0] = static_cast<uint32_t*>(idx->scratch);
+        launch_index_insert_count(gs0, idx->cells_cap[0] ? idx->cells_cap[0] : kGridCellsCap, idx->pts[0] + n_old[0] * 3, (uint32_t)add[0], ws[0], s);
+      }
+    }
+    ws[k] = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(idx->scratch) + off);
+    const GridSet gs{idx->desc[k], idx->cells[k], idx->sorted[k], idx->cap[k] + kGridPad, idx->rel[k], idx->cells_cap[k]};
+    untimed(ctx);
+    launch_index_insert_count(gs, cells, idx->pts[k] + n_old[k] * 3, (uint32_t)add[k], ws[k], s);
+  }
+  for (int k = 0; k < 2; k++) {
+    if (!merge[k]) continue;
+    HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_pinned[32 + k], ws[k], sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  }
+  if (merge[0] || merge[1]) HIP_TRY(ctx, hipStreamSynchronize(s));
+  for (int k = 0; k < 2; k++) {
+    if (!merge[k]) continue;
+    if (ctx->h_pinned[32 + k] != 0u) {  // a new point outside the grid: this kind is rebuilt around the larger set
+      merge[k] = false, rebuild |= 1u << k;
+      continue;
+    }
+    if (!idx->sorted2[k]) {
+      if (hipMalloc(reinterpret_cast<void**>(&idx->sorted2[k]), (idx->cap[k] + kGridPad) * sizeof(GridPoint)) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&idx->rel2[k]), 3 * (idx->cap[k] + kGridPad) * sizeof(float)) != hipSuccess) {
+        if (idx->sorted2[k]) (void)hipFree(idx->sorted2[k]);
+        idx->sorted2[k] = nullptr, idx->rel2[k] = nullptr;
+        merge[k] = false, rebuild |= 1u << k;  // (no room for the twins: the rebuild needs none)
+        continue;
+      }
+    }
+    const size_t cells = idx->cells_cap[k] ? idx->cells_cap[k] : kGridCellsCap;
+    const GridSet gs{idx->desc[k], idx->cells[k], idx->sorted[k], idx->cap[k] + kGridPad, idx->rel[k], idx->cells_cap[k]};
+    launch_index_insert_merge(gs, cells, (uint32_t)n_old[k], idx->pts[k] + n_old[k] * 3, (uint32_t)add[k], ws[k], idx->sorted2[k], idx->rel2[k], s);
+    int rc = check_launch(ctx, "index_insert kernels");
+    if (rc != LOAMX_OK) return rc;
+    std::swap(idx->sorted[k], idx->sorted2[k]);
+    std::swap(idx->rel[k], idx->rel2[k]);
+    idx->merges++;
+  }
+  if (rebuild) return index_build(ctx, idx, rebuild);
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return LOAMX_OK;
 }
 }  // namespace
 
@@ -1275,6 +1365,13 @@ int loamx_target_index_insert(loamx_ctx* ctx, loamx_target_index* index, const d
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (n_edge == 0 && n_planar == 0) return LOAMX_OK;
   return index_append(ctx, index, edge, n_edge, planar, n_planar);
+}
+
+int loamx_target_index_stats(const loamx_target_index* index, uint64_t* full_builds, uint64_t* merges) {
+  if (!index) return LOAMX_ERR_BAD_PARAM;
+  if (full_builds) *full_builds = index->full_builds;
+  if (merges) *merges = index->merges;
+  return LOAMX_OK;
 }
 
 int loamx_target_index_size(const loamx_target_index* index, size_t* n_edge, size_t* n_planar) {

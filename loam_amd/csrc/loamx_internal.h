@@ -205,7 +205,8 @@ struct RegBatch {
 };
 
 // scratch the multi-workgroup build of a map-sized target set needs per pair (at B.sort_scratch + pair * stride points)
-constexpr size_t kGridBigScratchBytes = 64 + (size_t)kGridCellsCap * sizeof(uint32_t);
+// (box keys, one cursor per cell, the tile sums of the table scan)
+constexpr size_t kGridBigScratchBytes = 64 + ((size_t)kGridCellsCap + kGridCellsCap / 4096 + 8) * sizeof(uint32_t);
 // cell table of a map-sized persistent index. Measured on a 1.02 M-point map (config 5; index build / registration
 // of a 39 k-feature scan): 2^16 cells 1.04 / 6.71 ms, 2^17 1.07 / 5.97, 2^18 1.38 / 5.88, 2^19 1.77 / 5.71,
 // 2^20 2.49 / 5.74, 2^21 4.75 / 8.19 (cells too small for the 5th neighbour: more second rounds)
@@ -236,6 +237,12 @@ void launch_lm_step(const RegBatch& B, hipStream_t s);
 void launch_moments(const RegBatch& B, hipStream_t s);
 void launch_outer_update(const RegBatch& B, const RegConfig& C, hipStream_t s);
 void launch_write_results(const RegBatch& B, loamx_reg_result* d_results, hipStream_t s);
+
+// incremental insert into a persistent index whose grid stays (register_kernels.hip); `cells` = entries of the cell table
+size_t index_insert_ws_bytes(size_t cells, size_t n_add);
+void launch_index_insert_count(const GridSet& gs, size_t cells, const double* d_add, uint32_t n_add, void* ws, hipStream_t s);
+void launch_index_insert_merge(const GridSet& gs, size_t cells, uint32_t n_old, const double* d_add, uint32_t n_add, void* ws,
+                               GridPoint* sorted2, float* rel2, hipStream_t s);
 
 // direct read-outs of rows a16-a19 (loamx_fit_lines / _planes, loamx_knn_search, loamx_associate)
 constexpr int kFitMaxK = 32;  // point sets of the host-callable fits (the association kernels keep <= kMaxK neighbours)

@@ -360,45 +360,88 @@ __global__ __launch_bounds__(kBigThreads) void gridbig_pass_kernel(const double*
   }
 }
 
-// exclusive scan of the cell counts of one pair: tiles of 65 536 entries, 64 consecutive entries per thread
-__global__ __launch_bounds__(1024) void gridbig_scan_kernel(const uint32_t* __restrict__ n_pts, size_t stride, uint32_t in_pitch, GridSet gs,
-                                                            GridPoint* scratch) {
-  __shared__ uint32_t s_wave_sum[16];
+// Exclusive scan of the cell counts of every pair in three small launches over tiles of kScanTile entries (tile sums,
+// scan of the tile sums, scan inside the tiles; blockIdx.y = pair). One workgroup per pair walking its whole table —
+// the first form — took 0.58 ms for the 2^18 cells of a map-sized index: 64 serial loads per thread and tile.
+constexpr uint32_t kScanTile = 4096, kScanThreads = 256, kScanPer = kScanTile / kScanThreads;
+__device__ __forceinline__ uint32_t block_incl_scan_256(uint32_t v, uint32_t* s_wave, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  uint32_t before = 0, all = 0;
+  for (int w = 0; w < (int)(kScanThreads / 64); w++) {
+    if (w < wave) before += s_wave[w];
+    all += s_wave[w];
+  }
+  __syncthreads();
+  if (total) *total = all;
+  return incl + before;
+}
+// (the tile sums of a pair live behind its cursors in the scratch area: kGridBigScratchBytes has the room)
+__device__ __forceinline__ uint32_t* big_tile_sums(GridPoint* scratch, size_t pair, size_t stride, const GridSet& gs) {
+  return reinterpret_cast<uint32_t*>(big_scratch(scratch, pair, stride) + 64) + (gs.cells_cap ? gs.cells_cap : kGridCellsCap);
+}
+__global__ __launch_bounds__(kScanThreads) void gridbig_tile_sum_kernel(size_t stride, GridSet gs, GridPoint* scratch) {
+  __shared__ uint32_t s_wave[kScanThreads / 64];
+  const size_t pair = blockIdx.y;
+  const GridDesc g = gs.desc[pair];
+  const uint32_t ncell = (uint32_t)(g.nx * g.ny * g.nz);
+  if (blockIdx.x * kScanTile >= ncell) return;  // uniform
+  const uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
+  const uint32_t c0 = blockIdx.x * kScanTile + threadIdx.x * kScanPer;
+  uint32_t local = 0;
+#pragma unroll
+  for (uint32_t u = 0; u < kScanPer; u++)
+    if (c0 + u < ncell) local += cs[c0 + u];
+  uint32_t total = 0;
+  (void)block_incl_scan_256(local, s_wave, &total);
+  if (threadIdx.x == 0) big_tile_sums(scratch, pair, stride, gs)[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kScanThreads) void gridbig_tile_scan_kernel(size_t stride, GridSet gs, GridPoint* scratch) {  // one workgroup per pair
+  __shared__ uint32_t s_wave[kScanThreads / 64];
   const size_t pair = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const GridDesc g = gs.desc[pair];
+  const uint32_t ncell = (uint32_t)(g.nx * g.ny * g.nz), n_tiles = (ncell + kScanTile - 1) / kScanTile;
+  uint32_t* __restrict__ ts = big_tile_sums(scratch, pair, stride, gs);
+  uint32_t carry = 0;
+  for (uint32_t t0 = 0; t0 < n_tiles; t0 += kScanThreads) {
+    const uint32_t t = t0 + threadIdx.x;
+    const uint32_t v = t < n_tiles ? ts[t] : 0u;
+    uint32_t total = 0;
+    const uint32_t incl = block_incl_scan_256(v, s_wave, &total);
+    if (t < n_tiles) ts[t] = carry + incl - v;
+    carry += total;
+  }
+}
+__global__ __launch_bounds__(kScanThreads) void gridbig_scan_kernel(const uint32_t* __restrict__ n_pts, size_t stride, uint32_t in_pitch, GridSet gs,
+                                                                    GridPoint* scratch) {
+  __shared__ uint32_t s_wave[kScanThreads / 64];
+  const size_t pair = blockIdx.y;
   const uint32_t n_raw = n_pts[pair * in_pitch], n = n_raw < stride ? n_raw : (uint32_t)stride;
   const GridDesc g = gs.desc[pair];
   const uint32_t ncell = (uint32_t)(g.nx * g.ny * g.nz);
+  if (blockIdx.x * kScanTile > ncell) return;  // uniform (the tile that holds entry ncell writes the total)
   uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
   uint32_t* __restrict__ cursor = reinterpret_cast<uint32_t*>(big_scratch(scratch, pair, stride) + 64);
-  constexpr uint32_t per = 64, tile = per * 1024;
-  uint32_t carry = 0;
-  for (uint32_t t0 = 0; t0 < ncell; t0 += tile) {
-    const uint32_t c0 = t0 + tid * per;
-    uint32_t local = 0;
-    for (uint32_t c = c0; c < c0 + per && c < ncell; c++) local += cs[c];
-    uint32_t incl = local;
+  const uint32_t c0 = blockIdx.x * kScanTile + threadIdx.x * kScanPer;
+  uint32_t cnt[kScanPer], local = 0;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t t = __shfl_up(incl, off);
-      if (lane >= off) incl += t;
-    }
-    if (lane == 63) s_wave_sum[wave] = incl;
-    __syncthreads();
-    uint32_t run = carry + incl - local, total = 0;
-    for (int w = 0; w < 16; w++) {
-      if (w < wave) run += s_wave_sum[w];
-      total += s_wave_sum[w];
-    }
-    for (uint32_t c = c0; c < c0 + per && c < ncell; c++) {
-      const uint32_t cnt = cs[c];
-      cs[c] = run, cursor[c] = run;
-      run += cnt;
-    }
-    carry += total;
-    __syncthreads();  // s_wave_sum is rewritten by the next tile
+  for (uint32_t u = 0; u < kScanPer; u++) cnt[u] = c0 + u < ncell ? cs[c0 + u] : 0u, local += cnt[u];
+  const uint32_t tile_base = blockIdx.x * kScanTile < ncell ? big_tile_sums(scratch, pair, stride, gs)[blockIdx.x] : n;
+  uint32_t run = tile_base + block_incl_scan_256(local, s_wave, nullptr) - local;
+#pragma unroll
+  for (uint32_t u = 0; u < kScanPer; u++) {
+    const uint32_t c = c0 + u;
+    if (c < ncell) cs[c] = run, cursor[c] = run;
+    else if (c == ncell) cs[c] = n;
+    run += cnt[u];
   }
-  if (tid == 0) cs[ncell] = n;
 }
 
 __global__ __launch_bounds__(kBigThreads) void gridbig_rel_kernel(const uint32_t* __restrict__ n_pts, size_t stride, uint32_t in_pitch,
@@ -414,6 +457,124 @@ __global__ __launch_bounds__(kBigThreads) void gridbig_rel_kernel(const uint32_t
   const GridDesc g = gs.desc[pair];
   const GridPoint e = gs.sorted[pair * gs.stride + p];
   rel[p] = (float)(e.x - g.ox), rel[gs.stride + p] = (float)(e.y - g.oy), rel[2 * gs.stride + p] = (float)(e.z - g.oz);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Incremental insert into a map-sized persistent index (round 3): the grid (origin, cell edge, dimensions)
+ * stays, the new points are merged into the cell-sorted arrays. Work: O(new points) for the counts and the scatter, one
+ * table scan, and ONE streaming copy of the old arrays into their twin buffers (44 bytes per old point each way:
+ * ~30 us per million points) — no bounding-box pass, no atomics over the old points, no re-sort. The result is an
+ * exactly packed index (no slack: the searches scan what a fresh build of the same grid would give them); only the
+ * order of the new points inside a cell depends on the order the atomics were served, which no search result depends
+ * on. A new point outside the grid raises a flag and the host rebuilds from scratch (index_build).
+ *   ws = [0] flag, [16 ...) add / shift table (ncell + 1), cursor table (ncell), cell of every new point
+ * ---------------------------------------------------------------------------------------------- */
+__global__ __launch_bounds__(256) void index_insert_count_kernel(const double* __restrict__ add, uint32_t n_add, const GridDesc* __restrict__ desc,
+                                                                 uint32_t* __restrict__ flag, uint32_t* __restrict__ add_count,
+                                                                 uint32_t* __restrict__ cell_of) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_add) return;
+  const GridDesc g = *desc;
+  const Vec3 p = v3(add[3 * (size_t)i], add[3 * (size_t)i + 1], add[3 * (size_t)i + 2]);
+  const int32_t cx = grid_cell_coord(p.x, g.ox, g.inv_h), cy = grid_cell_coord(p.y, g.oy, g.inv_h), cz = grid_cell_coord(p.z, g.oz, g.inv_h);
+  // (a point outside the grid, or not finite, cannot be filed under a boundary cell: the searches prune by the cells' slabs)
+  const bool inside = cx >= 0 && cx < g.nx && cy >= 0 && cy < g.ny && cz >= 0 && cz < g.nz && p.x - p.x == 0.0 && p.y - p.y == 0.0 && p.z - p.z == 0.0;
+  if (!inside) {
+    atomicOr(flag, 1u);
+    cell_of[i] = 0u;
+    return;
+  }
+  const uint32_t cell = (uint32_t)((cz * g.ny + cy) * g.nx + cx);
+  cell_of[i] = cell;
+  atomicAdd(&add_count[cell], 1u);
+}
+
+// shift[c] = number of new points in the cells before c (exclusive scan of the counts, in place) and the cursor of every
+// cell's new points in the merged array: new begin + old population. Tiled like gridbig_scan_kernel.
+__global__ __launch_bounds__(kScanThreads) void index_insert_tile_sum_kernel(const GridDesc* __restrict__ desc, const uint32_t* __restrict__ shift,
+                                                                             uint32_t* __restrict__ tile_sum) {
+  __shared__ uint32_t s_wave[kScanThreads / 64];
+  const uint32_t ncell = (uint32_t)(desc->nx * desc->ny * desc->nz);
+  const uint32_t c0 = blockIdx.x * kScanTile + threadIdx.x * kScanPer;
+  uint32_t local = 0;
+#pragma unroll
+  for (uint32_t u = 0; u < kScanPer; u++)
+    if (c0 + u < ncell) local += shift[c0 + u];
+  uint32_t total = 0;
+  (void)block_incl_scan_256(local, s_wave, &total);
+  if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kScanThreads) void index_insert_tile_scan_kernel(uint32_t* __restrict__ tile_sum, uint32_t n_tiles) {  // one workgroup
+  __shared__ uint32_t s_wave[kScanThreads / 64];
+  uint32_t carry = 0;
+  for (uint32_t t0 = 0; t0 < n_tiles; t0 += kScanThreads) {
+    const uint32_t t = t0 + threadIdx.x;
+    const uint32_t v = t < n_tiles ? tile_sum[t] : 0u;
+    uint32_t total = 0;
+    const uint32_t incl = block_incl_scan_256(v, s_wave, &total);
+    if (t < n_tiles) tile_sum[t] = carry + incl - v;
+    carry += total;
+  }
+}
+__global__ __launch_bounds__(kScanThreads) void index_insert_scan_kernel(const GridDesc* __restrict__ desc, const uint32_t* __restrict__ cell_start,
+                                                                         const uint32_t* __restrict__ tile_sum, uint32_t* __restrict__ shift,
+                                                                         uint32_t* __restrict__ cursor) {
+  __shared__ uint32_t s_wave[kScanThreads / 64];
+  const uint32_t ncell = (uint32_t)(desc->nx * desc->ny * desc->nz);
+  const uint32_t c0 = blockIdx.x * kScanTile + threadIdx.x * kScanPer;
+  uint32_t cnt[kScanPer], local = 0;
+#pragma unroll
+  for (uint32_t u = 0; u < kScanPer; u++) cnt[u] = c0 + u < ncell ? shift[c0 + u] : 0u, local += cnt[u];
+  uint32_t run = tile_sum[blockIdx.x] + block_incl_scan_256(local, s_wave, nullptr) - local;
+#pragma unroll
+  for (uint32_t u = 0; u < kScanPer; u++) {
+    const uint32_t c = c0 + u;
+    if (c < ncell) {
+      shift[c] = run;
+      cursor[c] = cell_start[c + 1] + run;  // old end of the cell, moved by the new points of the cells before it
+    } else if (c == ncell) {
+      shift[c] = run;  // the total
+    }
+    run += cnt[u];
+  }
+}
+
+// every old point to its place in the twin arrays: old position + new points filed before its cell
+__global__ __launch_bounds__(256) void index_insert_move_kernel(const GridDesc* __restrict__ desc, uint32_t n_old, size_t stride,
+                                                                const GridPoint* __restrict__ sorted, const float* __restrict__ rel,
+                                                                const uint32_t* __restrict__ shift, GridPoint* __restrict__ sorted2,
+                                                                float* __restrict__ rel2) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n_old) return;
+  const GridDesc g = *desc;
+  const GridPoint e = sorted[p];
+  const uint32_t np = p + shift[grid_cell_of_point(g, v3(e.x, e.y, e.z))];
+  sorted2[np] = e;
+  rel2[np] = rel[p], rel2[stride + np] = rel[stride + p], rel2[2 * stride + np] = rel[2 * stride + p];
+}
+
+__global__ __launch_bounds__(256) void index_insert_scatter_kernel(const double* __restrict__ add, uint32_t n_add, uint32_t first_index,
+                                                                   const GridDesc* __restrict__ desc, size_t stride,
+                                                                   const uint32_t* __restrict__ cell_of, uint32_t* __restrict__ cursor,
+                                                                   GridPoint* __restrict__ sorted2, float* __restrict__ rel2) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_add) return;
+  const GridDesc g = *desc;
+  const double x = add[3 * (size_t)i], y = add[3 * (size_t)i + 1], z = add[3 * (size_t)i + 2];
+  const uint32_t pos = atomicAdd(&cursor[cell_of[i]], 1u);
+  sorted2[pos] = GridPoint{x, y, z, first_index + i, 0u};
+  rel2[pos] = (float)(x - g.ox), rel2[stride + pos] = (float)(y - g.oy), rel2[2 * stride + pos] = (float)(z - g.oz);
+}
+
+// the cell table moves with the points; the point count and the float pads behind the set follow
+__global__ __launch_bounds__(256) void index_insert_table_kernel(GridDesc* __restrict__ desc, uint32_t* __restrict__ cell_start,
+                                                                 const uint32_t* __restrict__ shift, uint32_t n_new, size_t stride,
+                                                                 float* __restrict__ rel2) {
+  const uint32_t ncell = (uint32_t)(desc->nx * desc->ny * desc->nz);
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+  if (c <= ncell) cell_start[c] += shift[c];  // (entry ncell: the total)
+  if (c < kGridPad) rel2[n_new + c] = kRelPad, rel2[stride + n_new + c] = kRelPad, rel2[2 * stride + n_new + c] = kRelPad;
+  if (c == 0) desc->n_points = n_new;  // (read by nobody in this launch: the kernels before it took the grid by value)
 }
 
 // Second half of the ORDERED build (source sets): every point of the scratch copy is placed at
@@ -1522,7 +1683,7 @@ void launch_assoc_dump(const RegBatch& B, const RegConfig& C, const AssocDumpSet
 // map-sized target sets: the multi-workgroup build (needs kBigScratchBytes of scratch per pair)
 static bool grid_big(size_t stride, const GridPoint* scratch, uint32_t flags) {
   return !grid_small(stride, flags) && scratch != nullptr && stride * sizeof(GridPoint) >= kBigScratchBytes && !(flags & kRegFlagNoBigGrid);
-}  // (a caller that sets GridSet::cells_cap provides 64 + 4 * cells_cap bytes of scratch and one pair)
+}  // (a caller that sets GridSet::cells_cap provides 64 + 4 * (cells_cap + cells_cap / 4096 + 8) bytes of scratch and one pair)
 static void launch_grid_build_big(size_t n_pairs, const double* pts, const uint32_t* n_pts, size_t stride, uint32_t in_pitch,
                                   double max_dist, const GridSet& gs, GridPoint* scratch, hipStream_t s) {
   const dim3 chunks((unsigned)((stride + kBigChunk - 1) / kBigChunk), (unsigned)n_pairs);
@@ -1532,11 +1693,41 @@ static void launch_grid_build_big(size_t n_pairs, const double* pts, const uint3
                      scratch, n_pairs);
   (void)hipMemsetAsync(gs.cell_start, 0, (gs.cells_cap ? (size_t)gs.cells_cap + 1 : n_pairs * (size_t)(kGridCellsCap + 1)) * sizeof(uint32_t), s);
   launch_kernel(gridbig_pass_kernel<false>, chunks, dim3(kBigThreads), 0, s, pts, n_pts, stride, in_pitch, gs, scratch);
-  launch_kernel(gridbig_scan_kernel, dim3((unsigned)n_pairs), dim3(1024), 0, s, n_pts, stride, in_pitch, gs, scratch);
+  const unsigned n_tiles = (unsigned)(((gs.cells_cap ? gs.cells_cap : kGridCellsCap) + 1 + kScanTile - 1) / kScanTile);
+  launch_kernel(gridbig_tile_sum_kernel, dim3(n_tiles, (unsigned)n_pairs), dim3(kScanThreads), 0, s, stride, gs, scratch);
+  launch_kernel(gridbig_tile_scan_kernel, dim3((unsigned)n_pairs), dim3(kScanThreads), 0, s, stride, gs, scratch);
+  launch_kernel(gridbig_scan_kernel, dim3(n_tiles, (unsigned)n_pairs), dim3(kScanThreads), 0, s, n_pts, stride, in_pitch, gs, scratch);
   launch_kernel(gridbig_pass_kernel<true>, chunks, dim3(kBigThreads), 0, s, pts, n_pts, stride, in_pitch, gs, scratch);
   if (gs.rel)
     launch_kernel(gridbig_rel_kernel, dim3((unsigned)((stride + kGridPad + kBigThreads - 1) / kBigThreads), (unsigned)n_pairs), dim3(kBigThreads), 0,
                        s, n_pts, stride, in_pitch, gs);
+}
+
+// (see the kernels: "Incremental insert into a map-sized persistent index") — ws must hold index_insert_ws_bytes()
+size_t index_insert_ws_bytes(size_t cells, size_t n_add) {
+  return 16 + (2 * (cells + 1) + n_add + (cells + 1 + kScanTile - 1) / kScanTile) * sizeof(uint32_t);
+}
+void launch_index_insert_count(const GridSet& gs, size_t cells, const double* d_add, uint32_t n_add, void* ws, hipStream_t s) {
+  uint32_t* flag = static_cast<uint32_t*>(ws);
+  uint32_t* shift = flag + 4;
+  uint32_t* cell_of = shift + 2 * (cells + 1);
+  (void)hipMemsetAsync(ws, 0, 16 + (cells + 1) * sizeof(uint32_t), s);
+  launch_kernel(index_insert_count_kernel, dim3((n_add + 255) / 256), dim3(256), 0, s, d_add, n_add, gs.desc, flag, shift, cell_of);
+}
+void launch_index_insert_merge(const GridSet& gs, size_t cells, uint32_t n_old, const double* d_add, uint32_t n_add, void* ws,
+                               GridPoint* sorted2, float* rel2, hipStream_t s) {
+  uint32_t* shift = static_cast<uint32_t*>(ws) + 4;
+  uint32_t* cursor = shift + (cells + 1);
+  uint32_t* cell_of = shift + 2 * (cells + 1);
+  // (the tile sums sit in the cursor table's spare last entry region: behind the cells of the cell_of array)
+  uint32_t* tile_sum = cell_of + n_add;
+  const uint32_t n_tiles = (uint32_t)((cells + 1 + kScanTile - 1) / kScanTile);
+  launch_kernel(index_insert_tile_sum_kernel, dim3(n_tiles), dim3(kScanThreads), 0, s, gs.desc, shift, tile_sum);
+  launch_kernel(index_insert_tile_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, tile_sum, n_tiles);
+  launch_kernel(index_insert_scan_kernel, dim3(n_tiles), dim3(kScanThreads), 0, s, gs.desc, gs.cell_start, tile_sum, shift, cursor);
+  if (n_old) launch_kernel(index_insert_move_kernel, dim3((n_old + 255) / 256), dim3(256), 0, s, gs.desc, n_old, gs.stride, gs.sorted, gs.rel, shift, sorted2, rel2);
+  launch_kernel(index_insert_scatter_kernel, dim3((n_add + 255) / 256), dim3(256), 0, s, d_add, n_add, n_old, gs.desc, gs.stride, cell_of, cursor, sorted2, rel2);
+  launch_kernel(index_insert_table_kernel, dim3((unsigned)((cells + 1 + 255) / 256)), dim3(256), 0, s, gs.desc, gs.cell_start, shift, n_old + n_add, gs.stride, rel2);
 }
 
 static void debug_ptr(const char* what, const void* p, size_t need) {
