@@ -318,7 +318,8 @@ enum {
   LOAMX_K_CURVATURE = 0, /* curvature + validity, 33 B/point algorithmic */
   LOAMX_K_SELECT = 1,    /* per-sector greedy selection */
   LOAMX_K_COMPACT = 2,   /* feature gather */
-  LOAMX_K_GRID = 3,      /* target spatial index build */
+  LOAMX_K_GRID = 3,      /* spatial index builds (targets: searched; sources: ordered): 24 B read + 32 B written per point,
+                            + 12 B of float copies and 4 B per grid cell for the target sets that are searched by cells */
   LOAMX_K_ASSOC = 4,     /* kNN + line/plane fit */
   LOAMX_K_SWEEP = 5,     /* residual / Jacobian / normal equations, 56 B per plane + 72 B per edge slot streamed */
   LOAMX_K_LM = 6,        /* per-pair trust-region bookkeeping */

@@ -546,10 +546,11 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   B.moments = wsp<double>(ctx, WS_MOMENTS);
   B.flagged_list = wsp<uint32_t>(ctx, WS_FLAGGED_LIST);
   B.flagged_count = wsp<uint32_t>(ctx, WS_FLAGGED_COUNT);
-  // counters: [0] n_active (u32), [8..24) sweep slot counters (2 x u64)
+  // counters: [0] n_active (u32), [8..48) sweep / association / moment slot counters (5 x u64), [48..56) index-build bytes
   B.n_active = wsp<uint32_t>(ctx, WS_COUNTERS);
   B.sweep_slots = reinterpret_cast<unsigned long long*>(wsp<unsigned char>(ctx, WS_COUNTERS) + 8);
   B.assoc_slots = B.sweep_slots + 2;
+  B.grid_bytes = B.sweep_slots + 5;
   B.iter_info = want_iter_info ? wsp<loamx_iter_info>(ctx, WS_ITERINFO) : nullptr;
   B.want_nearest = hook ? 1u : 0u;
   B.max_counts = wsp<uint32_t>(ctx, WS_COUNTERS) + 16;  // bytes 64..88
@@ -1477,10 +1478,10 @@ int loamx_ctx_enable_kernel_timing(loamx_ctx* ctx, int enable) {
   return LOAMX_OK;
 }
 
-static int read_sweep_slots(loamx_ctx* ctx, unsigned long long out[5]) {
-  out[0] = out[1] = out[2] = out[3] = out[4] = 0;
+static int read_sweep_slots(loamx_ctx* ctx, unsigned long long out[6]) {
+  out[0] = out[1] = out[2] = out[3] = out[4] = out[5] = 0;
   if (!ctx->ws[WS_COUNTERS].p) return LOAMX_OK;
-  HIP_TRY(ctx, hipMemcpy(out, wsp<unsigned char>(ctx, WS_COUNTERS) + 8, 40, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(out, wsp<unsigned char>(ctx, WS_COUNTERS) + 8, 48, hipMemcpyDeviceToHost));
   return LOAMX_OK;
 }
 
@@ -1492,7 +1493,7 @@ int loamx_ctx_reset_kernel_stats(loamx_ctx* ctx) {
   if (rc != LOAMX_OK) return rc;
   memset(ctx->stats, 0, sizeof(ctx->stats));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->ws[WS_COUNTERS].p) HIP_TRY(ctx, hipMemset(wsp<unsigned char>(ctx, WS_COUNTERS) + 8, 0, 40));
+  if (ctx->ws[WS_COUNTERS].p) HIP_TRY(ctx, hipMemset(wsp<unsigned char>(ctx, WS_COUNTERS) + 8, 0, 48));
   if (ctx->ws[WS_EXTRACT_EVENTS].p) {
     unsigned long long ev[4] = {0, 0, 0, 0};
     HIP_TRY(ctx, hipMemcpy(ev, ctx->ws[WS_EXTRACT_EVENTS].p, sizeof(ev), hipMemcpyDeviceToHost));
@@ -1508,7 +1509,7 @@ int loamx_ctx_get_kernel_stats(loamx_ctx* ctx, loamx_kernel_stat* stats) {
   int rc = resolve_events(ctx);
   if (rc != LOAMX_OK) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  unsigned long long slots[5];
+  unsigned long long slots[6];
   rc = read_sweep_slots(ctx, slots);
   if (rc != LOAMX_OK) return rc;
   memcpy(stats, ctx->stats, sizeof(ctx->stats));
@@ -1517,6 +1518,7 @@ int loamx_ctx_get_kernel_stats(loamx_ctx* ctx, loamx_kernel_stat* stats) {
   // associate: read the 24 B source point, write the record + the 4 B nearest index
   stats[LOAMX_K_ASSOC].algorithmic_bytes = 100.0 * (double)slots[2] + 84.0 * (double)slots[3];
   stats[LOAMX_K_MOMENT].algorithmic_bytes = 56.0 * (double)slots[4];  // moment pass: every plane record once
+  stats[LOAMX_K_GRID].algorithmic_bytes = (double)slots[5];            // index builds: counted by the build kernels
   if (ctx->ws[WS_EXTRACT_EVENTS].p) {  // fused extraction: + (4 + 24) B per feature written (counted by the kernel since the reset)
     unsigned long long ev[4] = {0, 0, 0, 0};
     HIP_TRY(ctx, hipMemcpy(ev, ctx->ws[WS_EXTRACT_EVENTS].p, sizeof(ev), hipMemcpyDeviceToHost));

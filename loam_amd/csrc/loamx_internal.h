@@ -195,6 +195,7 @@ struct RegBatch {
   unsigned long long* sweep_slots;  // [0,1] edge / plane association slots streamed by sweep_kernel (roofline bytes);
                                     // [2,3] assoc_slots; [4] plane slots streamed by the moment pass
   unsigned long long* assoc_slots;  // [2] edge / plane source features processed by associate_kernel
+  unsigned long long* grid_bytes;   // roofline bytes of the single-workgroup index builds (may be null)
   loamx_iter_info* iter_info;  // optional [n_pairs][max_iterations]
   uint32_t* max_counts;   // [6] over the active pairs (state_init_kernel; read back by the host): largest source edge / planar
                           // count, largest target edge / planar count, smallest target edge / planar count

@@ -56,7 +56,8 @@ constexpr int kBuildThreads = LOAMX_BUILD_THREADS;
 template <bool ORDERED, bool PACKED>
 __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double* __restrict__ pts_base,
                                                                    const uint32_t* __restrict__ n_pts, size_t stride,
-                                                                   uint32_t in_pitch, double max_dist, GridSet gs, GridPoint* __restrict__ scratch) {
+                                                                   uint32_t in_pitch, double max_dist, GridSet gs, GridPoint* __restrict__ scratch,
+                                                                   unsigned long long* __restrict__ bytes) {
   __shared__ uint32_t s_cells[PACKED ? kGridLdsCells / 2 : kGridLdsCells];
   auto cell_get = [&](uint32_t c) -> uint32_t { return PACKED ? (s_cells[c >> 1] >> ((c & 1u) * 16u)) & 0xFFFFu : s_cells[c]; };
   auto cell_add = [&](uint32_t c) -> uint32_t {  // returns the value before the increment
@@ -219,6 +220,11 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
     STAMP();  // scatter
   }
   if (tid == 0) cs[ncell] = n;
+  // roofline bytes of the index builds (SURVEY 8d style: what has to move at least): 24 B read per point, the 32-byte cell-
+  // ordered copy written, + 12 B of float copies and the cell table (4 B per cell) for a target set that is searched by cells
+  if (tid == 0 && bytes)
+    atomicAdd(bytes, (unsigned long long)n * (ORDERED ? 56ull : (gs.rel ? 68ull : 56ull)) +
+                         ((!(ORDERED && PACKED) && (ORDERED || n > kBruteMax)) ? 4ull * (ncell + 1) : 0ull));
   if (PACKED) {
     const uint16_t* order = s_inv;
     if (ORDERED) {
@@ -1741,7 +1747,7 @@ static void debug_ptr(const char* what, const void* p, size_t need) {
 
 template <bool ORDERED>
 static void launch_grid_build(size_t n_pairs, const double* pts, const uint32_t* n_pts, size_t stride, uint32_t in_pitch,
-                              double max_dist, const GridSet& gs, GridPoint* scratch, uint32_t flags, hipStream_t s) {
+                              double max_dist, const GridSet& gs, GridPoint* scratch, uint32_t flags, hipStream_t s, unsigned long long* bytes) {
   if (g_debug_sync) {
     fprintf(stderr, "[loamx]   grid build ORDERED=%d n_pairs %zu stride %zu in_pitch %u gs.stride %zu\n", (int)ORDERED, n_pairs, stride, in_pitch, gs.stride);
     debug_ptr("pts", pts, n_pairs * in_pitch * stride * 24);
@@ -1758,16 +1764,16 @@ static void launch_grid_build(size_t n_pairs, const double* pts, const uint32_t*
   }
   if (grid_small(stride, flags))
     launch_kernel((grid_build_kernel<ORDERED, true>), dim3((unsigned)n_pairs), dim3(kBuildThreads), 0, s, pts, n_pts, stride,
-                       in_pitch, max_dist, gs, scratch);
+                       in_pitch, max_dist, gs, scratch, bytes);
   else
     launch_kernel((grid_build_kernel<ORDERED, false>), dim3((unsigned)n_pairs), dim3(kBuildThreads), 0, s, pts, n_pts, stride,
-                       in_pitch, max_dist, gs, scratch);
+                       in_pitch, max_dist, gs, scratch, bytes);
 }
 
 void launch_grid_build_target(const RegBatch& B, const RegConfig& C, bool plane, hipStream_t s) {
   if (B.n_pairs == 0) return;
-  if (plane) launch_grid_build<false>(B.n_pairs, B.tgt_planar, B.n_tgt_planar, B.planar_stride, B.in_pitch, C.r_plane, B.grid_plane, B.sort_scratch, C.flags, s);
-  else launch_grid_build<false>(B.n_pairs, B.tgt_edge, B.n_tgt_edge, B.edge_stride, B.in_pitch, C.r_edge, B.grid_edge, B.sort_scratch, C.flags, s);
+  if (plane) launch_grid_build<false>(B.n_pairs, B.tgt_planar, B.n_tgt_planar, B.planar_stride, B.in_pitch, C.r_plane, B.grid_plane, B.sort_scratch, C.flags, s, B.grid_bytes);
+  else launch_grid_build<false>(B.n_pairs, B.tgt_edge, B.n_tgt_edge, B.edge_stride, B.in_pitch, C.r_edge, B.grid_edge, B.sort_scratch, C.flags, s, B.grid_bytes);
 }
 void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   launch_grid_build_target(B, C, false, s);
@@ -1784,7 +1790,7 @@ void launch_grid_build_source(const RegBatch& B, const RegConfig& C, bool plane,
   const uint32_t* n_src = plane ? B.n_src_planar : B.n_src_edge;
   const GridSet& gs = plane ? B.src_grid_plane : B.src_grid_edge;
   launch_grid_build<true>(B.n_pairs, plane ? B.src_planar : B.src_edge, n_src, stride, B.in_pitch, plane ? C.r_plane : C.r_edge, gs,
-                          B.sort_scratch_src, C.flags, s);
+                          B.sort_scratch_src, C.flags, s, B.grid_bytes);
   if (stride && !grid_small(stride, C.flags))
     launch_kernel(grid_rank_kernel, dim3((unsigned)((stride + kRankThreads - 1) / kRankThreads), (unsigned)B.n_pairs), dim3(kRankThreads), 0, s,
                   n_src, stride, B.in_pitch, gs, B.sort_scratch_src);
