@@ -236,6 +236,7 @@ typedef struct {
   uint8_t* plane_valid;
   double* plane_moved;
   double* plane_planes;
+  uint32_t* queue_lengths; /* 4: queries the first k-NN pass handed on {edge, plane}, then those its second pass handed on */
 } loamx_assoc_dump;
 int loamx_associate(loamx_ctx* ctx, const double* src_edge, size_t n_src_edge, const double* src_planar, size_t n_src_planar,
                     const double* tgt_edge, size_t n_tgt_edge, const double* tgt_planar, size_t n_tgt_planar,

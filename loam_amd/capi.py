@@ -74,7 +74,7 @@ RESULT_DTYPE = np.dtype([("pose", np.float64, 7), ("termination", np.uint32), ("
 class AssocDump(C.Structure):
     """loamx_assoc_dump (include/loamx.h)"""
     _fields_ = [(n, C.c_void_p) for n in ("edge_nn_count", "edge_nn_idx", "edge_valid", "edge_moved", "edge_lines",
-                                          "plane_nn_count", "plane_nn_idx", "plane_valid", "plane_moved", "plane_planes")]
+                                          "plane_nn_count", "plane_nn_idx", "plane_valid", "plane_moved", "plane_planes", "queue_lengths")]
 
 
 EXPORTS = [
@@ -460,14 +460,15 @@ class Context:
         for kind in range(2):
             bufs.append(dict(cnt=np.zeros(n[kind], dtype=np.uint32), idx=np.full((n[kind], max(k[kind], 1)), 0xFFFFFFFF, dtype=np.uint32),
                              valid=np.zeros(n[kind], dtype=np.uint8), moved=np.zeros((n[kind], 3)), prim=np.zeros((n[kind], pw[kind]))))
-        d = AssocDump(*[b[f].ctypes.data for b in bufs for f in ("cnt", "idx", "valid", "moved", "prim")])
+        queues = np.zeros(4, dtype=np.uint32)
+        d = AssocDump(*([b[f].ctypes.data for b in bufs for f in ("cnt", "idx", "valid", "moved", "prim")] + [queues.ctypes.data]))
         self._check(self.lib.loamx_associate(self.h, _dp(arrs[0]), n[0], _dp(arrs[1]), n[1], _dp(arrs[2]), len(arrs[2]), _dp(arrs[3]),
                                              len(arrs[3]), _dp(pose), C.byref(reg), C.byref(d)))
         out = {}
         for kind, name in enumerate(("edge", "plane")):
             b = bufs[kind]
             out[name] = dict(nn=[b["idx"][i, :b["cnt"][i]].copy() for i in range(n[kind])], valid=b["valid"].astype(bool),
-                             moved=b["moved"], prim=b["prim"])
+                             moved=b["moved"], prim=b["prim"], queued=(int(queues[kind]), int(queues[2 + kind])))
         return out
 
     # ---- persistent target index (scan-to-map) -----------------------------------------------------------

@@ -628,6 +628,7 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
         {dump->plane_moved, D[1].moved, 24 * n[1]}, {dump->plane_planes, D[1].prim, 32 * n[1]}};
     for (const Out& o : outs)
       if (o.host && o.bytes && o.dev) HIP_TRY(ctx, hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, s));
+    if (dump->queue_lengths) HIP_TRY(ctx, hipMemcpyAsync(dump->queue_lengths, B.assoc.n_assoc + 2, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     return LOAMX_OK;
   }
