@@ -213,7 +213,7 @@ int loamx_fit_lines(loamx_ctx* ctx, const double* points, size_t n_sets, size_t 
 int loamx_fit_planes(loamx_ctx* ctx, const double* points, size_t n_sets, size_t k, double* planes_out, double* avg_dist_out);
 /* kdtree_internal::knnSearch (kdtree.h:49, kdtree.cpp:10-28) for n_queries points against one set of a target index
  * (which_set: 0 = its edge points, 1 = its planar points; the index plays the role of the reference's KDTree):
- * exact k nearest (k <= 8), ascending, then the strict radius filter (max_dist <= 0: none). indices_out:
+ * exact k nearest (k <= 16), ascending, then the strict radius filter (max_dist <= 0: none). indices_out:
  * n_queries x k indices into the array the index was built from (0xFFFFFFFF past the count); counts_out: n_queries. */
 int loamx_knn_search(loamx_ctx* ctx, const loamx_target_index* index, int which_set, const double* queries, size_t n_queries,
                      size_t k, double max_dist, uint32_t* indices_out, uint32_t* counts_out);

@@ -254,7 +254,7 @@ int make_extract_params(loamx_ctx* ctx, const loamx_lidar_params* lidar, const l
 int make_reg_config(loamx_ctx* ctx, const loamx_reg_params* r, RegConfig& C) {
   if (!r) return fail(ctx, LOAMX_ERR_BAD_PARAM, "null registration params");
   if (r->num_edge_neighbors > (uint64_t)kMaxK || r->num_plane_neighbors > (uint64_t)kMaxK)
-    return fail(ctx, LOAMX_ERR_UNSUPPORTED, "num_*_neighbors > 8 not supported by the kernels");
+    return fail(ctx, LOAMX_ERR_UNSUPPORTED, "num_*_neighbors > 16 not supported by the kernels");
   if (r->min_plane_fit_points < 3 && r->num_plane_neighbors > 0)
     return fail(ctx, LOAMX_ERR_BAD_PARAM, "min_plane_fit_points must be >= 3");
   if (r->min_line_fit_points < 2 && r->num_edge_neighbors > 0)
@@ -491,10 +491,12 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   ENSURE(ctx, WS_SORT_SCRATCH_SRC, grid_small(es > ps ? es : ps, C.flags) ? sizeof(GridPoint) : np * (es > ps ? es : ps) * sizeof(GridPoint));
   ENSURE(ctx, WS_ASSOC_E, 9 * np * es * sizeof(double));
   ENSURE(ctx, WS_ASSOC_P, 7 * np * ps * sizeof(double));
-  ENSURE(ctx, WS_NN_E, (size_t)(1 + kMaxK) * np * es * sizeof(uint32_t));
-  ENSURE(ctx, WS_NN_P, (size_t)(1 + kMaxK) * np * ps * sizeof(uint32_t));
-  ENSURE(ctx, WS_RNN_E, (size_t)(1 + kMaxK) * np * es * sizeof(uint32_t));
-  ENSURE(ctx, WS_RNN_P, (size_t)(1 + kMaxK) * np * ps * sizeof(uint32_t));
+  // (neighbour lists: the count + as many positions as the kernel variant in use keeps: 5, 8 or 16 — launch_associate)
+  const size_t km_e = C.k_edge <= 5 ? 5 : (C.k_edge <= 8 ? 8 : kMaxK), km_p = C.k_plane <= 5 ? 5 : (C.k_plane <= 8 ? 8 : kMaxK);
+  ENSURE(ctx, WS_NN_E, (1 + km_e) * np * es * sizeof(uint32_t));
+  ENSURE(ctx, WS_NN_P, (1 + km_p) * np * ps * sizeof(uint32_t));
+  ENSURE(ctx, WS_RNN_E, (1 + km_e) * np * es * sizeof(uint32_t));
+  ENSURE(ctx, WS_RNN_P, (1 + km_p) * np * ps * sizeof(uint32_t));
   ENSURE(ctx, WS_NEAREST_E, np * es * sizeof(uint32_t));
   ENSURE(ctx, WS_NEAREST_P, np * ps * sizeof(uint32_t));
   ENSURE(ctx, WS_REST_E, np * es * sizeof(uint32_t));
@@ -1112,7 +1114,7 @@ int loamx_knn_search(loamx_ctx* ctx, const loamx_target_index* index, int which_
     memset(counts_out, 0, n_queries * sizeof(uint32_t));
     return LOAMX_OK;
   }
-  if (k > (size_t)kMaxK) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "k > 8 neighbours not supported by the search kernels");
+  if (k > (size_t)kMaxK) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "k > 16 neighbours not supported by the search kernels");
   if (n_queries > 0x7FFFFFFFull / 64) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "too many queries in one call");
   untimed(ctx);
   ENSURE(ctx, WS_FIT_IN, n_queries * 24);

@@ -28,7 +28,7 @@
 
 namespace loamx {
 
-constexpr int kMaxK = 8;          // upper bound on num_*_neighbors the kernels keep in registers
+constexpr int kMaxK = 16;         // upper bound on num_*_neighbors the kernels keep in registers (instantiated for 5, 8 and 16)
 constexpr double kDblMin = 2.2250738585072014e-308;
 constexpr double kDblMax = 1.7976931348623157e308;
 constexpr double kDblEps = 2.220446049250313e-16;
@@ -686,6 +686,24 @@ LOAMX_HD void knn_rounds(const GridDesc& g, const uint32_t* __restrict__ cell_st
     first = false;
     if (knn_done(g, q, k, max_dist, cx, cy, cz, r, w)) break;
     w++;
+  }
+}
+
+// pos[(KM - k) + j] = src[j] for j < k (the shifted layout of the keyed collectors), zero elsewhere — with STATIC register
+// indices only. The obvious form, `if (j < k) pos[(KM - k) + j] = src[j]` in an unrolled loop, is compiled by hipcc 7.2
+// into an UNCONDITIONAL indexed register write (s_set_gpr_idx_on ... v_mov) followed by a select: in the iterations the
+// guard excludes, the index lies beyond the array and the write lands in whatever registers follow it. Found in round 3
+// when KM = 16, k = 13 overwrote the thread's own query index (a GPU memory fault); with KM = 5 / 8 the registers behind
+// the array happened to be dead.
+template <int KM>
+LOAMX_HD void knn_shift_positions(const uint32_t src[KM], int k, uint32_t pos[KM]) {
+#pragma unroll
+  for (int u = 0; u < KM; u++) {
+    uint32_t v = 0u;
+#pragma unroll
+    for (int t = 0; t < KM; t++)
+      if (t + (KM - k) == u) v = src[t];
+    pos[u] = v;
   }
 }
 
@@ -1440,8 +1458,7 @@ LOAMX_HD int knn_search_positions(const GridDesc& g, const uint32_t* __restrict_
     if (k > KM) k = KM;
     KnnResult<KM> r;
     kept = knn_search(g, cell_start, sp, q, k, max_dist, r, row_scratch, row_stride);
-    for (int j = 0; j < KM; j++) pos[j] = 0;
-    for (int j = 0; j < k; j++) pos[(KM - k) + j] = r.pos[j];
+    knn_shift_positions<KM>(r.pos, k, pos);
   }
   return kept;
 }

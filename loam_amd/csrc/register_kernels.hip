@@ -736,11 +736,7 @@ __global__ __launch_bounds__(kAssocThreads) void associate_knn_brute_kernel(RegB
       }
       if (kept < 0) {
         kept = knn_finish(r, k, max_dist);
-#pragma unroll
-        for (int j = 0; j < KM; j++) pos[j] = 0;
-#pragma unroll
-        for (int jj = 0; jj < KM; jj++)
-          if (jj < k) pos[(KM - k) + jj] = r.pos[jj];
+        knn_shift_positions<KM>(r.pos, k, pos);
       }
     }
   }
@@ -1593,18 +1589,16 @@ __global__ __launch_bounds__(64) void knn_queries_kernel(GridSet gs, const doubl
     knn_init(r);
     brute_scan_tile(r, kk, p, gs.sorted, 0u, g.n_points);  // (the set has kGridPad spare entries behind it)
     kept = knn_finish(r, kk, max_dist);
-#pragma unroll
-    for (int j = 0; j < KM; j++) pos[j] = 0;
-#pragma unroll
-    for (int j = 0; j < KM; j++)
-      if (j < kk) pos[(KM - kk) + j] = r.pos[j];
+    knn_shift_positions<KM>(r.pos, kk, pos);
   } else {
     kept = knn_search_positions<KM>(g, gs.cell_start, gs.sorted, p, kk, max_dist, pass_max, pos, s_rows + threadIdx.x, 64);
   }
   count_out[i] = (uint32_t)kept;
 #pragma unroll
-  for (int j = 0; j < KM; j++)
-    if (j < kk) idx_out[i * (size_t)k + j] = j < kept ? gs.sorted[pos[(KM - kk) + j]].orig : 0xFFFFFFFFu;
+  for (int u = 0; u < KM; u++) {  // (slot u holds neighbour u - (KM - kk): static register indices, see knn_shift_positions)
+    const int j = u - (KM - kk);
+    if (j >= 0) idx_out[i * (size_t)k + j] = j < kept ? gs.sorted[pos[u]].orig : 0xFFFFFFFFu;
+  }
   for (int j = KM; j < k; j++) idx_out[i * (size_t)k + j] = 0xFFFFFFFFu;
 }
 
@@ -1670,7 +1664,8 @@ void launch_knn_queries(const GridSet& gs, const double* d_q, size_t n_q, int k,
   const dim3 grid((unsigned)((n_q + 63) / 64));
   const double pass_max = knn_radius_pass_max(max_dist);
   if (k <= 5) launch_kernel((knn_queries_kernel<5>), grid, dim3(64), 0, s, gs, d_q, n_q, k, max_dist, pass_max, d_idx, d_count);
-  else launch_kernel((knn_queries_kernel<8>), grid, dim3(64), 0, s, gs, d_q, n_q, k, max_dist, pass_max, d_idx, d_count);
+  else if (k <= 8) launch_kernel((knn_queries_kernel<8>), grid, dim3(64), 0, s, gs, d_q, n_q, k, max_dist, pass_max, d_idx, d_count);
+  else launch_kernel((knn_queries_kernel<16>), grid, dim3(64), 0, s, gs, d_q, n_q, k, max_dist, pass_max, d_idx, d_count);
 }
 
 void launch_assoc_dump(const RegBatch& B, const RegConfig& C, const AssocDumpSet& edge, const AssocDumpSet& plane, hipStream_t s) {
@@ -1678,11 +1673,13 @@ void launch_assoc_dump(const RegBatch& B, const RegConfig& C, const AssocDumpSet
   const dim3 ge((unsigned)((2 * B.edge_stride + 255) / 256)), gp((unsigned)((2 * B.planar_stride + 255) / 256));
   if (edge.nn_count) {
     if (C.k_edge <= 5) launch_kernel((assoc_dump_kernel<false, 5>), ge, dim3(256), 0, s, B, C, edge);
-    else launch_kernel((assoc_dump_kernel<false, 8>), ge, dim3(256), 0, s, B, C, edge);
+    else if (C.k_edge <= 8) launch_kernel((assoc_dump_kernel<false, 8>), ge, dim3(256), 0, s, B, C, edge);
+    else launch_kernel((assoc_dump_kernel<false, 16>), ge, dim3(256), 0, s, B, C, edge);
   }
   if (plane.nn_count) {
     if (C.k_plane <= 5) launch_kernel((assoc_dump_kernel<true, 5>), gp, dim3(256), 0, s, B, C, plane);
-    else launch_kernel((assoc_dump_kernel<true, 8>), gp, dim3(256), 0, s, B, C, plane);
+    else if (C.k_plane <= 8) launch_kernel((assoc_dump_kernel<true, 8>), gp, dim3(256), 0, s, B, C, plane);
+    else launch_kernel((assoc_dump_kernel<true, 16>), gp, dim3(256), 0, s, B, C, plane);
   }
 }
 
@@ -1824,7 +1821,7 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
   const uint32_t be = B.assoc_blocks_edge != 0xFFFFFFFFu ? B.assoc_blocks_edge : (uint32_t)((B.edge_stride + kAssocThreads - 1) / kAssocThreads);
   const uint32_t bp = B.assoc_blocks_plane != 0xFFFFFFFFu ? B.assoc_blocks_plane : (uint32_t)((B.planar_stride + kAssocThreads - 1) / kAssocThreads);
   const size_t pair_groups = (B.n_pairs + 7) / 8;  // grid covers 8 XCD lanes x pair_groups x chunks
-  // register-resident neighbour lists are instantiated for K <= 5 (the reference's default) and K <= 8
+  // register-resident neighbour lists are instantiated for K <= 5 (the reference's default), K <= 8 and K <= 16
   // Per feature kind, two chains: A = brute force (small target sets) | round-1 k-NN -> fit of the
   // finished queries; B = k-NN of the queued queries (all rounds, then exact) -> their fit. B needs
   // only the round-1 kernel of A, and its short, uneven queues leave most of the GPU idle, so it runs on
@@ -1859,7 +1856,8 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
 #define LOAMX_ASSOC_K(STEP, PL, nblk, st)                \
   do {                                                   \
     if ((PL ? C.k_plane : C.k_edge) <= 5) STEP(PL, 5, nblk, st); \
-    else STEP(PL, 8, nblk, st);                          \
+    else if ((PL ? C.k_plane : C.k_edge) <= 8) STEP(PL, 8, nblk, st); \
+    else STEP(PL, 16, nblk, st);                         \
   } while (0)
   const bool edges = (what & kAssocEdges) != 0u && be != 0u, planes = (what & kAssocPlanes) != 0u && bp != 0u;
   // (edges alone: on the caller's stream, nothing to run them next to)

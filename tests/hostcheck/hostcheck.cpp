@@ -420,10 +420,11 @@ uint64_t hostcheck_knn_mismatches(void) { return g_knn_mismatch; }
 uint64_t hostcheck_knn(const double* pts, uint64_t n, const double q[3], uint64_t k, double max_dist, uint64_t* idx_out) {
   HostGrid G;
   build_grid(pts, (uint32_t)n, max_dist, G);
-  uint32_t pos[8];
-  // the kernels are instantiated for KM = 5 (default parameters) and KM = 8
+  uint32_t pos[16];
+  // the kernels are instantiated for KM = 5 (default parameters), 8 and 16
   const int kept = k <= 5 ? knn_both<5>(G, v3(q[0], q[1], q[2]), (int)k, max_dist, pos)
-                          : knn_both<8>(G, v3(q[0], q[1], q[2]), (int)k, max_dist, pos);
+                          : (k <= 8 ? knn_both<8>(G, v3(q[0], q[1], q[2]), (int)k, max_dist, pos)
+                                    : knn_both<16>(G, v3(q[0], q[1], q[2]), (int)k, max_dist, pos));
   for (int j = 0; j < kept; j++) idx_out[j] = G.sp[pos[j]].orig;
   return (uint64_t)kept;
 }

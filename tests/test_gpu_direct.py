@@ -130,8 +130,8 @@ def test_associate_fuzz_lists_and_fits(oracle, seed):
     src_e = src_e + rng.normal(size=src_e.shape) * 0.003
     src_p = src_p + rng.normal(size=src_p.shape) * 0.003
     reg, oreg = capi.RegistrationParams(), oracle.RegParams()
-    reg.num_edge_neighbors = oreg.num_edge_neighbors = int(rng.choice([2, 3, 5, 8]))
-    reg.num_plane_neighbors = oreg.num_plane_neighbors = int(rng.choice([4, 5, 7, 8]))
+    reg.num_edge_neighbors = oreg.num_edge_neighbors = int(rng.choice([2, 3, 5, 8, 11]))
+    reg.num_plane_neighbors = oreg.num_plane_neighbors = int(rng.choice([4, 5, 7, 8, 12, 16]))
     reg.min_line_fit_points = oreg.min_line_fit_points = int(rng.choice([2, 3]))
     reg.max_plane_neighbor_dist = oreg.max_plane_neighbor_dist = float(rng.choice([0.5, 2.0, -1.0]))
     reg.max_edge_neighbor_dist = oreg.max_edge_neighbor_dist = float(rng.choice([0.3, 1.0, -1.0]))
@@ -184,7 +184,7 @@ def test_fit_line_entry_point_on_degenerate_lattices(oracle):
 
 def test_knn_entry_point_against_the_oracle_tree(oracle):
     """kdtree_internal::knnSearch (kdtree.h:49) through loamx_knn_search on a target index: index lists in order for
-    k = 1..8, with and without the radius, queries inside, outside and far from the set; the empty set"""
+    k = 1..16, with and without the radius, queries inside, outside and far from the set; the empty set"""
     rng = np.random.default_rng(3)
     c = ctx()
     for n, scale in ((37, 1.0), (600, 3.0), (30000, 8.0)):
@@ -193,7 +193,7 @@ def test_knn_entry_point_against_the_oracle_tree(oracle):
         tree_p, tree_e = oracle.KDTree(pts), oracle.KDTree(pts[: n // 3])
         q = np.concatenate([pts[rng.integers(0, n, 150)] + rng.normal(size=(150, 3)) * 0.05, rng.normal(size=(40, 3)) * scale * 3,
                             np.array([[1e3, -1e3, 5e2]])])
-        for k in (1, 3, 5, 8):
+        for k in (1, 3, 5, 8, 13, 16):
             for radius in (-1.0, 0.4 * scale, 0.02):
                 got = c.knn_search(index, 1, q, k, radius)
                 for i in range(len(q)):
@@ -205,5 +205,5 @@ def test_knn_entry_point_against_the_oracle_tree(oracle):
     index = c.target_index(np.zeros((0, 3)), np.zeros((0, 3)))
     assert all(len(x) == 0 for x in c.knn_search(index, 1, rng.normal(size=(5, 3)), 5))  # tests/test_registration.cpp:177-199
     with pytest.raises(capi.LoamxError):
-        c.knn_search(index, 1, np.zeros((1, 3)), 9)
+        c.knn_search(index, 1, np.zeros((1, 3)), 17)
     c.target_index_destroy(index)

@@ -373,6 +373,6 @@ def test_knn_fuzz_every_path_is_exact(oracle, seed):
     before = Hc.knn_mismatches()
     for R in (2.0, -1.0, 0.3):
         for q in pts[rng.integers(0, len(pts), 60)] + rng.normal(size=(60, 3)) * 0.05:
-            for k in (5, 8):
+            for k in (5, 8, 13):
                 assert np.array_equal(oracle.knn_bruteforce(pts, q, k, R), Hc.knn(pts, q, k, R)), (seed, R, k)
     assert Hc.knn_mismatches() == before
