@@ -361,7 +361,7 @@ def test_association_fuzz_against_the_oracle(oracle, seed):
         else:  # lattice with three different spacings: rows of equidistant neighbours, cells filled evenly. (With ONE
             # spacing the five neighbours of an edge point form a cross whose covariance has two equal eigenvalues
             # and off-diagonals of rounding noise: "the" direction of the line is then decided by that noise — in
-            # Eigen by the order its reductions add in — and no restatement can be held to it, DESIGN.md §7.)
+            # Eigen by the order its reductions add in — and no restatement can be held to it, DESIGN.md §2.3.)
             g = int(round(n ** (1 / 3))) + 1
             pts = np.stack(np.meshgrid(np.arange(g) * 0.25, np.arange(g) * 0.27, np.arange(g) * 0.31), -1).reshape(-1, 3)[:n]
         return np.ascontiguousarray(pts + rng.normal(size=3))

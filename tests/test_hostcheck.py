@@ -169,7 +169,7 @@ def test_keyed_knn_ties_and_radius_edges(oracle):
     g = np.arange(-3, 4, dtype=np.float64)
     lattice = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
     before = Hc.knn_fallbacks()  # (exact ties: the grid orders by (d2, index) like the brute-force oracle; nanoflann's
-    # tie order depends on its traversal - DESIGN.md "tie policy")
+    # tie order depends on its traversal - DESIGN.md §2.3)
     for q in ([0, 0, 0], [1, -1, 2], [0.5, 0.5, 0.5], [0.25, 0, 0], [3, 3, 3], [10, 0, 0]):
         for k in (1, 5, 8):
             for R in (-1.0, 1.0, 1.5, 2.0):  # R = 1.0: the 6 face neighbours sit exactly ON the (strict) radius
