@@ -799,7 +799,7 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_kn
 // Second pass of the k-NN: the queries round 1 could not finish (sparse regions where the 3x3x3 block
 // does not hold k points close enough, queries outside the grid, undecided keys) were queued per
 // pair; here the keyed collector searches them over all rounds, on wavefronts that are dense again.
-// What the keys still cannot decide is queued once more, for associate_knn_exact_kernel.
+// What the keys still cannot decide is listed once more (exact[]) and searched exactly by associate_fit_queued_kernel.
 // Workgroups of pairs with an empty queue leave after one scalar load.
 #ifndef LOAMX_REST_THREADS
 #define LOAMX_REST_THREADS 64
@@ -860,22 +860,15 @@ __global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_
 }
 
 // Third pass: the queries whose keys stayed undecided (exact distance ties, a truncated distance
-// straddling the radius) are searched with the exact (d2, index) collector.
+// straddling the radius) are searched with the exact (d2, index) collector — by the thread that fits them, at the
+// head of associate_fit_queued_kernel. (It was a kernel of its own between the two until round 3: its 256-thread
+// workgroups found no room next to the plane fit kernel and so it ENDED with that kernel, whatever little it had to
+// do — 8 us of work, 260-490 us in the trace — and the queued fit started only then.)
 template <bool PLANE, int KM>
-__global__ __launch_bounds__(kAssocThreads) void associate_knn_exact_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
-  size_t pair;
-  uint32_t chunk0;
-  if (!xcd_pair_map(blockIdx.x, blocks_per_pair, B.n_pairs, pair, chunk0)) return;
-  const PairState& S = B.state[pair];
-  if (!S.active) return;                                              // uniform per workgroup
-  const uint32_t queued = B.assoc.n_assoc[8 * pair + (PLANE ? 5 : 4)];
-  if (queued == 0u) return;                                           // uniform per workgroup
-  __shared__ uint32_t s_rows[18 * kAssocThreads];
+__device__ __forceinline__ void knn_exact_one(const RegBatch& B, const RegConfig& C, const PairState& S, size_t pair, uint32_t i,
+                                              size_t slot, uint32_t* rnn, uint32_t* s_rows, int rows_stride) {
   const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
   const size_t field = B.n_pairs * stride;
-  uint32_t* __restrict__ rnn = PLANE ? B.assoc.rnn_plane : B.assoc.rnn_edge;
-  const uint32_t* __restrict__ rest = (PLANE ? B.assoc.rest_plane : B.assoc.rest_edge) + pair * stride;
-  const uint32_t* __restrict__ exact = (PLANE ? B.assoc.exact_plane : B.assoc.exact_edge) + pair * stride;
   const GridSet& gs = PLANE ? B.grid_plane : B.grid_edge;
   const GridSet& src_gs = PLANE ? B.src_grid_plane : B.src_grid_edge;
   const GridDesc g = gs.desc[pair];
@@ -883,18 +876,15 @@ __global__ __launch_bounds__(kAssocThreads) void associate_knn_exact_kernel(RegB
   const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
   int k = PLANE ? C.k_plane : C.k_edge;
   k = k < KM ? k : KM;
-  for (uint32_t t = chunk0 * kAssocThreads + threadIdx.x; t < queued; t += blocks_per_pair * kAssocThreads) {
-    const uint32_t qpos = exact[t], i = rest[qpos] & 0x7FFFFFFFu;
-    const size_t slot = pair * stride + qpos;
-    const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
-    const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));
-    KnnResult<KM> r;
-    const int kept = knn_search(g, cs, sp, p, k, PLANE ? C.r_plane : C.r_edge, r, s_rows + threadIdx.x, kAssocThreads);
-    rnn[slot] = (uint32_t)kept;
+  const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
+  const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));
+  KnnResult<KM> r;
+  const int kept = knn_search(g, cs, sp, p, k, PLANE ? C.r_plane : C.r_edge, r, s_rows, rows_stride);
+  uint32_t pos[KM];
+  knn_shift_positions<KM>(r.pos, k, pos);  // neighbour j is slot (KM - k) + j
+  rnn[slot] = (uint32_t)kept;
 #pragma unroll
-    for (int j = 0; j < KM; j++)
-      if (j < k) rnn[(size_t)(1 + (KM - k) + j) * field + slot] = r.pos[j];
-  }
+  for (int j = 0; j < KM; j++) rnn[(size_t)(1 + j) * field + slot] = pos[j];
 }
 
 // fitLine / fitPlane on the neighbours of query i of `pair` and its association record; the neighbour
@@ -983,8 +973,8 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_FIT_WAVES) void associate_fit_
   }
 }
 
-// The queued queries, after associate_knn_rest_kernel / associate_knn_exact_kernel: same fit, results
-// read by queue position.
+// The queued queries, after associate_knn_rest_kernel: what its keys left undecided is searched exactly first, then the
+// same fit, results read by queue position.
 template <bool PLANE, int KM>
 __global__ __launch_bounds__(kRestThreads) void associate_fit_queued_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
   size_t pair;
@@ -994,12 +984,17 @@ __global__ __launch_bounds__(kRestThreads) void associate_fit_queued_kernel(RegB
   if (!S.active) return;                                              // uniform per workgroup
   const uint32_t queued = B.assoc.n_assoc[8 * pair + (PLANE ? 3 : 2)];
   if (queued == 0u) return;                                           // uniform per workgroup
+  __shared__ uint32_t s_rows[18 * kRestThreads];
   const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
-  const uint32_t* __restrict__ rnn = PLANE ? B.assoc.rnn_plane : B.assoc.rnn_edge;
+  uint32_t* rnn = PLANE ? B.assoc.rnn_plane : B.assoc.rnn_edge;  // (written and read back here: no __restrict__)
   const uint32_t* __restrict__ rest = (PLANE ? B.assoc.rest_plane : B.assoc.rest_edge) + pair * stride;
   uint32_t count = 0;
-  for (uint32_t t = chunk0 * kRestThreads + threadIdx.x; t < queued; t += blocks_per_pair * kRestThreads)
-    count += fit_one<PLANE, KM, true>(B, C, S, pair, rest[t] & 0x7FFFFFFFu, rnn, pair * stride + t) ? 1u : 0u;
+  for (uint32_t t = chunk0 * kRestThreads + threadIdx.x; t < queued; t += blocks_per_pair * kRestThreads) {
+    const uint32_t i = rest[t] & 0x7FFFFFFFu;
+    if ((int)rnn[pair * stride + t] < 0)  // (rare: its own stores, read back by the same thread in fit_one)
+      knn_exact_one<PLANE, KM>(B, C, S, pair, i, pair * stride + t, rnn, s_rows + threadIdx.x, kRestThreads);
+    count += fit_one<PLANE, KM, true>(B, C, S, pair, i, rnn, pair * stride + t) ? 1u : 0u;
+  }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) count += __shfl_xor(count, off);
   if ((threadIdx.x & 63) == 0 && count) atomicAdd(&B.assoc.n_assoc[8 * pair + (PLANE ? 1 : 0)], count);
@@ -1845,11 +1840,9 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
                      (st), B, C, (nblk))
 #define LOAMX_ASSOC_B(PL, KMV, nblk, st)                                                                          \
   do {                                                                                                            \
-    const uint32_t rblk_ = rest_blocks(B.n_pairs, (nblk)), xblk_ = (nblk) < 2u ? (nblk) : 2u;                      \
+    const uint32_t rblk_ = rest_blocks(B.n_pairs, (nblk));                                                        \
     launch_kernel((associate_knn_rest_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * rblk_)),           \
                        dim3(kRestThreads), 0, (st), B, C, rblk_);                                                 \
-    launch_kernel((associate_knn_exact_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * xblk_)),          \
-                       dim3(kAssocThreads), 0, (st), B, C, xblk_);                                                \
     launch_kernel((associate_fit_queued_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * rblk_)),         \
                        dim3(kRestThreads), 0, (st), B, C, rblk_);                                                 \
   } while (0)
