@@ -1139,12 +1139,13 @@ LOAMX_HD int knn_popcount64(uint64_t v) {
 // What follows the walk of the 3x3x3 block, shared by the lean forms: is the search over (rigorous bound against the
 // distance to the block's faces), then the exact verification of the k selected candidates. The visited list (begin |
 // first batch << 16 per visited range) starts at word `vis_off` of the per-thread list.
-template <int KM>
+template <int KM, int W = 1>
 LOAMX_HD int knn_lean_finish(const GridDesc& g, const GridPoint* __restrict__ sp, Vec3 q, int k, double max_dist, double pass_max,
                              double a, int32_t cx, int32_t cy, int32_t cz, const KnnKeys32<KM>& c, uint64_t started,
                              const uint32_t* row_scratch, int row_stride, int vis_off, uint32_t pos[KM]) {
   constexpr uint32_t imask = 0xFFu;
-  // ---- is the search over after the 3x3x3 block? (same test as knn_done, with the rigorous bound)
+  constexpr int NR = (2 * W + 1) * (2 * W + 1);  // rows of the block (W = 1: the 3x3x3 block, W = 2: 5x5x5)
+  // ---- is the search over after the block of half-width W? (same test as knn_done, with the rigorous bound)
   {
     double guard = kDblMax;
     const double m = 1e-9 * g.h;
@@ -1152,12 +1153,12 @@ LOAMX_HD int knn_lean_finish(const GridDesc& g, const GridPoint* __restrict__ sp
     const double q3[3] = {q.x, q.y, q.z}, o3[3] = {g.ox, g.oy, g.oz};
 #pragma unroll
     for (int ax = 0; ax < 3; ax++) {
-      if (c3[ax] - 1 > 0) {
-        const double d = (q3[ax] - (o3[ax] + (double)(c3[ax] - 1) * g.h)) * (1.0 - 1e-9) - m;
+      if (c3[ax] - W > 0) {
+        const double d = (q3[ax] - (o3[ax] + (double)(c3[ax] - W) * g.h)) * (1.0 - 1e-9) - m;
         guard = d < guard ? d : guard;
       }
-      if (c3[ax] + 1 < n3[ax] - 1) {
-        const double d = ((o3[ax] + (double)(c3[ax] + 2) * g.h) - q3[ax]) * (1.0 - 1e-9) - m;
+      if (c3[ax] + W < n3[ax] - 1) {
+        const double d = ((o3[ax] + (double)(c3[ax] + W + 1) * g.h) - q3[ax]) * (1.0 - 1e-9) - m;
         guard = d < guard ? d : guard;
       }
     }
@@ -1175,7 +1176,7 @@ LOAMX_HD int knn_lean_finish(const GridDesc& g, const GridPoint* __restrict__ sp
   for (int i = 0; i < KM; i++) {
     const uint32_t tb = (c.key[i] & imask) >> 2;
     const int ord = knn_popcount64(started & ((2ull << tb) - 1ull)) - 1;  // the visited row this batch belongs to
-    vrow[i] = row_scratch[(vis_off + (ord < 0 ? 0 : (ord > 8 ? 8 : ord))) * row_stride];
+    vrow[i] = row_scratch[(vis_off + (ord < 0 ? 0 : (ord > NR - 1 ? NR - 1 : ord))) * row_stride];
   }
   GridPoint tp[KM];
 #pragma unroll
@@ -1218,7 +1219,7 @@ LOAMX_HD int knn_lean_finish(const GridDesc& g, const GridPoint* __restrict__ sp
     if (!(t6 > d5 + err)) undecided = true;
   }
   if (undecided) LOAMX_LEAN_REASON(2);
-  return undecided ? -1 : kept;
+  return undecided ? -3 : kept;  // (-3: the keys cannot decide — ties; -1 above: the block does not reach far enough)
 }
 
 // one batch of four candidates in registers (n = 0: none)
@@ -1229,7 +1230,7 @@ struct LeanBatch {
 
 // Half of the pipelined loop's body (trip `tu`): step to the next row if the range is used up, issue the loads of the next
 // batch into `nxt`, run `cur` (loaded one trip ago) through the collector. Returns whether this lane has anything left.
-template <int KM>
+template <int KM, int NR = 9>
 LOAMX_HD bool knn_lean_half_trip(KnnKeys32<KM>& c, LeanBatch& cur, LeanBatch& nxt, uint32_t tu, uint32_t& p, uint32_t& e, int& ri,
                                  int& nv, uint64_t& started, uint32_t& rw, uint32_t& rthr, int nrow, uint32_t* row_scratch,
                                  int row_stride, float qx, float qy, float qz, const float* __restrict__ rel_x,
@@ -1244,8 +1245,8 @@ LOAMX_HD bool knn_lean_half_trip(KnnKeys32<KM>& c, LeanBatch& cur, LeanBatch& nx
   p = take ? (rw & 0xFFFFu) : p, e = take ? (rw >> 16) : e;
   ri += step ? 1 : 0;
   {  // the entry of the row that is next now (used one trip later at the earliest)
-    const int rr = ri < 8 ? ri : 8;
-    rw = row_scratch[rr * row_stride], rthr = row_scratch[(9 + rr) * row_stride];
+    const int rr = ri < NR - 1 ? ri : NR - 1;
+    rw = row_scratch[rr * row_stride], rthr = row_scratch[(NR + rr) * row_stride];
   }
   {  // (unconditionally as well — a lane without a range reads position 0 — so that the wait for `cur` below can be
      // "all but the three loads just issued" on every path)
@@ -1413,6 +1414,108 @@ LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cel
 }
 
 
+/* ------------------------------------------------------------------------------------------------
+ * The same lean search over the 5x5x5 block (round 3): the second chance of a query whose 3x3x3 block did not hold k
+ * points closer than the block's faces — sparse neighbourhoods: ~3 % of the plane queries of the bench workload, which
+ * the FP64 search over all rounds (knn_search_keyed) served at 19 times the cost per query of the first round and a
+ * quarter of the whole association's time. 25 rows of up to five cells, in the order of their squared slab distance;
+ * same collector, same exactness argument (verification against the FP64 points, best rejected key, distance to the
+ * faces of the block that WAS searched), same return contract. Per-thread list: kLean2RowWords words.
+ * ---------------------------------------------------------------------------------------------- */
+constexpr int kLean2Rows = 25, kLean2RowWords = 2 * kLean2Rows;
+template <int KM>
+LOAMX_HD int knn_lean_round2(const GridDesc& g, const uint32_t* __restrict__ cell_start, const GridPoint* __restrict__ sp,
+                             const float* __restrict__ rel, uint32_t plane, Vec3 q, int k, double max_dist, double pass_max,
+                             uint32_t pos[KM], uint32_t* row_scratch, int row_stride) {
+#pragma unroll
+  for (int j = 0; j < KM; j++) pos[j] = 0;
+  if (g.n_points == 0 || k <= 0) return 0;
+  if (k > KM) k = KM;
+  const int32_t cx = grid_cell_coord(q.x, g.ox, g.inv_h);
+  const int32_t cy = grid_cell_coord(q.y, g.oy, g.inv_h);
+  const int32_t cz = grid_cell_coord(q.z, g.oz, g.inv_h);
+  const int32_t out = grid_outside_distance(g, cx, cy, cz);
+  if (max_dist > 0.0 && out >= 1 && (double)(out - 1) * g.h >= max_dist) return 0;
+  if (out > 2) return -1;
+  const double a = knn_f32_err_unit(g);
+  const double r2 = knn_radius_bound(max_dist);
+  const float qx = (float)(q.x - g.ox), qy = (float)(q.y - g.oy), qz = (float)(q.z - g.oz);
+  const float kDown = 0.99999f, kUp = 1.00001f;
+  float fy2[5], fz2[5];
+#pragma unroll
+  for (int d = 0; d < 5; d++) {
+    const double sy = d == 2 ? 0.0 : slab_dist(q.y, g.oy, g.h, cy + d - 2), sz = d == 2 ? 0.0 : slab_dist(q.z, g.oz, g.h, cz + d - 2);
+    fy2[d] = (float)(sy * sy) * kDown, fz2[d] = (float)(sz * sz) * kDown;
+  }
+  const float fr2 = r2 < 1e37 ? (float)r2 * kUp : 3.0e38f;
+  const float fa2 = (float)(3003.0 * a * a) * kUp;
+  int nrow = 0;
+  {
+    const int32_t xa = cx - 2 < 0 ? 0 : cx - 2, xb = cx + 2 > g.nx - 1 ? g.nx - 1 : cx + 2;
+    // rows in the order of (dy^2 + dz^2): 0, 1 x4, 2 x4, 4 x4, 5 x8, 8 x4; entry = (dy + 2) + 5 (dz + 2)
+    constexpr int kOrder[25] = {12, 7, 11, 13, 17, 6, 8, 16, 18, 2, 10, 14, 22, 1, 3, 5, 9, 15, 19, 21, 23, 0, 4, 20, 24};
+#pragma unroll
+    for (int o0 = 0; o0 < 25; o0 += 5) {  // five rows' table entries in flight at a time
+      uint32_t rb[5], re[5];
+#pragma unroll
+      for (int u = 0; u < 5; u++) {
+        const int j = kOrder[o0 + u];
+        const int32_t iy = cy + (j % 5) - 2, iz = cz + (j / 5) - 2;
+        const bool ok = xa <= xb && iy >= 0 && iy <= g.ny - 1 && iz >= 0 && iz <= g.nz - 1;
+        const uint32_t row = ok ? (uint32_t)((iz * g.ny + iy) * g.nx) : 0u;
+        rb[u] = cell_start_at(cell_start, ok ? row + (uint32_t)xa : 0u);
+        re[u] = cell_start_at(cell_start, ok ? row + (uint32_t)xb + 1u : 0u);
+        if (!ok) rb[u] = re[u] = 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 5; u++) {
+        const int j = kOrder[o0 + u];
+        const float s2 = fy2[j % 5] + fz2[j / 5];
+        const float x = (s2 * 0.99799f - fa2) * kDown;  // (as knn_lean_round1: the row's admissibility as a threshold on the key)
+        const uint32_t thr = x > 0.0f ? (knn_f32_bits(x) & ~0xFFu) : 0u;
+        if (rb[u] < re[u] && s2 <= fr2) {
+          row_scratch[nrow * row_stride] = rb[u] | (re[u] << 16);
+          row_scratch[(kLean2Rows + nrow) * row_stride] = thr;
+          nrow++;
+        }
+      }
+    }
+  }
+  KnnKeys32<KM> c;
+  knn_init(c, k);
+  constexpr uint32_t tmax = 64;
+  const float* __restrict__ rel_x = rel;
+  const float* __restrict__ rel_y = rel + (size_t)plane;
+  const float* __restrict__ rel_z = rel + 2 * (size_t)plane;
+  uint32_t p = 0, e = 0;
+  int ri = 0, nv = 0;
+  uint64_t started = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t keep;
+  asm volatile("v_mov_b32 %0, 0xffffff00" : "=v"(keep));
+#else
+  const uint32_t keep = ~0xFFu;
+#endif
+  LeanBatch b0 = {}, b1 = {};
+  uint32_t rw = row_scratch[0], rthr = row_scratch[kLean2Rows * row_stride];
+  bool more = true;
+  uint32_t t = 0;
+  for (; t < tmax; t += 2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t tu = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+#else
+    const uint32_t tu = t;
+#endif
+    knn_lean_half_trip<KM, kLean2Rows>(c, b0, b1, tu, p, e, ri, nv, started, rw, rthr, nrow, row_scratch, row_stride, qx, qy, qz, rel_x,
+                                       rel_y, rel_z, keep);
+    more = knn_lean_half_trip<KM, kLean2Rows>(c, b1, b0, tu + 1u, p, e, ri, nv, started, rw, rthr, nrow, row_scratch, row_stride, qx, qy,
+                                              qz, rel_x, rel_y, rel_z, keep);
+    if (!more) break;
+  }
+  if (more) return -2;  // more than 63 batches: the FP64 search's business
+  return knn_lean_finish<KM, 2>(g, sp, q, k, max_dist, pass_max, a, cx, cy, cz, c, started, row_scratch, row_stride, 0, pos);
+}
+
 // WIDE = false: 8-bit running numbers (the fast kernel; a query with more than 63 batches is queued);
 // WIDE = true: 10 or 12 bits (the queue kernel tries this before the FP64 search: dense local maps).
 template <int KM, bool WIDE = false>
@@ -1527,12 +1630,74 @@ LOAMX_HD void fit_line(const Vec3 pts[KM], int K, Vec3& a, Vec3& b) {
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * Square roots and divisions of fit_plane. The compiler's FP64 sequences are correctly rounded and long: a division
+ * is v_div_scale x2, v_rcp (quarter rate) + two Newton steps, quotient, remainder, v_div_fmas, v_div_fixup = 11
+ * instructions; a square root 17, of which 7 only rescale tiny arguments and patch 0 / inf. They were 55 % of the
+ * issue slots of associate_fit_kernel. FAST = the very same sequences with
+ *   - the steps that depend on the divisor alone (refined reciprocal) done once for the divisions that share it,
+ *   - the scaling / special-case steps left out, which is the identity when every operand is a normal number of
+ *     moderate exponent: that is CHECKED per operand (`ok`), and a fit that fails one check anywhere is redone with
+ *     the plain operators (fit_plane below). Results are bit-identical to the plain operators either way
+ *     (tests/test_gpu_direct.py compares the kernels with the g++ build of this header bit for bit).
+ * Host builds only have the plain operators.
+ * ---------------------------------------------------------------------------------------------- */
+struct SharedDivisor {
+  double y, r;  // divisor, refined reciprocal (FAST) — or just the divisor
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+LOAMX_HD bool fast_range(double x) {  // 2^-300 < |x| < 2^300: v_div_scale would leave both operands alone, no step under- / overflows
+  const double a = fabs(x);
+  return a > 4.909093465297727e-91 && a < 2.037035976334486e+90;
+}
+template <bool FAST>
+LOAMX_HD double fit_sqrt(double x, bool& ok) {
+  if (!FAST) return sqrt(x);
+  ok = ok && x > 1.9010815379079637e-211 && x < 1.0715086071862673e+301;  // (2^-700, 2^1000): no rescaling, not 0 / inf / nan
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = y * 0.5;
+  const double e = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, e, g);
+  h = __builtin_fma(h, e, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
+}
+template <bool FAST>
+LOAMX_HD SharedDivisor fit_divisor(double y, bool& ok) {
+  if (!FAST) return SharedDivisor{y, 0.0};
+  ok = ok && fast_range(y);
+  double r = __builtin_amdgcn_rcp(y);
+  double e = __builtin_fma(-y, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-y, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return SharedDivisor{y, r};
+}
+template <bool FAST>
+LOAMX_HD double fit_div(double x, const SharedDivisor& s, bool& ok) {
+  if (!FAST) return x / s.y;
+  ok = ok && fast_range(x);  // (a zero numerator too: the remainder step would lose the sign of a -0 quotient)
+  const double q = x * s.r;
+  const double rem = __builtin_fma(-s.y, q, x);
+  return __builtin_fma(rem, s.r, q);
+}
+#else
+template <bool FAST>
+LOAMX_HD double fit_sqrt(double x, bool&) { return sqrt(x); }
+template <bool FAST>
+LOAMX_HD SharedDivisor fit_divisor(double y, bool&) { return SharedDivisor{y, 0.0}; }
+template <bool FAST>
+LOAMX_HD double fit_div(double x, const SharedDivisor& s, bool&) { return x / s.y; }
+#endif
+
+/* ------------------------------------------------------------------------------------------------
  * fitPlane (geometry.cpp:62-73): least squares P * abc = 1 by column-pivoted Householder QR
  * (Eigen ColPivHouseholderQR semantics incl. its near-zero pivot cut-off), n = abc/|abc|,
  * d = 1/|abc|, returns the signed mean of P n - d.
  * ---------------------------------------------------------------------------------------------- */
-template <int KM>
-LOAMX_HD double fit_plane(const Vec3 pts[KM], int K, Vec3& normal, double& d_out) {
+template <int KM, bool FAST>
+LOAMX_HD double fit_plane_impl(const Vec3 pts[KM], int K, Vec3& normal, double& d_out, bool& ok) {
   double c0[KM], c1[KM], c2[KM];  // columns of the K x 3 matrix
 #pragma unroll
   for (int r = 0; r < KM; r++) {
@@ -1543,7 +1708,7 @@ LOAMX_HD double fit_plane(const Vec3 pts[KM], int K, Vec3& normal, double& d_out
   double nu0 = 0, nu1 = 0, nu2 = 0;
 #pragma unroll
   for (int r = 0; r < KM; r++) nu0 += c0[r] * c0[r], nu1 += c1[r] * c1[r], nu2 += c2[r] * c2[r];
-  nu0 = sqrt(nu0), nu1 = sqrt(nu1), nu2 = sqrt(nu2);
+  nu0 = fit_sqrt<FAST>(nu0, ok), nu1 = fit_sqrt<FAST>(nu1, ok), nu2 = fit_sqrt<FAST>(nu2, ok);
   double nd0 = nu0, nd1 = nu1, nd2 = nu2;
   double maxn = nu0 > nu1 ? nu0 : nu1;
   maxn = maxn > nu2 ? maxn : nu2;
@@ -1574,10 +1739,11 @@ LOAMX_HD double fit_plane(const Vec3 pts[KM], int K, Vec3& normal, double& d_out
 #pragma unroll
       for (int r = 1; r < KM; r++) c0[r] = 0;
     } else {
-      beta = sqrt(x0 * x0 + tail);
+      beta = fit_sqrt<FAST>(x0 * x0 + tail, ok);
       if (x0 >= 0) beta = -beta;
+      const SharedDivisor dv = fit_divisor<FAST>(x0 - beta, ok);
 #pragma unroll
-      for (int r = 1; r < KM; r++) c0[r] = c0[r] / (x0 - beta);
+      for (int r = 1; r < KM; r++) c0[r] = fit_div<FAST>(c0[r], dv, ok);
       tau0 = (beta - x0) / beta;
     }
     c0[0] = beta;
@@ -1595,28 +1761,28 @@ LOAMX_HD double fit_plane(const Vec3 pts[KM], int K, Vec3& normal, double& d_out
       temp = (1.0 + temp) * (1.0 - temp);
       temp = temp < 0 ? 0 : temp;
       const double ratio = nu1 / nd1;
-      if (temp * ratio * ratio <= downdate_thr) {
-        double s = 0;
+      // (one square root for both outcomes: the compiler evaluated both sides)
+      const bool redo = temp * ratio * ratio <= downdate_thr;
+      double s = 0;
 #pragma unroll
-        for (int r = 1; r < KM; r++) s += c1[r] * c1[r];
-        nd1 = sqrt(s), nu1 = nd1;
-      } else {
-        nu1 *= sqrt(temp);
-      }
+      for (int r = 1; r < KM; r++) s += c1[r] * c1[r];
+      const double sq = fit_sqrt<FAST>(redo ? s : temp, ok);
+      if (redo) nd1 = sq, nu1 = sq;
+      else nu1 *= sq;
     }
     if (nu2 != 0) {
       double temp = fabs(c2[0]) / nu2;
       temp = (1.0 + temp) * (1.0 - temp);
       temp = temp < 0 ? 0 : temp;
       const double ratio = nu2 / nd2;
-      if (temp * ratio * ratio <= downdate_thr) {
-        double s = 0;
+      // (one square root for both outcomes: the compiler evaluated both sides)
+      const bool redo = temp * ratio * ratio <= downdate_thr;
+      double s = 0;
 #pragma unroll
-        for (int r = 1; r < KM; r++) s += c2[r] * c2[r];
-        nd2 = sqrt(s), nu2 = nd2;
-      } else {
-        nu2 *= sqrt(temp);
-      }
+      for (int r = 1; r < KM; r++) s += c2[r] * c2[r];
+      const double sq = fit_sqrt<FAST>(redo ? s : temp, ok);
+      if (redo) nd2 = sq, nu2 = sq;
+      else nu2 *= sq;
     }
   }
   // ---- k = 1
@@ -1636,10 +1802,11 @@ LOAMX_HD double fit_plane(const Vec3 pts[KM], int K, Vec3& normal, double& d_out
 #pragma unroll
       for (int r = 2; r < KM; r++) c1[r] = 0;
     } else {
-      beta = sqrt(x0 * x0 + tail);
+      beta = fit_sqrt<FAST>(x0 * x0 + tail, ok);
       if (x0 >= 0) beta = -beta;
+      const SharedDivisor dv = fit_divisor<FAST>(x0 - beta, ok);
 #pragma unroll
-      for (int r = 2; r < KM; r++) c1[r] = c1[r] / (x0 - beta);
+      for (int r = 2; r < KM; r++) c1[r] = fit_div<FAST>(c1[r], dv, ok);
       tau1 = (beta - x0) / beta;
     }
     c1[1] = beta;
@@ -1656,14 +1823,14 @@ LOAMX_HD double fit_plane(const Vec3 pts[KM], int K, Vec3& normal, double& d_out
       temp = (1.0 + temp) * (1.0 - temp);
       temp = temp < 0 ? 0 : temp;
       const double ratio = nu2 / nd2;
-      if (temp * ratio * ratio <= downdate_thr) {
-        double s = 0;
+      // (one square root for both outcomes: the compiler evaluated both sides)
+      const bool redo = temp * ratio * ratio <= downdate_thr;
+      double s = 0;
 #pragma unroll
-        for (int r = 2; r < KM; r++) s += c2[r] * c2[r];
-        nd2 = sqrt(s), nu2 = nd2;
-      } else {
-        nu2 *= sqrt(temp);
-      }
+      for (int r = 2; r < KM; r++) s += c2[r] * c2[r];
+      const double sq = fit_sqrt<FAST>(redo ? s : temp, ok);
+      if (redo) nd2 = sq, nu2 = sq;
+      else nu2 *= sq;
     }
   }
   // ---- k = 2
@@ -1679,10 +1846,11 @@ LOAMX_HD double fit_plane(const Vec3 pts[KM], int K, Vec3& normal, double& d_out
 #pragma unroll
       for (int r = 3; r < KM; r++) c2[r] = 0;
     } else {
-      beta = sqrt(x0 * x0 + tail);
+      beta = fit_sqrt<FAST>(x0 * x0 + tail, ok);
       if (x0 >= 0) beta = -beta;
+      const SharedDivisor dv = fit_divisor<FAST>(x0 - beta, ok);
 #pragma unroll
-      for (int r = 3; r < KM; r++) c2[r] = c2[r] / (x0 - beta);
+      for (int r = 3; r < KM; r++) c2[r] = fit_div<FAST>(c2[r], dv, ok);
       tau2 = (beta - x0) / beta;
     }
     c2[2] = beta;
@@ -1732,14 +1900,28 @@ LOAMX_HD double fit_plane(const Vec3 pts[KM], int K, Vec3& normal, double& d_out
     if (p1 == j) abc[j] = y1;
     if (p2 == j) abc[j] = y2;
   }
-  const double n = sqrt(abc[0] * abc[0] + abc[1] * abc[1] + abc[2] * abc[2]);
-  normal = v3(abc[0] / n, abc[1] / n, abc[2] / n);
-  d_out = 1.0 / n;
+  const double n = fit_sqrt<FAST>(abc[0] * abc[0] + abc[1] * abc[1] + abc[2] * abc[2], ok);
+  const SharedDivisor dn = fit_divisor<FAST>(n, ok);
+  normal = v3(fit_div<FAST>(abc[0], dn, ok), fit_div<FAST>(abc[1], dn, ok), fit_div<FAST>(abc[2], dn, ok));
+  d_out = fit_div<FAST>(1.0, dn, ok);
   double sum = 0;
 #pragma unroll
   for (int r = 0; r < KM; r++)
     if (r < K) sum += (pts[r].x * normal.x + pts[r].y * normal.y + pts[r].z * normal.z) - d_out;
   return sum / (double)K;
+}
+
+template <int KM>
+LOAMX_HD double fit_plane(const Vec3 pts[KM], int K, Vec3& normal, double& d_out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (K == KM) {  // (zero-padded rows are zero numerators: those sets take the plain operators directly)
+    bool ok = true;
+    const double avg = fit_plane_impl<KM, true>(pts, K, normal, d_out, ok);
+    if (ok) return avg;
+  }
+#endif
+  bool unused = true;
+  return fit_plane_impl<KM, false>(pts, K, normal, d_out, unused);
 }
 
 /* ------------------------------------------------------------------------------------------------

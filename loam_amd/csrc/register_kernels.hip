@@ -1644,7 +1644,10 @@ __global__ __launch_bounds__(256) void assoc_dump_kernel(RegBatch B, RegConfig C
 void launch_fit_sets(bool plane, const double* d_pts, size_t n_sets, int k, double* d_prim, double* d_aux, hipStream_t s) {
   if (n_sets == 0) return;
   const dim3 grid((unsigned)((n_sets + 63) / 64));
-  if (k <= 8) {
+  if (k <= 5) {  // (the instantiation the association kernels use for the reference's default of 5 neighbours)
+    if (plane) launch_kernel((fit_sets_kernel<true, 5>), grid, dim3(64), 0, s, d_pts, n_sets, k, d_prim, d_aux);
+    else launch_kernel((fit_sets_kernel<false, 5>), grid, dim3(64), 0, s, d_pts, n_sets, k, d_prim, d_aux);
+  } else if (k <= 8) {
     if (plane) launch_kernel((fit_sets_kernel<true, 8>), grid, dim3(64), 0, s, d_pts, n_sets, k, d_prim, d_aux);
     else launch_kernel((fit_sets_kernel<false, 8>), grid, dim3(64), 0, s, d_pts, n_sets, k, d_prim, d_aux);
   } else {

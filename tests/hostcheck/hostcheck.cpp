@@ -383,21 +383,26 @@ extern "C++" {
 // Runs the keyed fast path (what the kernels run) and the exact collector on the same query and
 // requires identical answers; returns the answer. g_knn_fallbacks counts undecided keyed queries.
 static uint64_t g_plane_streams = 0;
-static uint64_t g_knn_fallbacks = 0, g_knn_mismatch = 0, g_knn_queued = 0;
+static uint64_t g_knn_fallbacks = 0, g_knn_mismatch = 0, g_knn_queued = 0, g_knn_round2 = 0;
 template <int KM>
 static int knn_both(const HostGrid& G, Vec3 q, int k, double max_dist, uint32_t pos[KM]) {
-  uint32_t rows[kLeanRowWords], fb = 0;
+  uint32_t rows[kLean2RowWords], fb = 0;
   // as the kernels do: round-1-only keyed search; what it cannot finish goes to the complete search
   const double pass_max = knn_radius_pass_max(max_dist);
   int kept = knn_search_f32_round1<KM>(G.g, G.cell_start.data(), G.sp.data(), G.rel.data(), (uint32_t)G.sp.size(), q, k, max_dist,
                                        pass_max, pos, rows, 1);
   if (kept < 0) {
     g_knn_queued++;
-    // the queue kernel: a query that only ran out of 8-bit running numbers retries the FP32 pre-selection with
-    // wide ones; then the complete FP64 search
+    // the queue kernel (associate_knn_rest_kernel): a query that only ran out of 8-bit running numbers retries the FP32
+    // pre-selection with wide ones, any other one the lean FP32 search of the 5x5x5 block; then the complete FP64 search
     if (kept == -2)
       kept = knn_search_f32_round1<KM, true>(G.g, G.cell_start.data(), G.sp.data(), G.rel.data(), (uint32_t)G.sp.size(), q, k,
                                              max_dist, pass_max, pos, rows, 1);
+    else if (G.g.n_points <= kLeanMaxPoints) {
+      kept = knn_lean_round2<KM>(G.g, G.cell_start.data(), G.sp.data(), G.rel.data(), (uint32_t)G.sp.size(), q, k, max_dist, pass_max, pos,
+                                 rows, 1);
+      if (kept >= 0) g_knn_round2++;
+    }
   }
   if (kept < 0) {
     kept = knn_search_positions<KM>(G.g, G.cell_start.data(), G.sp.data(), q, k, max_dist, pass_max, pos, rows, 1, &fb);
@@ -415,6 +420,7 @@ static int knn_both(const HostGrid& G, Vec3 q, int k, double max_dist, uint32_t 
 uint64_t hostcheck_plane_streams(void) { return g_plane_streams; }
 uint64_t hostcheck_knn_fallbacks(void) { return g_knn_fallbacks; }
 uint64_t hostcheck_knn_queued(void) { return g_knn_queued; }
+uint64_t hostcheck_knn_round2(void) { return g_knn_round2; }  // queued queries the lean 5x5x5 search finished
 uint64_t hostcheck_knn_mismatches(void) { return g_knn_mismatch; }
 
 uint64_t hostcheck_knn(const double* pts, uint64_t n, const double q[3], uint64_t k, double max_dist, uint64_t* idx_out) {
@@ -438,7 +444,7 @@ void hostcheck_knn_stats(const double* pts, uint64_t n, const double* queries, u
   grid_out[0] = G.g.nx, grid_out[1] = G.g.ny, grid_out[2] = G.g.nz, grid_out[3] = G.g.h;
   const double pass = knn_radius_pass_max(max_dist);
   for (uint64_t i = 0; i < nq; i++) {
-    uint32_t rows[kLeanRowWords], pos[8];
+    uint32_t rows[kLean2RowWords], pos[8];
     g_cand = g_rows = g_general = 0;
     const Vec3 q = v3(queries[3 * i], queries[3 * i + 1], queries[3 * i + 2]);
     if (k <= 5) knn_search_keyed<5>(G.g, G.cell_start.data(), G.sp.data(), q, (int)k, max_dist, pass, pos, rows, 1);
@@ -467,13 +473,31 @@ void hostcheck_lean_stats(const double* pts, uint64_t n, const double* queries, 
   build_grid(pts, (uint32_t)n, max_dist, G);
   const double pass = knn_radius_pass_max(max_dist);
   for (uint64_t i = 0; i < nq; i++) {
-    uint32_t rows[kLeanRowWords], pos[8];
+    uint32_t rows[kLean2RowWords], pos[8];
     g_cand = 0, g_lean_trips = g_lean_nrow = g_lean_taken = g_lean_reason = 0;
     const Vec3 q = v3(queries[3 * i], queries[3 * i + 1], queries[3 * i + 2]);
     const int r = knn_search_f32_round1<5>(G.g, G.cell_start.data(), G.sp.data(), G.rel.data(), (uint32_t)G.sp.size(), q, (int)k,
                                            max_dist, pass, pos, rows, 1);
     out[5 * i] = g_lean_trips, out[5 * i + 1] = g_lean_nrow, out[5 * i + 2] = g_lean_taken, out[5 * i + 3] = (uint32_t)g_cand;
     out[5 * i + 4] = (uint32_t)(r + 2) | (g_lean_reason << 8);
+  }
+}
+
+// the queue's FP32 pass per query (analysis): out[i] = return value + 2 of knn_lean_round2 for the queries round 1 hands on
+// with -1 (0xFF: round 1 finished the query, or handed it on as "too many batches")
+void hostcheck_lean2_stats(const double* pts, uint64_t n, const double* queries, uint64_t nq, uint64_t k, double max_dist, uint32_t* out) {
+  HostGrid G;
+  build_grid(pts, (uint32_t)n, max_dist, G);
+  const double pass = knn_radius_pass_max(max_dist);
+  for (uint64_t i = 0; i < nq; i++) {
+    uint32_t rows[kLean2RowWords], pos[8];
+    const Vec3 q = v3(queries[3 * i], queries[3 * i + 1], queries[3 * i + 2]);
+    const int r1 = knn_search_f32_round1<5>(G.g, G.cell_start.data(), G.sp.data(), G.rel.data(), (uint32_t)G.sp.size(), q, (int)k, max_dist, pass, pos, rows, 1);
+    out[2 * i] = 0xFFu, out[2 * i + 1] = 0;
+    if (r1 != -1) continue;
+    g_lean_reason = 0;
+    const int r2 = knn_lean_round2<5>(G.g, G.cell_start.data(), G.sp.data(), G.rel.data(), (uint32_t)G.sp.size(), q, (int)k, max_dist, pass, pos, rows, 1);
+    out[2 * i] = (uint32_t)(r2 + 2), out[2 * i + 1] = g_lean_reason;
   }
 }
 

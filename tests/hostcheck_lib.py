@@ -61,6 +61,8 @@ def lib():
         _lib.hostcheck_knn.restype = C.c_uint64
         _lib.hostcheck_knn_fallbacks.restype = C.c_uint64
         _lib.hostcheck_knn_mismatches.restype = C.c_uint64
+        _lib.hostcheck_knn_round2.restype = C.c_uint64
+        _lib.hostcheck_knn_queued.restype = C.c_uint64
         _lib.hostcheck_fit_plane.restype = C.c_double
     return _lib
 
@@ -195,6 +197,11 @@ def synth_pose(seed, pair):
 def knn_fallbacks():
     """keyed-collector queries that were undecided and re-ran through the exact collector (cumulative)"""
     return int(lib().hostcheck_knn_fallbacks())
+
+
+def knn_round2():
+    """queued queries the lean FP32 search of the 5x5x5 block finished / all queued queries so far"""
+    return int(lib().hostcheck_knn_round2()), int(lib().hostcheck_knn_queued())
 
 
 def knn_mismatches():

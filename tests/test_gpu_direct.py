@@ -171,6 +171,40 @@ def test_fit_entry_points_against_the_oracle(oracle):
         ctx().fit_planes(np.zeros((1, 33, 3)))
 
 
+def test_fits_are_bit_identical_to_the_host_build_of_the_same_header():
+    """The kernels' fit_line / fit_plane against the g++ build of the same header (tests/hostcheck), bit for bit: the
+    device's division and square-root sequences — including the reciprocal that divisions by one divisor share in
+    fit_plane — round exactly as IEEE division does. Sets of every scale, near-degenerate and exactly degenerate."""
+    import hostcheck_lib as Hc
+    rng = np.random.default_rng(5)
+    sets = []
+    for k in (3, 4, 5, 7, 8):
+        n = 1500
+        o = rng.normal(size=(n, 1, 3)) * 5
+        u, v = rng.normal(size=(n, 1, 3)), rng.normal(size=(n, 1, 3))
+        flat = o + rng.uniform(-1, 1, (n, k, 1)) * u + rng.uniform(-1, 1, (n, k, 1)) * v + rng.normal(size=(n, k, 3)) * 10.0 ** rng.integers(-9, 0, (n, 1, 1))
+        scale = np.where(rng.random((n, 1, 1)) < 0.2, 10.0 ** rng.integers(-140, 140, (n, 1, 1)), 10.0 ** rng.integers(-3, 4, (n, 1, 1)))
+        pts = flat * scale
+        lattice = np.round(rng.normal(size=(200, k, 3)) * 2) * 0.25 + 2.0   # exact ties, zero columns, collinear sets
+        axis = np.zeros((50, k, 3))
+        axis[:, :, 0] = rng.normal(size=(50, k))                            # rank 1: two zero columns
+        sets.append(np.concatenate([pts, lattice, axis]))
+    for pts in sets:
+        k = pts.shape[1]
+        nrm, d, avg = ctx().fit_planes(pts)
+        a, b, _ = ctx().fit_lines(pts)
+        bad = 0
+        for i in range(len(pts)):
+            hn, hd, havg = Hc.fit_plane(pts[i])
+            got = np.array([*nrm[i], d[i], avg[i]])
+            want = np.array([*hn, hd, havg])
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64)) or (np.isnan(got) == np.isnan(want)).all() and np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)]), (k, i, got, want)
+            ha, hb = Hc.fit_line(pts[i])
+            gl, wl = np.array([*a[i], *b[i]]), np.array([*ha, *hb])
+            bad += not (np.array_equal(gl, wl) or (np.isnan(gl).any() and np.isnan(wl).any()))
+        assert bad == 0, (k, bad)
+
+
 def test_fit_line_entry_point_on_degenerate_lattices(oracle):
     """neighbours on a lattice: covariance exactly diagonal with two EQUAL eigenvalues — "the" direction is the one
     Eigen's selection sort leaves last (oracle symeig3 / reg_math.h fit_line)"""

@@ -376,3 +376,19 @@ def test_knn_fuzz_every_path_is_exact(oracle, seed):
             for k in (5, 8, 13):
                 assert np.array_equal(oracle.knn_bruteforce(pts, q, k, R), Hc.knn(pts, q, k, R)), (seed, R, k)
     assert Hc.knn_mismatches() == before
+
+
+def test_lean_second_round_serves_the_sparse_queries(oracle):
+    """Round 3: a query whose 3x3x3 block does not hold k points closer than its faces (sparse neighbourhood) gets the lean
+    FP32 search of the 5x5x5 block before the FP64 search over all rounds. On a sparse shell nearly every query is such a
+    query: most must be finished by the second lean round, and every answer must be brute force's."""
+    rng = np.random.default_rng(77)
+    d = rng.normal(size=(6000, 3))
+    pts = np.ascontiguousarray(d / np.linalg.norm(d, axis=1, keepdims=True) * 12.0 + rng.normal(size=(6000, 3)) * 0.02)
+    r0, q0 = Hc.knn_round2()
+    before = Hc.knn_mismatches()
+    for q in pts[rng.integers(0, len(pts), 400)] + rng.normal(size=(400, 3)) * 0.05:
+        assert np.array_equal(oracle.knn_bruteforce(pts, q, 5, 2.0), Hc.knn(pts, q, 5, 2.0))
+    r1, q1 = Hc.knn_round2()
+    assert Hc.knn_mismatches() == before
+    assert q1 - q0 > 100 and (r1 - r0) > 0.8 * (q1 - q0), (r1 - r0, q1 - q0)
