@@ -466,7 +466,7 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
   untimed(ctx);
   if (in.n_pairs > 0x7FFFFFFFull / 128) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "too many pairs in one call");
   const size_t np = in.n_pairs, es = in.edge_stride ? in.edge_stride : 1, ps = in.planar_stride ? in.planar_stride : 1;
-  if (es > 0x7FFFFFFFull || ps > 0x7FFFFFFFull) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "feature set too large");
+  if (es > 0x3FFFFFFFull || ps > 0x3FFFFFFFull) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "feature set too large");  // (queue entries: 30-bit query index + 2 flags)
   RegBatch B{};
   B.n_pairs = np, B.edge_stride = es, B.planar_stride = ps, B.in_pitch = in.in_pitch;
   B.src_edge = in.src_edge, B.n_src_edge = in.n_src_edge, B.src_planar = in.src_planar, B.n_src_planar = in.n_src_planar;
@@ -727,8 +727,10 @@ int loamx_ctx_create(int device, loamx_ctx** out) {
   // optional: without the auxiliary stream the edge and plane association chains simply run in sequence
   // The auxiliary streams carry the small, latency-bound kernels next to the big ones of the main stream. Round 1 gave
   // them the highest priority (their workgroups dispatched as soon as they are ready: association 2.61 -> 2.57 ms then);
-  // with the round-2 kernels it is the other way round (2.12 -> 2.09 ms at normal priority: the plane k-NN kernel is the
-  // critical path and loses less to its neighbours). LOAMX_AUX_HIGH_PRIO=1 restores the old arrangement.
+  // with the round-2 kernels it is the other way round (2.12 -> 2.09 ms at the LOWEST priority — HIP's range here is
+  // least = 1, greatest = -1, the context stream runs at 0: the plane k-NN kernel is the critical path and loses less to
+  // its neighbours). LOAMX_AUX_HIGH_PRIO=1 restores the old arrangement. (Round 3: priority 1 / 0 / -1 for the queue
+  // chain's stream: 2.077 / 2.084 / 2.090 ms.)
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   if (!getenv("LOAMX_NO_AUX_STREAM") &&
@@ -1005,7 +1007,7 @@ static int register_features_impl(loamx_ctx* ctx, const loamx_target_index* inde
     n_te = 0, n_tp = 0;  // the target lives in the index
   }
   const size_t es = n_se > n_te ? n_se : n_te, ps = n_sp > n_tp ? n_sp : n_tp;
-  if (es > 0x7FFFFFFFull || ps > 0x7FFFFFFFull) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "feature set too large");
+  if (es > 0x3FFFFFFFull || ps > 0x3FFFFFFFull) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "feature set too large");  // (queue entries: 30-bit query index + 2 flags)
   hipStream_t s = ctx->stream;
   const size_t esz = (es ? es : 1) * 3 * sizeof(double), psz = (ps ? ps : 1) * 3 * sizeof(double);
   ENSURE(ctx, WS_SRC_E, esz);

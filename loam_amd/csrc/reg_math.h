@@ -1415,18 +1415,37 @@ LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cel
 
 
 /* ------------------------------------------------------------------------------------------------
- * The same lean search over the 5x5x5 block (round 3): the second chance of a query whose 3x3x3 block did not hold k
- * points closer than the block's faces — sparse neighbourhoods: ~3 % of the plane queries of the bench workload, which
- * the FP64 search over all rounds (knn_search_keyed) served at 19 times the cost per query of the first round and a
- * quarter of the whole association's time. 25 rows of up to five cells, in the order of their squared slab distance;
- * same collector, same exactness argument (verification against the FP64 points, best rejected key, distance to the
- * faces of the block that WAS searched), same return contract. Per-thread list: kLean2RowWords words.
+ * The same lean search over a larger block (round 3), half-width W cells: W = 2 (5x5x5) is the second chance of a query
+ * whose 3x3x3 block did not hold k points closer than the block's faces — sparse neighbourhoods: ~3 % of the plane
+ * queries of the bench workload, which the FP64 search over all rounds (knn_search_keyed) served at 19 times the cost
+ * per query of the first round; W = 4 (9x9x9) reaches the search radius itself when the cell edge is a quarter of it,
+ * i.e. it is final for an ISOLATED query, whose shell-by-shell walk was a chain of ~200 dependent look-ups.
+ * (2W+1)^2 rows of up to 2W+1 cells, in the order of their squared slab distance, 2W+1 rows' table entries in flight
+ * at a time; same collector, same exactness argument (verification against the FP64 points, best rejected key,
+ * distance to the faces of the block that WAS searched, or the radius), same return contract: >= 0 done, -1 the block
+ * does not reach far enough, -2 more than 63 batches, -3 tied keys. Per-thread list: 2 (2W+1)^2 words.
  * ---------------------------------------------------------------------------------------------- */
-constexpr int kLean2Rows = 25, kLean2RowWords = 2 * kLean2Rows;
-template <int KM>
-LOAMX_HD int knn_lean_round2(const GridDesc& g, const uint32_t* __restrict__ cell_start, const GridPoint* __restrict__ sp,
-                             const float* __restrict__ rel, uint32_t plane, Vec3 q, int k, double max_dist, double pass_max,
-                             uint32_t pos[KM], uint32_t* row_scratch, int row_stride) {
+template <int W>
+struct LeanRowOrder {  // the rows (dy, dz) of the block, entry = (dy + W) + (2W+1) (dz + W), by dy^2 + dz^2 (stable)
+  static constexpr int D = 2 * W + 1, NR = D * D;
+  int v[NR];
+  static constexpr int key(int j) { return (j % D - W) * (j % D - W) + (j / D - W) * (j / D - W); }
+  constexpr LeanRowOrder() : v() {
+    for (int i = 0; i < NR; i++) v[i] = i;
+    for (int i = 1; i < NR; i++) {
+      const int x = v[i];
+      int j = i - 1;
+      while (j >= 0 && key(v[j]) > key(x)) { v[j + 1] = v[j]; j--; }
+      v[j + 1] = x;
+    }
+  }
+};
+constexpr int kLean2Rows = 25, kLean2RowWords = 2 * kLean2Rows, kLean4Rows = 81, kLean4RowWords = 2 * kLean4Rows;
+template <int KM, int W>
+LOAMX_HD int knn_lean_block(const GridDesc& g, const uint32_t* __restrict__ cell_start, const GridPoint* __restrict__ sp,
+                            const float* __restrict__ rel, uint32_t plane, Vec3 q, int k, double max_dist, double pass_max,
+                            uint32_t pos[KM], uint32_t* row_scratch, int row_stride) {
+  constexpr int D = 2 * W + 1, NR = D * D;
 #pragma unroll
   for (int j = 0; j < KM; j++) pos[j] = 0;
   if (g.n_points == 0 || k <= 0) return 0;
@@ -1436,31 +1455,30 @@ LOAMX_HD int knn_lean_round2(const GridDesc& g, const uint32_t* __restrict__ cel
   const int32_t cz = grid_cell_coord(q.z, g.oz, g.inv_h);
   const int32_t out = grid_outside_distance(g, cx, cy, cz);
   if (max_dist > 0.0 && out >= 1 && (double)(out - 1) * g.h >= max_dist) return 0;
-  if (out > 2) return -1;
+  if (out > W) return -1;
   const double a = knn_f32_err_unit(g);
   const double r2 = knn_radius_bound(max_dist);
   const float qx = (float)(q.x - g.ox), qy = (float)(q.y - g.oy), qz = (float)(q.z - g.oz);
   const float kDown = 0.99999f, kUp = 1.00001f;
-  float fy2[5], fz2[5];
+  float fy2[D], fz2[D];
 #pragma unroll
-  for (int d = 0; d < 5; d++) {
-    const double sy = d == 2 ? 0.0 : slab_dist(q.y, g.oy, g.h, cy + d - 2), sz = d == 2 ? 0.0 : slab_dist(q.z, g.oz, g.h, cz + d - 2);
+  for (int d = 0; d < D; d++) {
+    const double sy = d == W ? 0.0 : slab_dist(q.y, g.oy, g.h, cy + d - W), sz = d == W ? 0.0 : slab_dist(q.z, g.oz, g.h, cz + d - W);
     fy2[d] = (float)(sy * sy) * kDown, fz2[d] = (float)(sz * sz) * kDown;
   }
   const float fr2 = r2 < 1e37 ? (float)r2 * kUp : 3.0e38f;
   const float fa2 = (float)(3003.0 * a * a) * kUp;
   int nrow = 0;
   {
-    const int32_t xa = cx - 2 < 0 ? 0 : cx - 2, xb = cx + 2 > g.nx - 1 ? g.nx - 1 : cx + 2;
-    // rows in the order of (dy^2 + dz^2): 0, 1 x4, 2 x4, 4 x4, 5 x8, 8 x4; entry = (dy + 2) + 5 (dz + 2)
-    constexpr int kOrder[25] = {12, 7, 11, 13, 17, 6, 8, 16, 18, 2, 10, 14, 22, 1, 3, 5, 9, 15, 19, 21, 23, 0, 4, 20, 24};
+    const int32_t xa = cx - W < 0 ? 0 : cx - W, xb = cx + W > g.nx - 1 ? g.nx - 1 : cx + W;
+    constexpr LeanRowOrder<W> order{};  // W = 2: 12, 7, 11, 13, 17, 6, 8, 16, 18, 2, 10, 14, 22, 1, 3, 5, 9, ...
 #pragma unroll
-    for (int o0 = 0; o0 < 25; o0 += 5) {  // five rows' table entries in flight at a time
-      uint32_t rb[5], re[5];
+    for (int o0 = 0; o0 < NR; o0 += D) {  // D rows' table entries in flight at a time
+      uint32_t rb[D], re[D];
 #pragma unroll
-      for (int u = 0; u < 5; u++) {
-        const int j = kOrder[o0 + u];
-        const int32_t iy = cy + (j % 5) - 2, iz = cz + (j / 5) - 2;
+      for (int u = 0; u < D; u++) {
+        const int j = order.v[o0 + u];
+        const int32_t iy = cy + (j % D) - W, iz = cz + (j / D) - W;
         const bool ok = xa <= xb && iy >= 0 && iy <= g.ny - 1 && iz >= 0 && iz <= g.nz - 1;
         const uint32_t row = ok ? (uint32_t)((iz * g.ny + iy) * g.nx) : 0u;
         rb[u] = cell_start_at(cell_start, ok ? row + (uint32_t)xa : 0u);
@@ -1468,14 +1486,14 @@ LOAMX_HD int knn_lean_round2(const GridDesc& g, const uint32_t* __restrict__ cel
         if (!ok) rb[u] = re[u] = 0u;
       }
 #pragma unroll
-      for (int u = 0; u < 5; u++) {
-        const int j = kOrder[o0 + u];
-        const float s2 = fy2[j % 5] + fz2[j / 5];
+      for (int u = 0; u < D; u++) {
+        const int j = order.v[o0 + u];
+        const float s2 = fy2[j % D] + fz2[j / D];
         const float x = (s2 * 0.99799f - fa2) * kDown;  // (as knn_lean_round1: the row's admissibility as a threshold on the key)
         const uint32_t thr = x > 0.0f ? (knn_f32_bits(x) & ~0xFFu) : 0u;
         if (rb[u] < re[u] && s2 <= fr2) {
           row_scratch[nrow * row_stride] = rb[u] | (re[u] << 16);
-          row_scratch[(kLean2Rows + nrow) * row_stride] = thr;
+          row_scratch[(NR + nrow) * row_stride] = thr;
           nrow++;
         }
       }
@@ -1497,7 +1515,7 @@ LOAMX_HD int knn_lean_round2(const GridDesc& g, const uint32_t* __restrict__ cel
   const uint32_t keep = ~0xFFu;
 #endif
   LeanBatch b0 = {}, b1 = {};
-  uint32_t rw = row_scratch[0], rthr = row_scratch[kLean2Rows * row_stride];
+  uint32_t rw = row_scratch[0], rthr = row_scratch[NR * row_stride];
   bool more = true;
   uint32_t t = 0;
   for (; t < tmax; t += 2) {
@@ -1506,14 +1524,20 @@ LOAMX_HD int knn_lean_round2(const GridDesc& g, const uint32_t* __restrict__ cel
 #else
     const uint32_t tu = t;
 #endif
-    knn_lean_half_trip<KM, kLean2Rows>(c, b0, b1, tu, p, e, ri, nv, started, rw, rthr, nrow, row_scratch, row_stride, qx, qy, qz, rel_x,
-                                       rel_y, rel_z, keep);
-    more = knn_lean_half_trip<KM, kLean2Rows>(c, b1, b0, tu + 1u, p, e, ri, nv, started, rw, rthr, nrow, row_scratch, row_stride, qx, qy,
-                                              qz, rel_x, rel_y, rel_z, keep);
+    knn_lean_half_trip<KM, NR>(c, b0, b1, tu, p, e, ri, nv, started, rw, rthr, nrow, row_scratch, row_stride, qx, qy, qz, rel_x, rel_y,
+                               rel_z, keep);
+    more = knn_lean_half_trip<KM, NR>(c, b1, b0, tu + 1u, p, e, ri, nv, started, rw, rthr, nrow, row_scratch, row_stride, qx, qy, qz,
+                                      rel_x, rel_y, rel_z, keep);
     if (!more) break;
   }
   if (more) return -2;  // more than 63 batches: the FP64 search's business
-  return knn_lean_finish<KM, 2>(g, sp, q, k, max_dist, pass_max, a, cx, cy, cz, c, started, row_scratch, row_stride, 0, pos);
+  return knn_lean_finish<KM, W>(g, sp, q, k, max_dist, pass_max, a, cx, cy, cz, c, started, row_scratch, row_stride, 0, pos);
+}
+template <int KM>
+LOAMX_HD int knn_lean_round2(const GridDesc& g, const uint32_t* __restrict__ cell_start, const GridPoint* __restrict__ sp,
+                             const float* __restrict__ rel, uint32_t plane, Vec3 q, int k, double max_dist, double pass_max,
+                             uint32_t pos[KM], uint32_t* row_scratch, int row_stride) {
+  return knn_lean_block<KM, 2>(g, cell_start, sp, rel, plane, q, k, max_dist, pass_max, pos, row_scratch, row_stride);
 }
 
 // WIDE = false: 8-bit running numbers (the fast kernel; a query with more than 63 batches is queued);

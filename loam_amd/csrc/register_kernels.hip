@@ -748,6 +748,9 @@ __global__ __launch_bounds__(kAssocThreads) void associate_knn_brute_kernel(RegB
   for (int j = 0; j < KM; j++) nn[(1 + j) * field + slot] = pos[j];
 }
 
+// entries of the queues rest_*: a query index and why round 1 queued it
+constexpr uint32_t kQueueIndex = 0x3FFFFFFFu, kQueueWide = 0x80000000u, kQueueTied = 0x40000000u;
+
 // Association is split in two kernels so that each runs at its own register budget:
 //   associate_knn_kernel : the latency-bound grid walk; writes the neighbour count and the positions
 //                          (in the cell-sorted target array) of the k nearest, ascending.
@@ -788,18 +791,26 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_kn
   nn[slot] = kept < 0 ? 0xFFFFFFFFu : (uint32_t)kept;
   if (kept < 0) {  // not finished by round 1: queued for associate_knn_rest_kernel
     const uint32_t at = atomicAdd(&B.assoc.n_assoc[8 * pair + (PLANE ? 3 : 2)], 1u);
-    // (bit 31: the query only ran out of 8-bit running numbers — a dense block: the queue kernel retries the
-    // FP32 pre-selection with wide numbers before the FP64 search)
-    (PLANE ? B.assoc.rest_plane : B.assoc.rest_edge)[pair * stride + at] = i | (kept == -2 ? 0x80000000u : 0u);
+    // (bit 31: the query only ran out of 8-bit running numbers — a dense block: the queue kernel retries the FP32
+    // pre-selection with wide numbers; bit 30: its FP32 keys were tied — an ordinary neighbourhood the FP64 keys decide)
+    (PLANE ? B.assoc.rest_plane : B.assoc.rest_edge)[pair * stride + at] = i | (kept == -2 ? kQueueWide : kept == -3 ? kQueueTied : 0u);
   }
 #pragma unroll
   for (int j = 0; j < KM; j++) nn[(1 + j) * field + slot] = pos[j];  // neighbour j is slot (KM - k) + j
 }
 
-// Second pass of the k-NN: the queries round 1 could not finish (sparse regions where the 3x3x3 block
-// does not hold k points close enough, queries outside the grid, undecided keys) were queued per
-// pair; here the keyed collector searches them over all rounds, on wavefronts that are dense again.
-// What the keys still cannot decide is listed once more (exact[]) and searched exactly by associate_fit_queued_kernel.
+// The queue chain. Round 1 queues 1-7 % of the plane queries, nearly all of them because their 3x3x3 block does not hold
+// k points closer than its faces (sparse neighbourhoods). Three kernels of 64-thread workgroups and at most ~100
+// registers, so that their wavefronts find room next to the plane fit kernel, which runs at the same time:
+//   associate_knn_rest_kernel  : the lean FP32 search again, over the 5x5x5 block (or with wide running numbers for the
+//                                queries of dense blocks): finishes 93-98 % of the queue on dense wavefronts. What is
+//                                left — isolated queries, tied FP32 keys, every entry of a map-sized set — is listed.
+//   associate_knn_left_kernel  : the listed ones, compacted (a few hundred wavefronts for a 1 024-pair batch): the FP64
+//                                keyed collector over all rounds. Long walks, few wavefronts: latency the fit kernel hides.
+//   associate_fit_queued_kernel: exact collector for what even the FP64 keys leave undecided, then the fit.
+// (Until round 3 the second kernel's search ran on every wavefront of the first: 50-70 % of them held one or two
+// isolated queries and walked every shell with 27 % of their lanes — 0.3-0.45 ms next to the fit kernel, which it slowed
+// from 0.63 to 0.96 ms.)
 // Workgroups of pairs with an empty queue leave after one scalar load.
 #ifndef LOAMX_REST_THREADS
 #define LOAMX_REST_THREADS 64
@@ -818,12 +829,12 @@ __global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_
   if (!S.active) return;                                              // uniform per workgroup
   const uint32_t queued = B.assoc.n_assoc[8 * pair + (PLANE ? 3 : 2)];
   if (queued == 0u) return;                                           // uniform per workgroup
-  __shared__ uint32_t s_rows[kLeanRowWords * kRestThreads];
+  __shared__ uint32_t s_rows[kLean2RowWords * kRestThreads];  // (the larger of the two per-thread row lists used below)
   const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
   const size_t field = B.n_pairs * stride;
   uint32_t* __restrict__ rnn = PLANE ? B.assoc.rnn_plane : B.assoc.rnn_edge;  // results by queue position
   const uint32_t* __restrict__ rest = (PLANE ? B.assoc.rest_plane : B.assoc.rest_edge) + pair * stride;
-  uint32_t* __restrict__ exact = (PLANE ? B.assoc.exact_plane : B.assoc.exact_edge) + pair * stride;
+  uint32_t* __restrict__ left = (PLANE ? B.assoc.exact_plane : B.assoc.exact_edge) + pair * stride;
   const GridSet& gs = PLANE ? B.grid_plane : B.grid_edge;
   const GridSet& src_gs = PLANE ? B.src_grid_plane : B.src_grid_edge;
   const GridDesc g = gs.desc[pair];
@@ -836,24 +847,68 @@ __global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_
   const bool spread = B.n_pairs < 8 && (size_t)queued * 4 <= (size_t)blocks_per_pair * kRestThreads;
   const uint32_t t0 = spread ? chunk0 + blocks_per_pair * threadIdx.x : chunk0 * kRestThreads + threadIdx.x;
   const uint32_t dt = spread ? 0xFFFFFFFFu - t0 : blocks_per_pair * kRestThreads;  // (spread: one entry per lane)
+  const bool lean_set = g.n_points <= kLeanMaxPoints;  // (uniform: a property of the set; positions travel as 16-bit halves)
+  const int kq = PLANE ? C.k_plane : C.k_edge;
+  const double max_dist = PLANE ? C.r_plane : C.r_edge, pass_max = PLANE ? C.pass_plane : C.pass_edge;
   for (uint32_t t = t0; t < queued; t += dt) {
-    const uint32_t entry = rest[t], i = entry & 0x7FFFFFFFu;
+    const uint32_t entry = rest[t], i = entry & kQueueIndex;
     const size_t slot = pair * stride + t;  // (queue position, not query index)
+    uint32_t pos[KM];
+#pragma unroll
+    for (int j = 0; j < KM; j++) pos[j] = 0;
+    int kept = -1;
+    if (!(entry & kQueueTied) && (lean_set || (entry & kQueueWide))) {
+      const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
+      const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));
+      if (entry & kQueueWide)
+        kept = knn_search_f32_round1<KM, true>(g, cs, sp, gs.rel + pair * 3 * gs.stride, (uint32_t)gs.stride, p, kq, max_dist, pass_max, pos,
+                                                s_rows + threadIdx.x, kRestThreads);
+      else
+        kept = knn_lean_round2<KM>(g, cs, sp, gs.rel + pair * 3 * gs.stride, (uint32_t)gs.stride, p, kq, max_dist, pass_max, pos,
+                                   s_rows + threadIdx.x, kRestThreads);
+    }
+    rnn[slot] = (uint32_t)kept;
+    if (kept < 0) left[atomicAdd(&B.assoc.n_assoc[8 * pair + (PLANE ? 5 : 4)], 1u)] = t;
+#pragma unroll
+    for (int j = 0; j < KM; j++) rnn[(1 + j) * field + slot] = pos[j];
+  }
+}
+
+// The listed queue entries (see above): the FP64 keyed collector — each candidate ONE double, the bits of d2 with the
+// low mantissa bits replaced by the position — over all rounds. What its keys cannot decide keeps its negative count.
+template <bool PLANE, int KM>
+__global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_left_kernel(RegBatch B, RegConfig C,
+                                                                                              uint32_t blocks_per_pair) {
+  size_t pair;
+  uint32_t chunk0;
+  if (!xcd_pair_map(blockIdx.x, blocks_per_pair, B.n_pairs, pair, chunk0)) return;
+  const PairState& S = B.state[pair];
+  if (!S.active) return;                                              // uniform per workgroup
+  const uint32_t listed = B.assoc.n_assoc[8 * pair + (PLANE ? 5 : 4)];
+  if (listed == 0u) return;                                           // uniform per workgroup
+  __shared__ uint32_t s_rows[kLeanRowWords * kRestThreads];
+  const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
+  const size_t field = B.n_pairs * stride;
+  uint32_t* __restrict__ rnn = PLANE ? B.assoc.rnn_plane : B.assoc.rnn_edge;
+  const uint32_t* __restrict__ rest = (PLANE ? B.assoc.rest_plane : B.assoc.rest_edge) + pair * stride;
+  const uint32_t* __restrict__ left = (PLANE ? B.assoc.exact_plane : B.assoc.exact_edge) + pair * stride;
+  const GridSet& gs = PLANE ? B.grid_plane : B.grid_edge;
+  const GridSet& src_gs = PLANE ? B.src_grid_plane : B.src_grid_edge;
+  const GridDesc g = gs.desc[pair];
+  const uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
+  const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
+  const bool spread = B.n_pairs < 8 && (size_t)listed * 4 <= (size_t)blocks_per_pair * kRestThreads;  // (as above)
+  const uint32_t t0 = spread ? chunk0 + blocks_per_pair * threadIdx.x : chunk0 * kRestThreads + threadIdx.x;
+  const uint32_t dt = spread ? 0xFFFFFFFFu - t0 : blocks_per_pair * kRestThreads;
+  for (uint32_t t = t0; t < listed; t += dt) {
+    const uint32_t qpos = left[t], i = rest[qpos] & kQueueIndex;
+    const size_t slot = pair * stride + qpos;
     const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
     const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));
     uint32_t pos[KM];
-    // first the FP32 pre-selection with wide running numbers (queries of dense blocks that ran out of the 8-bit
-    // numbers in the round-1 kernel), then the FP64 keyed collector over all rounds
-    int kept = -1;
-    if (entry & 0x80000000u)
-      kept = knn_search_f32_round1<KM, true>(g, cs, sp, gs.rel + pair * 3 * gs.stride, (uint32_t)gs.stride, p,
-                                              PLANE ? C.k_plane : C.k_edge, PLANE ? C.r_plane : C.r_edge,
-                                              PLANE ? C.pass_plane : C.pass_edge, pos, s_rows + threadIdx.x, kRestThreads);
-    if (kept < 0)
-      kept = knn_search_keyed<KM>(g, cs, sp, p, PLANE ? C.k_plane : C.k_edge, PLANE ? C.r_plane : C.r_edge,
-                                  PLANE ? C.pass_plane : C.pass_edge, pos, s_rows + threadIdx.x, kRestThreads);
+    const int kept = knn_search_keyed<KM>(g, cs, sp, p, PLANE ? C.k_plane : C.k_edge, PLANE ? C.r_plane : C.r_edge,
+                                          PLANE ? C.pass_plane : C.pass_edge, pos, s_rows + threadIdx.x, kRestThreads);
     rnn[slot] = (uint32_t)kept;
-    if (kept < 0) exact[atomicAdd(&B.assoc.n_assoc[8 * pair + (PLANE ? 5 : 4)], 1u)] = t;
 #pragma unroll
     for (int j = 0; j < KM; j++) rnn[(1 + j) * field + slot] = pos[j];
   }
@@ -976,7 +1031,7 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_FIT_WAVES) void associate_fit_
 // The queued queries, after associate_knn_rest_kernel: what its keys left undecided is searched exactly first, then the
 // same fit, results read by queue position.
 template <bool PLANE, int KM>
-__global__ __launch_bounds__(kRestThreads) void associate_fit_queued_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
+__global__ __launch_bounds__(kRestThreads, 4) void associate_fit_queued_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {  // (4: <= 128 registers — it was 230 and waited for two fit wavefronts to leave a SIMD at once)
   size_t pair;
   uint32_t chunk0;
   if (!xcd_pair_map(blockIdx.x, blocks_per_pair, B.n_pairs, pair, chunk0)) return;
@@ -990,7 +1045,7 @@ __global__ __launch_bounds__(kRestThreads) void associate_fit_queued_kernel(RegB
   const uint32_t* __restrict__ rest = (PLANE ? B.assoc.rest_plane : B.assoc.rest_edge) + pair * stride;
   uint32_t count = 0;
   for (uint32_t t = chunk0 * kRestThreads + threadIdx.x; t < queued; t += blocks_per_pair * kRestThreads) {
-    const uint32_t i = rest[t] & 0x7FFFFFFFu;
+    const uint32_t i = rest[t] & kQueueIndex;
     if ((int)rnn[pair * stride + t] < 0)  // (rare: its own stores, read back by the same thread in fit_one)
       knn_exact_one<PLANE, KM>(B, C, S, pair, i, pair * stride + t, rnn, s_rows + threadIdx.x, kRestThreads);
     count += fit_one<PLANE, KM, true>(B, C, S, pair, i, rnn, pair * stride + t) ? 1u : 0u;
@@ -1619,7 +1674,7 @@ __global__ __launch_bounds__(256) void assoc_dump_kernel(RegBatch B, RegConfig C
     i = t, at = t, src = nn;
     if (nn[t] == 0xFFFFFFFFu) return;  // queued: written from the queue's results below
   } else {
-    at = t - n_src, i = rest[at] & 0x7FFFFFFFu, src = rnn;
+    at = t - n_src, i = rest[at] & kQueueIndex, src = rnn;
   }
   const uint32_t orig = src_gs.sorted[i].orig;
   const int kq = PLANE ? C.k_plane : C.k_edge, kk = kq < KM ? kq : KM, shift = KM - kk;
@@ -1845,6 +1900,8 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
   do {                                                                                                            \
     const uint32_t rblk_ = rest_blocks(B.n_pairs, (nblk));                                                        \
     launch_kernel((associate_knn_rest_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * rblk_)),           \
+                       dim3(kRestThreads), 0, (st), B, C, rblk_);                                                 \
+    launch_kernel((associate_knn_left_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * rblk_)),           \
                        dim3(kRestThreads), 0, (st), B, C, rblk_);                                                 \
     launch_kernel((associate_fit_queued_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * rblk_)),         \
                        dim3(kRestThreads), 0, (st), B, C, rblk_);                                                 \

@@ -444,7 +444,7 @@ void hostcheck_knn_stats(const double* pts, uint64_t n, const double* queries, u
   grid_out[0] = G.g.nx, grid_out[1] = G.g.ny, grid_out[2] = G.g.nz, grid_out[3] = G.g.h;
   const double pass = knn_radius_pass_max(max_dist);
   for (uint64_t i = 0; i < nq; i++) {
-    uint32_t rows[kLean2RowWords], pos[8];
+    uint32_t rows[kLean4RowWords], pos[8];
     g_cand = g_rows = g_general = 0;
     const Vec3 q = v3(queries[3 * i], queries[3 * i + 1], queries[3 * i + 2]);
     if (k <= 5) knn_search_keyed<5>(G.g, G.cell_start.data(), G.sp.data(), q, (int)k, max_dist, pass, pos, rows, 1);
@@ -473,7 +473,7 @@ void hostcheck_lean_stats(const double* pts, uint64_t n, const double* queries, 
   build_grid(pts, (uint32_t)n, max_dist, G);
   const double pass = knn_radius_pass_max(max_dist);
   for (uint64_t i = 0; i < nq; i++) {
-    uint32_t rows[kLean2RowWords], pos[8];
+    uint32_t rows[kLean4RowWords], pos[8];
     g_cand = 0, g_lean_trips = g_lean_nrow = g_lean_taken = g_lean_reason = 0;
     const Vec3 q = v3(queries[3 * i], queries[3 * i + 1], queries[3 * i + 2]);
     const int r = knn_search_f32_round1<5>(G.g, G.cell_start.data(), G.sp.data(), G.rel.data(), (uint32_t)G.sp.size(), q, (int)k,
@@ -490,7 +490,7 @@ void hostcheck_lean2_stats(const double* pts, uint64_t n, const double* queries,
   build_grid(pts, (uint32_t)n, max_dist, G);
   const double pass = knn_radius_pass_max(max_dist);
   for (uint64_t i = 0; i < nq; i++) {
-    uint32_t rows[kLean2RowWords], pos[8];
+    uint32_t rows[kLean4RowWords], pos[8];
     const Vec3 q = v3(queries[3 * i], queries[3 * i + 1], queries[3 * i + 2]);
     const int r1 = knn_search_f32_round1<5>(G.g, G.cell_start.data(), G.sp.data(), G.rel.data(), (uint32_t)G.sp.size(), q, (int)k, max_dist, pass, pos, rows, 1);
     out[2 * i] = 0xFFu, out[2 * i + 1] = 0;
@@ -498,6 +498,12 @@ void hostcheck_lean2_stats(const double* pts, uint64_t n, const double* queries,
     g_lean_reason = 0;
     const int r2 = knn_lean_round2<5>(G.g, G.cell_start.data(), G.sp.data(), G.rel.data(), (uint32_t)G.sp.size(), q, (int)k, max_dist, pass, pos, rows, 1);
     out[2 * i] = (uint32_t)(r2 + 2), out[2 * i + 1] = g_lean_reason;
+    if (r2 == -1) {  // (analysis: what the 9x9x9 block then does with it: bits 8.. = its return value + 4, bits 16.. = candidates)
+      g_lean_trips = 0;
+      const int r4 = knn_lean_block<5, 4>(G.g, G.cell_start.data(), G.sp.data(), G.rel.data(), (uint32_t)G.sp.size(), q, (int)k, max_dist, pass, pos, rows, 1);
+      out[2 * i] |= (uint32_t)(r4 + 4) << 8;
+      out[2 * i + 1] |= (uint32_t)g_lean_trips << 8;
+    }
   }
 }
 
