@@ -1006,7 +1006,6 @@ __device__ __forceinline__ bool fit_one(const RegBatch& B, const RegConfig& C, c
 template <bool PLANE, int KM>
 __global__ __launch_bounds__(kAssocThreads, LOAMX_FIT_WAVES) void associate_fit_kernel(RegBatch B, RegConfig C,
                                                                                         uint32_t blocks_per_pair) {
-  __shared__ uint32_t s_count[kAssocThreads / 64];
   size_t pair;
   uint32_t chunk;
   if (!xcd_pair_map(blockIdx.x, blocks_per_pair, B.n_pairs, pair, chunk)) return;
@@ -1018,14 +1017,9 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_FIT_WAVES) void associate_fit_
   const uint32_t* __restrict__ nn = PLANE ? B.assoc.nn_plane : B.assoc.nn_edge;
   bool valid = false;
   if (i < n_src && i < stride) valid = fit_one<PLANE, KM>(B, C, S, pair, i, nn, pair * stride + i);  // (queued queries: skipped inside)
+  // (one atomic per wavefront, no barrier: a wavefront that is done leaves)
   const unsigned long long m = __ballot(valid);
-  if ((threadIdx.x & 63) == 0) s_count[threadIdx.x >> 6] = (uint32_t)__popcll(m);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t c = 0;
-    for (int w = 0; w < kAssocThreads / 64; w++) c += s_count[w];
-    if (c) atomicAdd(&B.assoc.n_assoc[8 * pair + (PLANE ? 1 : 0)], c);
-  }
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&B.assoc.n_assoc[8 * pair + (PLANE ? 1 : 0)], (uint32_t)__popcll(m));
 }
 
 // The queued queries, after associate_knn_rest_kernel: what its keys left undecided is searched exactly first, then the

@@ -8,7 +8,7 @@ V=$ROOT/loam_amd/lib/variants
 if [ "$1" = build ]; then
   mkdir -p "$V"
   cd "$ROOT/loam_amd/csrc"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $3 -o "$V/$2.so" loamx_api.hip extract_kernels.hip register_kernels.hip synth_kernels.hip -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $3 -o "$V/$2.so" loamx_api.hip extract_kernels.hip register_kernels.hip synth_kernels.hip -ldl -Wl,-rpath,/opt/rocm/lib
   echo "built $V/$2.so"
 elif [ "$1" = run ]; then
   pat=$2; shift 2
