@@ -1741,6 +1741,7 @@ LOAMX_HD double fit_plane_impl(const Vec3 pts[KM], int K, Vec3& normal, double& 
   int p0 = 0, p1 = 1, p2 = 2;  // column permutation: physical column j holds original column pj
   int nonzero_pivots = 3;
   double tau0 = 0, tau1 = 0, tau2 = 0;
+  SharedDivisor piv0 = {1.0, 1.0}, piv1 = {1.0, 1.0}, piv2 = {1.0, 1.0};  // the pivots beta_k divide tau_k here and y_k in the back substitution
 
 #define LOAMX_SWAP(a_, b_) { double t_ = a_; a_ = b_; b_ = t_; }
 #define LOAMX_SWAPCOL(ca, cb) { _Pragma("unroll") for (int r_ = 0; r_ < KM; r_++) LOAMX_SWAP(ca[r_], cb[r_]) }
@@ -1768,8 +1769,9 @@ LOAMX_HD double fit_plane_impl(const Vec3 pts[KM], int K, Vec3& normal, double& 
       const SharedDivisor dv = fit_divisor<FAST>(x0 - beta, ok);
 #pragma unroll
       for (int r = 1; r < KM; r++) c0[r] = fit_div<FAST>(c0[r], dv, ok);
-      tau0 = (beta - x0) / beta;
     }
+    piv0 = fit_divisor<FAST>(beta, ok);
+    if (!(tail <= kDblMin)) tau0 = fit_div<FAST>(beta - x0, piv0, ok);
     c0[0] = beta;
     if (tau0 != 0) {
       double t1 = c1[0], t2 = c2[0];
@@ -1831,8 +1833,9 @@ LOAMX_HD double fit_plane_impl(const Vec3 pts[KM], int K, Vec3& normal, double& 
       const SharedDivisor dv = fit_divisor<FAST>(x0 - beta, ok);
 #pragma unroll
       for (int r = 2; r < KM; r++) c1[r] = fit_div<FAST>(c1[r], dv, ok);
-      tau1 = (beta - x0) / beta;
     }
+    piv1 = fit_divisor<FAST>(beta, ok);
+    if (!(tail <= kDblMin)) tau1 = fit_div<FAST>(beta - x0, piv1, ok);
     c1[1] = beta;
     if (tau1 != 0) {
       double t2 = c2[1];
@@ -1875,8 +1878,9 @@ LOAMX_HD double fit_plane_impl(const Vec3 pts[KM], int K, Vec3& normal, double& 
       const SharedDivisor dv = fit_divisor<FAST>(x0 - beta, ok);
 #pragma unroll
       for (int r = 3; r < KM; r++) c2[r] = fit_div<FAST>(c2[r], dv, ok);
-      tau2 = (beta - x0) / beta;
     }
+    piv2 = fit_divisor<FAST>(beta, ok);
+    if (!(tail <= kDblMin)) tau2 = fit_div<FAST>(beta - x0, piv2, ok);
     c2[2] = beta;
   }
 #undef LOAMX_SWAPCOL
@@ -1914,9 +1918,9 @@ LOAMX_HD double fit_plane_impl(const Vec3 pts[KM], int K, Vec3& normal, double& 
   }
   // R = [[c0[0], c1[0], c2[0]], [0, c1[1], c2[1]], [0, 0, c2[2]]]
   double y0 = 0, y1 = 0, y2 = 0;
-  if (nonzero_pivots > 2) y2 = rhs[2] / c2[2];
-  if (nonzero_pivots > 1) y1 = (rhs[1] - c2[1] * y2) / c1[1];
-  if (nonzero_pivots > 0) y0 = (rhs[0] - c1[0] * y1 - c2[0] * y2) / c0[0];
+  if (nonzero_pivots > 2) y2 = fit_div<FAST>(rhs[2], piv2, ok);  // (c2[2] == beta of k = 2, etc.)
+  if (nonzero_pivots > 1) y1 = fit_div<FAST>(rhs[1] - c2[1] * y2, piv1, ok);
+  if (nonzero_pivots > 0) y0 = fit_div<FAST>(rhs[0] - c1[0] * y1 - c2[0] * y2, piv0, ok);
   double abc[3] = {0, 0, 0};
 #pragma unroll
   for (int j = 0; j < 3; j++) {
