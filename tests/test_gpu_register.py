@@ -389,11 +389,12 @@ def test_association_fuzz_against_the_oracle(oracle, seed):
             assert np.array_equal(pairs[:, 0], np.nonzero(valid)[0]), (seed, key)
             assert np.array_equal(pairs[:, 1], nearest[valid]), (seed, key)
     if io:
-        # the first ICF iteration starts from identical state: its update is the well-posed comparison (some of these
-        # scenes are ill-conditioned — three random planes and a few lattice edges — and a registration that runs into
-        # MAX_ITER there amplifies 1e-11 to 1e-4 through a single accept / reject decision, in either implementation)
-        rot, trans = pose_diff(oracle, np.array(list(oinfo[0].update)), det["iterations"][0]["estimate_update"])
-        assert rot < 1e-7 and trans < 1e-7, (seed, rot, trans)
-        if to == capi.CONVERGED:
-            rot, trans = pose_diff(oracle, po, pg)
-            assert rot < SE3_TOL and trans < SE3_TOL, (seed, rot, trans)
+        # every ICF iteration's update and the final pose, whatever the termination type (13 of the 80 scenes run into
+        # MAX_ITER, one ends with too few associations: GPU and oracle stay within 5e-15 m of each other there too, the
+        # worst single update differs by 3e-12 — measured in round 3; rounds 1-2 compared the first update only)
+        assert len(oinfo) == len(det["iterations"])
+        for i in range(len(oinfo)):
+            rot, trans = pose_diff(oracle, np.array(list(oinfo[i].update)), det["iterations"][i]["estimate_update"])
+            assert rot < 1e-7 and trans < 1e-7, (seed, i, rot, trans)
+        rot, trans = pose_diff(oracle, po, pg)
+        assert rot < SE3_TOL and trans < SE3_TOL, (seed, to, rot, trans)

@@ -51,9 +51,8 @@ def test_batches_of_other_shapes_twice_and_against_the_oracle(oracle, H, W, P, f
     eb, pb = oracle.extract_features(B, H, W, 1.0, 120.0, ofe)
     po, to, io = oracle.register_features(B[eb], B[pb], A[ea], A[pa], None, oreg)
     assert (res[pr]["termination"], res[pr]["iterations"]) == (to, io)
-    if to == capi.CONVERGED:
-        rot, trans = pose_diff(oracle, po, res[pr]["pose"])
-        assert rot < 1e-5 and trans < 1e-5, (rot, trans)
+    rot, trans = pose_diff(oracle, po, res[pr]["pose"])  # (whatever the termination type)
+    assert rot < 1e-5 and trans < 1e-5, (to, rot, trans)
 
 
 def _scene(rng, n_e, n_p):
@@ -119,6 +118,5 @@ def test_ragged_batch_equals_single_pair_calls(oracle):
         oreg.min_associations = 20
         po, to, io = oracle.register_features(*scenes[p], None, oreg)
         assert (res[p]["termination"], res[p]["iterations"]) == (to, io), p
-        if to == capi.CONVERGED:
-            rot, trans = pose_diff(oracle, po, res[p]["pose"])
-            assert rot < 1e-5 and trans < 1e-5, (p, rot, trans)
+        rot, trans = pose_diff(oracle, po, res[p]["pose"])  # (whatever the termination type)
+        assert rot < 1e-5 and trans < 1e-5, (p, to, rot, trans)

@@ -6,7 +6,10 @@ end, duration (us), queue and kernel of every dispatch, and the idle gaps of the
 """
 import csv, glob, re, sys
 d, sub = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "trace")
-rows = list(csv.DictReader(open(glob.glob(d + "/" + sub + "/*/*_kernel_trace.csv")[0])))
+files = glob.glob(d + "/" + sub + "/*/*_kernel_trace.csv")
+if len(files) != 1:
+    sys.exit("step_timeline: %d traces under %s/%s (remove the directory before profiling into it again)" % (len(files), d, sub))
+rows = list(csv.DictReader(open(files[0])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if "curvature" in r["Kernel_Name"]]
 seg = rows[starts[-1]:]

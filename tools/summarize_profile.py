@@ -12,10 +12,20 @@ curvature_valid_kernel, whose read volume is known: 24 B/point), WRITE_SIZE is e
 import collections
 import csv
 import glob
+
 import json
 import os
 import re
 import sys
+
+
+def one_pass(pattern):
+    """the ONE output file of a rocprofv3 pass: gpurun merges a call's files into what is already under gpurun_out/, so a
+    directory that was profiled twice holds both runs' files (named by process id) — summarising a mix is worse than failing"""
+    files = glob.glob(pattern)
+    if len(files) > 1:
+        sys.exit("summarize_profile: %d files match %s — remove the directory before profiling into it again" % (len(files), pattern))
+    return files
 
 
 def source_hash():
@@ -45,7 +55,7 @@ def main():
     for sub, log, title in (("trace", "bench_under_rocprof.log", "`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline`"),
                             ("trace_seq", "bench_under_rocprof_seq.log", "the same with `LOAMX_NO_AUX_STREAM=1` (association chains in sequence on one stream: "
                              "per-kernel durations without the inflation that concurrent kernels report)")):
-        stats = glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
+        stats = one_pass(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
         if not stats:
             continue
         rows = list(csv.DictReader(open(stats[0])))
@@ -70,7 +80,7 @@ def main():
         md.append("")
     pmc = {}
     for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-        files = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
+        files = one_pass(os.path.join(src, sub, "*", "*_counter_collection.csv"))
         if not files:
             continue
         agg = collections.defaultdict(lambda: [0, 0.0])
@@ -118,8 +128,10 @@ def main():
         json.dump(pmc_json, open(dst + "_pmc.json", "w"), indent=1)
     # any further counter passes (pmc_x*): per-kernel average per dispatch
     extra = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
-    for f in sorted(glob.glob(os.path.join(src, "pmc_x*", "*", "*_counter_collection.csv"))):
-        for r in csv.DictReader(open(f)):
+    for d in sorted(glob.glob(os.path.join(src, "pmc_x*"))):
+        if not os.path.isdir(d):
+            continue
+        for r in csv.DictReader(open(one_pass(os.path.join(d, "*", "*_counter_collection.csv"))[0])):
             a = extra[short(r["Kernel_Name"])][r["Counter_Name"]]
             a[0] += 1
             a[1] += float(r["Counter_Value"])
