@@ -110,6 +110,8 @@ constexpr uint32_t kRegFlagNoPackedGrid = 2u;  // scan-sized sets through the si
 constexpr uint32_t kRegFlagNoBigGrid = 4u;     // map-sized sets through the single-workgroup build as well
 constexpr uint32_t kRegFlagNoGridSide = 8u;    // source index builds behind the target builds on the context stream
 constexpr uint32_t kRegFlagPoison = 16u;       // registration scratch starts as 0xFF bytes
+constexpr uint32_t kRegFlagQueueTwoStage = 32u;  // queue chain: always lean 5x5x5 search + listed leftovers (launch_associate)
+constexpr uint32_t kRegFlagQueueOneStage = 64u;  // queue chain: always the FP64 search over all rounds in one kernel
 
 // One target feature set's spatial index (device pointers into the workspace)
 struct GridSet {

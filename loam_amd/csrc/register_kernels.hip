@@ -819,9 +819,10 @@ constexpr int kRestThreads = LOAMX_REST_THREADS;  // small workgroups: the queue
 #ifndef LOAMX_REST_WAVES
 #define LOAMX_REST_WAVES 5  // measured (association scope): unconstrained (150 VGPRs, 3 waves/SIMD) 2.18 ms, 4 -> 2.12, 5 -> 2.11, 6 -> 2.14
 #endif
-template <bool PLANE, int KM>
+template <bool PLANE, int KM, bool ONE_STAGE>
 __global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_rest_kernel(RegBatch B, RegConfig C,
                                                                                               uint32_t blocks_per_pair) {
+  constexpr bool one_stage = ONE_STAGE;  // (two instantiations: each at its own register budget)
   size_t pair;
   uint32_t chunk0;
   if (!xcd_pair_map(blockIdx.x, blocks_per_pair, B.n_pairs, pair, chunk0)) return;
@@ -829,7 +830,7 @@ __global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_
   if (!S.active) return;                                              // uniform per workgroup
   const uint32_t queued = B.assoc.n_assoc[8 * pair + (PLANE ? 3 : 2)];
   if (queued == 0u) return;                                           // uniform per workgroup
-  __shared__ uint32_t s_rows[kLean2RowWords * kRestThreads];  // (the larger of the two per-thread row lists used below)
+  __shared__ uint32_t s_rows[(ONE_STAGE ? kLeanRowWords : kLean2RowWords) * kRestThreads];  // (the largest per-thread row list used below)
   const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
   const size_t field = B.n_pairs * stride;
   uint32_t* __restrict__ rnn = PLANE ? B.assoc.rnn_plane : B.assoc.rnn_edge;  // results by queue position
@@ -857,18 +858,21 @@ __global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_
 #pragma unroll
     for (int j = 0; j < KM; j++) pos[j] = 0;
     int kept = -1;
-    if (!(entry & kQueueTied) && (lean_set || (entry & kQueueWide))) {
+    if (one_stage || (!(entry & kQueueTied) && (lean_set || (entry & kQueueWide)))) {
       const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
       const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));
       if (entry & kQueueWide)
         kept = knn_search_f32_round1<KM, true>(g, cs, sp, gs.rel + pair * 3 * gs.stride, (uint32_t)gs.stride, p, kq, max_dist, pass_max, pos,
                                                 s_rows + threadIdx.x, kRestThreads);
-      else
+      else if (!one_stage)
         kept = knn_lean_round2<KM>(g, cs, sp, gs.rel + pair * 3 * gs.stride, (uint32_t)gs.stride, p, kq, max_dist, pass_max, pos,
                                    s_rows + threadIdx.x, kRestThreads);
+      // one stage (small batches, see launch_associate): the FP64 search over all rounds here and now
+      if (one_stage && kept < 0)
+        kept = knn_search_keyed<KM>(g, cs, sp, p, kq, max_dist, pass_max, pos, s_rows + threadIdx.x, kRestThreads);
     }
     rnn[slot] = (uint32_t)kept;
-    if (kept < 0) left[atomicAdd(&B.assoc.n_assoc[8 * pair + (PLANE ? 5 : 4)], 1u)] = t;
+    if (kept < 0) left[atomicAdd(&B.assoc.n_assoc[8 * pair + (PLANE ? 5 : 4)], 1u)] = t;  // (one stage: counted only)
 #pragma unroll
     for (int j = 0; j < KM; j++) rnn[(1 + j) * field + slot] = pos[j];
   }
@@ -1025,7 +1029,7 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_FIT_WAVES) void associate_fit_
 // The queued queries, after associate_knn_rest_kernel: what its keys left undecided is searched exactly first, then the
 // same fit, results read by queue position.
 template <bool PLANE, int KM>
-__global__ __launch_bounds__(kRestThreads, 4) void associate_fit_queued_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {  // (4: <= 128 registers — it was 230 and waited for two fit wavefronts to leave a SIMD at once)
+__global__ __launch_bounds__(kRestThreads, 3) void associate_fit_queued_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {  // (3: <= 168 registers — unbounded it took 230 and waited for two fit wavefronts to leave a SIMD at once; at 128 it spills 376 bytes)
   size_t pair;
   uint32_t chunk0;
   if (!xcd_pair_map(blockIdx.x, blocks_per_pair, B.n_pairs, pair, chunk0)) return;
@@ -1854,6 +1858,17 @@ void launch_state_init(const RegBatch& B, const RegConfig& C, hipStream_t s) {
 #endif
 // workgroups (of kRestThreads) per pair for the queue kernels: a few for big batches (queues are short),
 // enough to cover a whole set when there are only a few pairs (scan-to-map: one pair, 40 k queries)
+// Queue chain in one stage (the FP64 search over all rounds inside associate_knn_rest_kernel) or two (lean search of the
+// 5x5x5 block, then the listed leftovers on compacted wavefronts)? Two stages halve the chain's work, but their
+// latencies add up — about 0.3 ms for the slowest leftover walks whatever the batch — and only a plane fit kernel that
+// runs at least that long hides them. Measured (same box, 64 x 1024 scan pairs): 256 pairs 3.73 (one) vs 3.88 ms (two),
+// 512 / 1 024 pairs equal, 2 048 / 4 096 pairs 22.7 / 45.2 vs 22.5 / 44.3 ms; a single pair 0.92 vs 0.98 ms.
+constexpr size_t kQueueTwoStageMin = 16u << 20;  // source features in the batch (1 024 pairs of 64 x 1024: 20 M slots)
+static bool queue_one_stage(const RegBatch& B, const RegConfig& C, bool plane) {
+  if (C.flags & kRegFlagQueueTwoStage) return false;
+  if (C.flags & kRegFlagQueueOneStage) return true;
+  return B.n_pairs * (plane ? B.planar_stride : B.edge_stride) < kQueueTwoStageMin;
+}
 static uint32_t rest_blocks(size_t n_pairs, uint32_t nblk) {
   const uint32_t cover = nblk * (uint32_t)(kAssocThreads / kRestThreads);  // one pass over a full queue
   uint32_t want = (uint32_t)(4096 / (n_pairs ? n_pairs : 1));
@@ -1893,10 +1908,16 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
 #define LOAMX_ASSOC_B(PL, KMV, nblk, st)                                                                          \
   do {                                                                                                            \
     const uint32_t rblk_ = rest_blocks(B.n_pairs, (nblk));                                                        \
-    launch_kernel((associate_knn_rest_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * rblk_)),           \
-                       dim3(kRestThreads), 0, (st), B, C, rblk_);                                                 \
-    launch_kernel((associate_knn_left_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * rblk_)),           \
-                       dim3(kRestThreads), 0, (st), B, C, rblk_);                                                 \
+    const uint32_t one_ = queue_one_stage(B, C, (PL)) ? 1u : 0u;                                                  \
+    if (one_) {                                                                                                   \
+      launch_kernel((associate_knn_rest_kernel<PL, KMV, true>), dim3((unsigned)(pair_groups * 8 * rblk_)),   \
+                         dim3(kRestThreads), 0, (st), B, C, rblk_);                                               \
+    } else {                                                                                                      \
+      launch_kernel((associate_knn_rest_kernel<PL, KMV, false>), dim3((unsigned)(pair_groups * 8 * rblk_)),  \
+                         dim3(kRestThreads), 0, (st), B, C, rblk_);                                               \
+      launch_kernel((associate_knn_left_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * rblk_)),         \
+                         dim3(kRestThreads), 0, (st), B, C, rblk_);                                               \
+    }                                                                                                             \
     launch_kernel((associate_fit_queued_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * rblk_)),         \
                        dim3(kRestThreads), 0, (st), B, C, rblk_);                                                 \
   } while (0)

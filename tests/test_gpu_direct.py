@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import reference_kats as K
-from gpu_common import ctx
+from gpu_common import ctx, option
 from loam_amd import capi
 
 pytestmark = pytest.mark.gpu
@@ -89,10 +89,12 @@ def test_associate_on_the_reference_scene_with_ties(oracle):
     src_e = K.transform_points(case["source_T_target"], tgt_e)
     src_p = K.transform_points(case["source_T_target"], tgt_p)
     pose = IDENT if case["init"] is None else np.asarray(case["init"], dtype=np.float64)
-    dump = ctx().associate(src_e, src_p, tgt_e, tgt_p, pose)
     oreg = oracle.RegParams()
-    check_kind(oracle, "edge", dump, src_e, tgt_e, pose, False, oreg, ties=True)
-    check_kind(oracle, "plane", dump, src_p, tgt_p, pose, True, oreg, ties=True)
+    for stage in ("QUEUE_ONE_STAGE", "QUEUE_TWO_STAGE"):
+        with option(stage):
+            dump = ctx().associate(src_e, src_p, tgt_e, tgt_p, pose)
+        check_kind(oracle, "edge " + stage, dump, src_e, tgt_e, pose, False, oreg, ties=True)
+        check_kind(oracle, "plane " + stage, dump, src_p, tgt_p, pose, True, oreg, ties=True)
 
 
 @pytest.mark.parametrize("seed", range(40))
@@ -136,9 +138,13 @@ def test_associate_fuzz_lists_and_fits(oracle, seed):
     reg.max_plane_neighbor_dist = oreg.max_plane_neighbor_dist = float(rng.choice([0.5, 2.0, -1.0]))
     reg.max_edge_neighbor_dist = oreg.max_edge_neighbor_dist = float(rng.choice([0.3, 1.0, -1.0]))
     pose = K.pose7(K.quat_angle_axis(rng.uniform(0, 0.02), ax / np.linalg.norm(ax)), rng.normal(size=3) * 0.02)
-    dump = ctx().associate(src_e, src_p, tgt_e, tgt_p, pose, reg)
-    check_kind(oracle, f"edge {seed}", dump, src_e, tgt_e, pose, False, oreg, ties=tie_e)
-    check_kind(oracle, f"plane {seed}", dump, src_p, tgt_p, pose, True, oreg, ties=tie_p)
+    # both forms of the queue chain: small batches take the one-stage form by themselves, the two-stage form (lean search
+    # of the 5x5x5 block, then the listed leftovers) is what 1 024-pair batches run
+    for stage in ("QUEUE_ONE_STAGE", "QUEUE_TWO_STAGE"):
+        with option(stage):
+            dump = ctx().associate(src_e, src_p, tgt_e, tgt_p, pose, reg)
+        check_kind(oracle, f"edge {seed} {stage}", dump, src_e, tgt_e, pose, False, oreg, ties=tie_e)
+        check_kind(oracle, f"plane {seed} {stage}", dump, src_p, tgt_p, pose, True, oreg, ties=tie_p)
 
 
 def test_fit_entry_points_against_the_oracle(oracle):

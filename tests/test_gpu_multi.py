@@ -151,6 +151,25 @@ def test_lm_loop_streaming_path_agrees_with_the_moment_path(oracle):
         assert rot < 1e-5 and trans < 1e-5, (pr, rot, trans)
 
 
+def test_both_forms_of_the_queue_chain_give_the_same_bits():
+    """The queued k-NN queries are searched in one kernel (small batches) or in two stages (lean search of the 5x5x5 block,
+    then the listed leftovers: batches of ~1 000 pairs). Both are exact searches, so the whole registration must come
+    out bit for bit the same whichever is forced — on a 96-pair batch, every ICF iteration of every pair."""
+    c = ctx()
+    P = 96
+    d_xyz, d_res = c.alloc(P * 2 * N * 24), c.alloc(P * 64)
+    c.synth_scan_pairs_dev(SEED, 700, P, H, W, 0.01, d_xyz.ptr)
+    with option("QUEUE_ONE_STAGE"):
+        one = _run(c, d_xyz.ptr, P, d_res)
+    with option("QUEUE_TWO_STAGE"):
+        two = _run(c, d_xyz.ptr, P, d_res)
+    auto = _run(c, d_xyz.ptr, P, d_res)
+    d_xyz.free()
+    d_res.free()
+    assert np.array_equal(one, two) and np.array_equal(one, auto)
+    assert (one.view(capi.RESULT_DTYPE)["termination"] == capi.CONVERGED).all()
+
+
 def test_128_beam_batch_source_and_target_builds_do_not_share_scratch(oracle):
     """Feature sets above 20 480 points (128-beam scans: ~34 k planar features) take the index builds that need scratch
     memory — the multi-workgroup build of the target sets and the ordered single-workgroup build + rank of the source
