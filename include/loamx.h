@@ -134,8 +134,8 @@ int loamx_ctx_extract_counters(loamx_ctx* ctx, uint64_t* tie_replays, uint64_t* 
  * switch only ever affects the context it was set on. None changes a result beyond the summation order of
  * NO_MOMENTS. Names (DESIGN.md section 5 describes each): FORCE_TIE_REPLAY, FORCE_SCAN_GIVEUP, CURV_V1,
  * NO_FUSED_COMPACT, NO_MIS_SELECT, FUSED_EXTRACT, NO_MOMENTS, NO_PACKED_GRID, NO_BIG_GRID, NO_GRID_SIDE,
- * DEBUG_POISON, QUEUE_TWO_STAGE, QUEUE_ONE_STAGE, MAP_CELLS_LOG2 (a number: 0 = default). Unknown name:
- * LOAMX_ERR_BAD_PARAM. */
+ * DEBUG_POISON, QUEUE_TWO_STAGE, QUEUE_ONE_STAGE, NO_MIXED_ASSOC, MAP_CELLS_LOG2 (a number: 0 = default). Unknown
+ * name: LOAMX_ERR_BAD_PARAM. */
 int loamx_ctx_set_option(loamx_ctx* ctx, const char* name, int value);
 int loamx_ctx_get_option(loamx_ctx* ctx, const char* name, int* value);
 

@@ -115,7 +115,8 @@ const OptionName kOptionNames[] = {
     {"NO_FUSED_COMPACT", true, kFlagNoFusedCompact}, {"NO_MIS_SELECT", true, kFlagNoMisSelect}, {"FUSED_EXTRACT", true, kFlagFusedExtract},
     {"NO_MOMENTS", false, kRegFlagNoMoments}, {"NO_PACKED_GRID", false, kRegFlagNoPackedGrid}, {"NO_BIG_GRID", false, kRegFlagNoBigGrid},
     {"NO_GRID_SIDE", false, kRegFlagNoGridSide}, {"DEBUG_POISON", false, kRegFlagPoison},
-    {"QUEUE_TWO_STAGE", false, kRegFlagQueueTwoStage}, {"QUEUE_ONE_STAGE", false, kRegFlagQueueOneStage}};
+    {"QUEUE_TWO_STAGE", false, kRegFlagQueueTwoStage}, {"QUEUE_ONE_STAGE", false, kRegFlagQueueOneStage},
+    {"NO_MIXED_ASSOC", false, kRegFlagNoMixedAssoc}};
 
 int fail(loamx_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->last_error = msg;

@@ -681,11 +681,14 @@ __device__ __forceinline__ void brute_scan_tile(Coll& c, int k, Vec3 q, const Gr
   }
 }
 
+// (bodies of the k-NN kernels as functions of a workgroup number: associate_knn_mixed_kernel runs both kinds of workgroup
+// in one launch)
 template <bool PLANE, int KM>
-__global__ __launch_bounds__(kAssocThreads) void associate_knn_brute_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
+__device__ __forceinline__ void knn_brute_body(const RegBatch& B, const RegConfig& C, uint32_t blocks_per_pair, uint32_t block,
+                                               GridPoint* s_tile) {
   size_t pair;
   uint32_t chunk;
-  if (!xcd_pair_map(blockIdx.x, blocks_per_pair, B.n_pairs, pair, chunk)) return;
+  if (!xcd_pair_map(block, blocks_per_pair, B.n_pairs, pair, chunk)) return;
   const PairState& S = B.state[pair];
   if (!S.active) return;  // uniform per workgroup
   const GridSet& gs = PLANE ? B.grid_plane : B.grid_edge;
@@ -700,7 +703,6 @@ __global__ __launch_bounds__(kAssocThreads) void associate_knn_brute_kernel(RegB
   const bool has = i < n_src && i < stride;
   const GridSet& src_gs = PLANE ? B.src_grid_plane : B.src_grid_edge;
   const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
-  __shared__ GridPoint s_tile[kBruteTile + kGridPad];
   Vec3 p = v3(0, 0, 0);
   if (has) {
     const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
@@ -747,6 +749,11 @@ __global__ __launch_bounds__(kAssocThreads) void associate_knn_brute_kernel(RegB
 #pragma unroll
   for (int j = 0; j < KM; j++) nn[(1 + j) * field + slot] = pos[j];
 }
+template <bool PLANE, int KM>
+__global__ __launch_bounds__(kAssocThreads) void associate_knn_brute_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
+  __shared__ GridPoint s_tile[kBruteTile + kGridPad];
+  knn_brute_body<PLANE, KM>(B, C, blocks_per_pair, blockIdx.x, s_tile);
+}
 
 // entries of the queues rest_*: a query index and why round 1 queued it
 constexpr uint32_t kQueueIndex = 0x3FFFFFFFu, kQueueWide = 0x80000000u, kQueueTied = 0x40000000u;
@@ -757,11 +764,11 @@ constexpr uint32_t kQueueIndex = 0x3FFFFFFFu, kQueueWide = 0x80000000u, kQueueTi
 //   associate_fit_kernel : pure FP64 arithmetic — gathers the neighbours, fitLine / fitPlane, guards,
 //                          writes the association record.
 template <bool PLANE, int KM>
-__global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_knn_kernel(RegBatch B, RegConfig C,
-                                                                                         uint32_t blocks_per_pair) {
+__device__ __forceinline__ void knn_round1_body(const RegBatch& B, const RegConfig& C, uint32_t blocks_per_pair, uint32_t block,
+                                                uint32_t* s_rows) {
   size_t pair;
   uint32_t chunk;
-  if (!xcd_pair_map(blockIdx.x, blocks_per_pair, B.n_pairs, pair, chunk)) return;
+  if (!xcd_pair_map(block, blocks_per_pair, B.n_pairs, pair, chunk)) return;
   const uint32_t i = chunk * kAssocThreads + threadIdx.x;
   const PairState& S = B.state[pair];
   if (!S.active) return;  // uniform per workgroup
@@ -780,8 +787,7 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_kn
   const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));  // registration.cpp:34 / :75
   const uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
   const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
-  __shared__ uint32_t s_rows[kLeanRowWords * kAssocThreads];  // per-thread row lists of knn_lean_round1, [word][thread] (conflict free)
-  uint32_t pos[KM];
+  uint32_t pos[KM];  // (s_rows: per-thread row lists of knn_lean_round1, [word][thread], conflict free)
   const float* __restrict__ rel = gs.rel + pair * 3 * gs.stride;
   const int kept = knn_search_f32_round1<KM>(g, cs, sp, rel, (uint32_t)gs.stride, p, PLANE ? C.k_plane : C.k_edge,
                                              PLANE ? C.r_plane : C.r_edge, PLANE ? C.pass_plane : C.pass_edge, pos,
@@ -797,6 +803,24 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_kn
   }
 #pragma unroll
   for (int j = 0; j < KM; j++) nn[(1 + j) * field + slot] = pos[j];  // neighbour j is slot (KM - k) + j
+}
+template <bool PLANE, int KM>
+__global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_knn_kernel(RegBatch B, RegConfig C,
+                                                                                         uint32_t blocks_per_pair) {
+  __shared__ uint32_t s_rows[kLeanRowWords * kAssocThreads];
+  knn_round1_body<PLANE, KM>(B, C, blocks_per_pair, blockIdx.x, s_rows);
+}
+// The edge sets of a scan (<= 512 points: brute force) and its planar sets (grid search) in ONE launch: the first
+// `edge_blocks` workgroups are the brute-force kernel's, the rest the round-1 kernel's. As two kernels on two streams the
+// edge chain cost the plane kernel about half of its own duration (1.07 -> 1.22 ms); as extra workgroups of the same
+// dispatch it costs its instructions. One LDS buffer serves both kinds (the row lists are the larger).
+template <int KME, int KMP>
+__global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_knn_mixed_kernel(RegBatch B, RegConfig C, uint32_t blocks_edge,
+                                                                                               uint32_t blocks_plane, uint32_t edge_blocks) {
+  constexpr size_t kRowBytes = sizeof(uint32_t) * kLeanRowWords * kAssocThreads, kTileBytes = sizeof(GridPoint) * (kBruteTile + kGridPad);
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[kRowBytes > kTileBytes ? kRowBytes : kTileBytes];
+  if (blockIdx.x < edge_blocks) knn_brute_body<false, KME>(B, C, blocks_edge, blockIdx.x, reinterpret_cast<GridPoint*>(s_raw));
+  else knn_round1_body<true, KMP>(B, C, blocks_plane, blockIdx.x - edge_blocks, reinterpret_cast<uint32_t*>(s_raw));
 }
 
 // The queue chain. Round 1 queues 1-7 % of the plane queries, nearly all of them because their 3x3x3 block does not hold
@@ -1008,11 +1032,10 @@ __device__ __forceinline__ bool fit_one(const RegBatch& B, const RegConfig& C, c
 #define LOAMX_FIT_WAVES 4
 #endif
 template <bool PLANE, int KM>
-__global__ __launch_bounds__(kAssocThreads, LOAMX_FIT_WAVES) void associate_fit_kernel(RegBatch B, RegConfig C,
-                                                                                        uint32_t blocks_per_pair) {
+__device__ __forceinline__ void fit_body(const RegBatch& B, const RegConfig& C, uint32_t blocks_per_pair, uint32_t block) {
   size_t pair;
   uint32_t chunk;
-  if (!xcd_pair_map(blockIdx.x, blocks_per_pair, B.n_pairs, pair, chunk)) return;
+  if (!xcd_pair_map(block, blocks_per_pair, B.n_pairs, pair, chunk)) return;
   const uint32_t i = chunk * kAssocThreads + threadIdx.x;
   const PairState& S = B.state[pair];
   if (!S.active) return;  // uniform per workgroup
@@ -1024,6 +1047,17 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_FIT_WAVES) void associate_fit_
   // (one atomic per wavefront, no barrier: a wavefront that is done leaves)
   const unsigned long long m = __ballot(valid);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(&B.assoc.n_assoc[8 * pair + (PLANE ? 1 : 0)], (uint32_t)__popcll(m));
+}
+template <bool PLANE, int KM>
+__global__ __launch_bounds__(kAssocThreads, LOAMX_FIT_WAVES) void associate_fit_kernel(RegBatch B, RegConfig C,
+                                                                                        uint32_t blocks_per_pair) {
+  fit_body<PLANE, KM>(B, C, blocks_per_pair, blockIdx.x);
+}
+template <int KME, int KMP>  // (edge and plane fits in one launch, as associate_knn_mixed_kernel)
+__global__ __launch_bounds__(kAssocThreads, LOAMX_FIT_WAVES) void associate_fit_mixed_kernel(RegBatch B, RegConfig C, uint32_t blocks_edge,
+                                                                                              uint32_t blocks_plane, uint32_t edge_blocks) {
+  if (blockIdx.x < edge_blocks) fit_body<false, KME>(B, C, blocks_edge, blockIdx.x);
+  else fit_body<true, KMP>(B, C, blocks_plane, blockIdx.x - edge_blocks);
 }
 
 // The queued queries, after associate_knn_rest_kernel: what its keys left undecided is searched exactly first, then the
@@ -1928,6 +1962,24 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
     else STEP(PL, 16, nblk, st);                         \
   } while (0)
   const bool edges = (what & kAssocEdges) != 0u && be != 0u, planes = (what & kAssocPlanes) != 0u && bp != 0u;
+  // The usual case — every edge set small enough for brute force, every planar set searched through its grid, the
+  // reference's five neighbours — runs the first kernels of both kinds as ONE launch each (associate_knn_mixed_kernel,
+  // associate_fit_mixed_kernel): no edge chain on a side stream.
+  if (edges && planes && B.knn_mode_edge == 2u && B.knn_mode_plane == 1u && C.k_edge <= 5 && C.k_plane <= 5 &&
+      !(C.flags & kRegFlagNoMixedAssoc)) {
+    const uint32_t edge_blocks = (uint32_t)(pair_groups * 8 * be);
+    const dim3 grid((unsigned)(edge_blocks + pair_groups * 8 * bp));
+    LaunchScope* outer = g_launch_scope;
+    if (knn_scope) g_launch_scope = knn_scope;
+    launch_kernel((associate_knn_mixed_kernel<5, 5>), grid, dim3(kAssocThreads), 0, s, B, C, be, bp, edge_blocks);
+    g_launch_scope = outer;
+    hipStream_t sb = aux2 ? aux2 : aux;
+    const bool fork2 = sb != nullptr && hipEventRecord(ev_mid, s) == hipSuccess && hipStreamWaitEvent(sb, ev_mid, 0) == hipSuccess;
+    launch_kernel((associate_fit_mixed_kernel<5, 5>), grid, dim3(kAssocThreads), 0, s, B, C, be, bp, edge_blocks);
+    LOAMX_ASSOC_B(true, 5, bp, (fork2 ? sb : s));
+    if (fork2 && hipEventRecord(aux2 ? ev_join2 : ev_join, sb) == hipSuccess) (void)hipStreamWaitEvent(s, aux2 ? ev_join2 : ev_join, 0);
+    return;
+  }
   // (edges alone: on the caller's stream, nothing to run them next to)
   const bool use_aux = aux != nullptr && planes;  // the side streams only make sense next to the plane chain
   const bool fork = use_aux && (edges || !aux2) && hipEventRecord(ev_fork, s) == hipSuccess &&
