@@ -164,9 +164,11 @@ def test_both_forms_of_the_queue_chain_give_the_same_bits():
     with option("QUEUE_TWO_STAGE"):
         two = _run(c, d_xyz.ptr, P, d_res)
     auto = _run(c, d_xyz.ptr, P, d_res)
+    with option("NO_MIXED_ASSOC"):  # (edge and plane first kernels as separate launches on two streams instead of one launch each)
+        separate = _run(c, d_xyz.ptr, P, d_res)
     d_xyz.free()
     d_res.free()
-    assert np.array_equal(one, two) and np.array_equal(one, auto)
+    assert np.array_equal(one, two) and np.array_equal(one, auto) and np.array_equal(one, separate)
     assert (one.view(capi.RESULT_DTYPE)["termination"] == capi.CONVERGED).all()
 
 
