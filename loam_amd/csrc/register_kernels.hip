@@ -663,6 +663,8 @@ __device__ __forceinline__ bool xcd_pair_map(uint32_t block, uint32_t blocks_per
 // streams through LDS in tiles and every lane scans all of it — no divergence, no dependent loads,
 // and none of the empty-cell rounds a grid search spends on sparse sets. Same collectors, same result.
 constexpr int kBruteTile = 256;
+// LDS of a brute-force workgroup: one tile of 32-byte points (FP64 passes) and behind it three rows of floats (FP32 pass)
+constexpr size_t kBruteLdsBytes = (kBruteTile + kGridPad) * sizeof(GridPoint) + ((3 * (kBruteTile + kGridPad) * sizeof(float) + 31) / 32) * 32;
 
 template <class Coll>
 __device__ __forceinline__ void brute_scan_tile(Coll& c, int k, Vec3 q, const GridPoint* s_tile, uint32_t tile, uint32_t tn) {
@@ -716,16 +718,85 @@ __device__ __forceinline__ void knn_brute_body(const RegBatch& B, const RegConfi
   for (int j = 0; j < KM; j++) pos[j] = 0;
   int kept = 0;
   if (k > 0 && n_tgt > 0) {
-    KnnKeys<KM> c;
-    knn_init(c, k, n_tgt);
-    for (uint32_t tile = 0; tile < n_tgt; tile += kBruteTile) {
-      const uint32_t tn = n_tgt - tile < (uint32_t)kBruteTile ? n_tgt - tile : (uint32_t)kBruteTile;
-      __syncthreads();
-      for (uint32_t t = threadIdx.x; t < tn + kGridPad; t += kAssocThreads) s_tile[t] = sp[tile + t];  // (the set has kGridPad spare entries)
-      __syncthreads();
-      if (has) brute_scan_tile(c, k, p, s_tile, tile, tn);
+    const double pass_max = PLANE ? C.pass_plane : C.pass_edge;
+    // ---- FP32 pre-selection, as in the grid kernel: 32-bit keys (float bits of d2, the low 9 bits = the candidate's
+    // position: the set has at most 512 points) through the v_med3_u32 collector, 10 instructions per candidate instead
+    // of 25; then the k selected are fetched in FP64 and the usual three checks (strictly ascending exact distances, best
+    // rejected key beyond the FP32 error, finite) decide whether the answer stands. Otherwise: the FP64 passes below.
+    kept = has ? -1 : 0;
+    const GridDesc g = gs.desc[pair];
+    if (gs.rel != nullptr && g.h > 0.0) {
+      float* s_f = reinterpret_cast<float*>(s_tile + kBruteTile + kGridPad);  // three rows of kBruteTile + kGridPad floats
+      constexpr int kRow = kBruteTile + kGridPad;
+      const float* __restrict__ rel = gs.rel + pair * 3 * gs.stride;
+      const double a = knn_f32_err_unit(g);
+      const bool inside = has && grid_outside_distance(g, grid_cell_coord(p.x, g.ox, g.inv_h), grid_cell_coord(p.y, g.oy, g.inv_h),
+                                                       grid_cell_coord(p.z, g.oz, g.inv_h)) <= 1;
+      const float qx = (float)(p.x - g.ox), qy = (float)(p.y - g.oy), qz = (float)(p.z - g.oz);
+      constexpr uint32_t imask = 0x1FFu;  // (positions 0 .. kBruteMax - 1)
+      static_assert(kBruteMax <= 512, "nine position bits");
+      KnnKeys32<KM> c;
+      knn_init(c, k);
+      for (uint32_t tile = 0; tile < n_tgt; tile += kBruteTile) {
+        const uint32_t tn = n_tgt - tile < (uint32_t)kBruteTile ? n_tgt - tile : (uint32_t)kBruteTile;
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < tn + kGridPad; t += kAssocThreads) {
+          s_f[t] = rel[tile + t], s_f[kRow + t] = rel[gs.stride + tile + t], s_f[2 * kRow + t] = rel[2 * gs.stride + tile + t];
+        }
+        __syncthreads();
+        if (inside)
+          for (uint32_t u = 0; u < tn; u += 4)
+            knn_collect_batch_f32<KM>(c, qx, qy, qz, *reinterpret_cast<const KnnF4*>(s_f + u), *reinterpret_cast<const KnnF4*>(s_f + kRow + u),
+                                      *reinterpret_cast<const KnnF4*>(s_f + 2 * kRow + u), tn - u, tile + u, ~imask);
+      }
+      if (inside) {
+        int count = 0, kk = 0;
+        bool undecided = false, open = true;
+        double prev = -1.0, d5 = 0.0;
+        GridPoint tp[KM];
+#pragma unroll
+        for (int j = 0; j < KM; j++) {
+          const uint32_t pp = c.key[j] & imask;
+          pos[j] = j >= KM - k && c.key[j] != 0xFFFFFFFFu ? pp : 0u;
+          tp[j] = sp[pp < n_tgt ? pp : 0u];
+        }
+#pragma unroll
+        for (int j = 0; j < KM; j++) {
+          const uint32_t key = c.key[j];
+          if (j >= KM - k && key != 0xFFFFFFFFu) {
+            if (key >= 0x7F800000u) undecided = true;
+            const double dx = p.x - tp[j].x, dy = p.y - tp[j].y, dz = p.z - tp[j].z;
+            const double d2 = dx * dx + dy * dy + dz * dz;  // as knn_scan_batch
+            if (!(d2 > prev) || !(d2 <= kDblMax)) undecided = true;  // a tie, an inversion, not finite
+            prev = d2, d5 = d2;
+            count++;
+            if (open) {
+              if (d2 <= pass_max) kk++;
+              else open = false;
+            }
+          }
+        }
+        const uint32_t k6 = c.key[KM];
+        if (count == k && k6 != 0xFFFFFFFFu) {
+          const double t6 = (double)knn_bits_f32(k6 & ~imask);
+          const double err = 2.0 * (3.4641016151377544 * a * sqrt(d5) + 3.0 * a * a + 2.384185791015625e-7 * d5);  // x2 safety (as knn_lean_finish; the key's position bits only lower t6)
+          if (!(t6 > d5 + err)) undecided = true;
+        }
+        if (!undecided) kept = kk;
+      }
     }
-    kept = has ? knn_keys_finish(c, k, PLANE ? C.pass_plane : C.pass_edge, pos) : 0;
+    if (__syncthreads_or(kept < 0)) {  // FP64 keyed collector for the lanes the pre-selection could not finish
+      KnnKeys<KM> c;
+      knn_init(c, k, n_tgt);
+      for (uint32_t tile = 0; tile < n_tgt; tile += kBruteTile) {
+        const uint32_t tn = n_tgt - tile < (uint32_t)kBruteTile ? n_tgt - tile : (uint32_t)kBruteTile;
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < tn + kGridPad; t += kAssocThreads) s_tile[t] = sp[tile + t];  // (the set has kGridPad spare entries)
+        __syncthreads();
+        if (kept < 0) brute_scan_tile(c, k, p, s_tile, tile, tn);
+      }
+      if (kept < 0) kept = knn_keys_finish(c, k, pass_max, pos);
+    }
     if (__syncthreads_or(kept < 0)) {  // undecided keys somewhere in the workgroup: exact collector for those lanes
       KnnResult<KM> r;
       knn_init(r);
@@ -751,7 +822,7 @@ __device__ __forceinline__ void knn_brute_body(const RegBatch& B, const RegConfi
 }
 template <bool PLANE, int KM>
 __global__ __launch_bounds__(kAssocThreads) void associate_knn_brute_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
-  __shared__ GridPoint s_tile[kBruteTile + kGridPad];
+  __shared__ GridPoint s_tile[kBruteLdsBytes / sizeof(GridPoint)];
   knn_brute_body<PLANE, KM>(B, C, blocks_per_pair, blockIdx.x, s_tile);
 }
 
@@ -817,7 +888,7 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_kn
 template <int KME, int KMP>
 __global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_knn_mixed_kernel(RegBatch B, RegConfig C, uint32_t blocks_edge,
                                                                                                uint32_t blocks_plane, uint32_t edge_blocks) {
-  constexpr size_t kRowBytes = sizeof(uint32_t) * kLeanRowWords * kAssocThreads, kTileBytes = sizeof(GridPoint) * (kBruteTile + kGridPad);
+  constexpr size_t kRowBytes = sizeof(uint32_t) * kLeanRowWords * kAssocThreads, kTileBytes = kBruteLdsBytes;
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[kRowBytes > kTileBytes ? kRowBytes : kTileBytes];
   if (blockIdx.x < edge_blocks) knn_brute_body<false, KME>(B, C, blocks_edge, blockIdx.x, reinterpret_cast<GridPoint*>(s_raw));
   else knn_round1_body<true, KMP>(B, C, blocks_plane, blockIdx.x - edge_blocks, reinterpret_cast<uint32_t*>(s_raw));
