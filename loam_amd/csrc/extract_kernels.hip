@@ -857,7 +857,10 @@ __device__ __forceinline__ bool select_line(int lane, size_t line, int W, int CH
   return false;
 }
 
-template <int R, int WAVES, bool TWO>
+// WT: the line length as a compile-time constant (1024, 2048) or 0 = P.W. Everything below is inlined, so a constant W
+// and CH turn the per-point loops of select_line / mis_pass into straight code: bit masks built with immediate
+// operands instead of 64-bit variable shifts, chunk indices without the magic multiply.
+template <int R, int WAVES, bool TWO, int WT = 0>
 __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __restrict__ curv,
                                                                 const uint8_t* __restrict__ mask, size_t n_lines,
                                                                 ExtractParams P, ExtractStage st, ExtractFused fz) {
@@ -865,7 +868,7 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const size_t line = (size_t)blockIdx.x * WAVES + wave;
   if (line >= n_lines) return;  // whole wavefront leaves; no workgroup barrier below
-  const int W = (int)P.W, CH = (W + 63) / 64;
+  const int W = WT ? WT : (int)P.W, CH = (W + 63) / 64;
   // LDS layout: every lane's chunk of CH points is followed by one spare double (4 spare bytes in
   // the mask): with the chunk stride CH (16 for W = 1024) the lanes of a wavefront would all read the
   // same LDS bank when each walks its own chunk; CH + 1 spreads them over all banks.
@@ -1102,8 +1105,16 @@ static void launch_select_mis2(const double* d_curv, const uint8_t* d_mask, size
 #else
   if (per_wave * 4 <= 48 * 1024) {
 #endif
-    launch_kernel((select_mis_kernel<R, 4, TWO>), dim3((unsigned)((n_lines + 3) / 4)), dim3(256), per_wave * 4, s, d_curv,
-                       d_mask, n_lines, P, st, fz);
+    // (the reference's neighbor_points = 3 on the two usual line lengths: W compiled in)
+    if (R == 2 && !TWO && P.W == 1024)
+      launch_kernel((select_mis_kernel<R, 4, TWO, (R == 2 && !TWO) ? 1024 : 0>), dim3((unsigned)((n_lines + 3) / 4)), dim3(256), per_wave * 4, s,
+                         d_curv, d_mask, n_lines, P, st, fz);
+    else if (R == 2 && TWO && P.W == 2048)
+      launch_kernel((select_mis_kernel<R, 4, TWO, (R == 2 && TWO) ? 2048 : 0>), dim3((unsigned)((n_lines + 3) / 4)), dim3(256), per_wave * 4, s,
+                         d_curv, d_mask, n_lines, P, st, fz);
+    else
+      launch_kernel((select_mis_kernel<R, 4, TWO>), dim3((unsigned)((n_lines + 3) / 4)), dim3(256), per_wave * 4, s, d_curv,
+                         d_mask, n_lines, P, st, fz);
   } else {
     launch_kernel((select_mis_kernel<R, 1, TWO>), dim3((unsigned)n_lines), dim3(64), per_wave, s, d_curv, d_mask, n_lines,
                        P, st, fz);
