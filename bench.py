@@ -326,7 +326,9 @@ def main():
                         roofline["traffic"] = sum(pmc["kernels"][k]["traffic_bytes_per_dispatch"] for k in names)
                         roofline["traffic_source"] = f"{os.path.relpath(PMC_FILE, ROOT)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; sources {h_now})"
                     ctr = pmc.get("counters", {})
-                    knn = next((k for k in ctr if k.startswith("associate_knn_kernel<true")), None)
+                    # (the plane round-1 k-NN kernel: on its own, or — every edge set small, k = 5 — one launch with the edge sets'
+                    # brute-force search as its first workgroups)
+                    knn = next((k for k in ctr if k.startswith("associate_knn_mixed_kernel") or k.startswith("associate_knn_kernel<true")), None)
                     if knn and "SQ_INSTS_VALU" in ctr[knn] and "knn_plane_kernel" in kern:
                         insts = ctr[knn]["SQ_INSTS_VALU"]  # wave-instructions per dispatch
                         ach = insts / (kern["knn_plane_kernel"]["avg_ms"] * 1e-3) / 1e9
