@@ -1418,8 +1418,9 @@ LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cel
  * The same lean search over a larger block (round 3), half-width W cells: W = 2 (5x5x5) is the second chance of a query
  * whose 3x3x3 block did not hold k points closer than the block's faces — sparse neighbourhoods: ~3 % of the plane
  * queries of the bench workload, which the FP64 search over all rounds (knn_search_keyed) served at 19 times the cost
- * per query of the first round; W = 4 (9x9x9) reaches the search radius itself when the cell edge is a quarter of it,
- * i.e. it is final for an ISOLATED query, whose shell-by-shell walk was a chain of ~200 dependent look-ups.
+ * per query of the first round; W = 4 (9x9x9) reaches the search radius itself when the cell edge is a quarter of it
+ * (analysed on the host only — tests/hostcheck, EXPERIMENTS.md: it finishes half of the isolated queries, the other half
+ * run out of the 63 batches — the kernels use W = 2).
  * (2W+1)^2 rows of up to 2W+1 cells, in the order of their squared slab distance, 2W+1 rows' table entries in flight
  * at a time; same collector, same exactness argument (verification against the FP64 points, best rejected key,
  * distance to the faces of the block that WAS searched, or the radius), same return contract: >= 0 done, -1 the block
