@@ -583,11 +583,12 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_
     TimedScope t(ctx, LOAMX_K_GRID, 0.0);
     // the source builds next to the target builds on the auxiliary stream: every workgroup of one build kernel is in
     // the same phase at the same time (reads, then writes), two different kernels side by side even the HBM demand
-    // out (measured 1.19 -> 1.11 ms per step); not for a few pairs (fork / join latency).
+    // out (measured 1.19 -> 1.11 ms per step). For a single pair too since round 3 (the two planar builds are one
+    // workgroup of 45 and 83 us each: side by side 100 instead of 150 us; one pair 0.82 -> 0.80 ms).
     // (Round 3: the first ICF iteration's edge chains right behind the edge builds on the auxiliary stream, i.e. next to
     // the planar index builds instead of next to the plane k-NN kernel: 11.60 / 11.72 vs 11.65 / 11.53 ms per step —
     // what the k-NN kernel gains the HBM-bound builds lose. Not kept.)
-    const bool side = B.n_pairs >= 8 && !(C.flags & kRegFlagNoGridSide) && ctx->aux_stream && !prebuilt &&
+    const bool side = !(C.flags & kRegFlagNoGridSide) && ctx->aux_stream && !prebuilt &&
                       hipEventRecord(ctx->ev_fork, s) == hipSuccess && hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0) == hipSuccess;
     if (!prebuilt) launch_grid_build_targets(B, C, s);
     launch_grid_build_sources(B, C, side ? ctx->aux_stream : s);
