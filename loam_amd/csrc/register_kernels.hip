@@ -1284,8 +1284,14 @@ struct LightLds {
   double T[kMomDim][7], Z[kMomDim][7];
 };
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+// Kept in LDS for the whole solve of a pair (lm_pair_loop_kernel), because every one of its <= 5 evaluations reads them
+// and from global memory they were dependent round trips on the one wavefront's critical path (measured per evaluation
+// of a single pair: 20 counts of listed records, one after the other, 5.2 us; edge records 4.2 us of a 15 us evaluation):
+// the pair's edge records and the numbers of listed plane records of its moment tiles.
+constexpr uint32_t kEdgeCache = 320;   // records (9 doubles each: 23 KB); a scan yields ~290 edge features
+constexpr uint32_t kListCache = 64;    // moment tiles of a pair (4 per chunk of kSweepChunk slots)
 __device__ __forceinline__ double light_eval(const RegBatch& B, size_t pair, const double x[7], uint32_t n_se, uint32_t n_sp,
-                                             const double* mom, LightLds& L) {
+                                             const double* mom, LightLds& L, const double (*s_edge)[kEdgeCache], const uint32_t* s_listed) {
   const int lane = threadIdx.x;  // (64-thread workgroup)
   const size_t efield = B.n_pairs * B.edge_stride, pfield = B.n_pairs * B.planar_stride;
   const double* __restrict__ E = B.assoc.edge + pair * B.edge_stride;
@@ -1294,16 +1300,18 @@ __device__ __forceinline__ double light_eval(const RegBatch& B, size_t pair, con
 #pragma unroll
   for (int j = 0; j < kAccSize; j++) acc[j] = 0.0;
   for (uint32_t v = lane; v < n_se; v += 64) {
-    const double f0 = E[v];
+    const bool cached = v < kEdgeCache;  // (the same records in the same order either way)
+    const double f0 = cached ? s_edge[0][v] : E[v];
     if (f0 == f0) {  // NaN in field 0 marks an invalid slot
       double prim[6];
 #pragma unroll
-      for (int f = 0; f < 6; f++) prim[f] = E[(3 + f) * efield + v];
-      residual_accumulate(false, v3(f0, E[efield + v], E[2 * efield + v]), prim, x, acc);
+      for (int f = 0; f < 6; f++) prim[f] = cached ? s_edge[3 + f][v] : E[(3 + f) * efield + v];
+      residual_accumulate(false, v3(f0, cached ? s_edge[1][v] : E[efield + v], cached ? s_edge[2][v] : E[2 * efield + v]), prim, x, acc);
     }
   }
   for (uint32_t lb = 0; lb < B.mom_blocks_per_pair * 4 && (lb / 4) * kSweepChunk < n_sp; lb++) {
-    const uint32_t cnt = B.flagged_count[pair * B.mom_blocks_per_pair * 4 + lb];
+    const uint32_t cnt = lb < kListCache ? s_listed[lb] : B.flagged_count[pair * B.mom_blocks_per_pair * 4 + lb];
+    if (cnt == 0u) continue;  // (uniform)
     const uint32_t* __restrict__ fl = B.flagged_list + (pair * B.mom_blocks_per_pair * 4 + lb) * (size_t)(kSweepChunk / 4);
     for (uint32_t k = lane; k < cnt; k += 64) {
       const uint32_t q = fl[k];
@@ -1504,6 +1512,8 @@ __global__ __launch_bounds__(64) void lm_pair_loop_kernel(RegBatch B, RegConfig 
   __shared__ LightLds L;
   __shared__ double s_mom[kMomSize + 2];
   __shared__ double s_acc[kAccSize];
+  __shared__ double s_edge[9][kEdgeCache];
+  __shared__ uint32_t s_listed[kListCache];
   const int lane = threadIdx.x;
   const size_t pair = blockIdx.x;
   PairState& S = B.state[pair];
@@ -1515,6 +1525,17 @@ __global__ __launch_bounds__(64) void lm_pair_loop_kernel(RegBatch B, RegConfig 
   const uint32_t n_se_raw = B.n_src_edge[pair * B.in_pitch], n_sp_raw = B.n_src_planar[pair * B.in_pitch];
   const uint32_t n_se = n_se_raw < B.edge_stride ? n_se_raw : (uint32_t)B.edge_stride;
   const uint32_t n_sp = n_sp_raw < B.planar_stride ? n_sp_raw : (uint32_t)B.planar_stride;
+  {  // the pair's edge records and listed-record counts into LDS (independent loads: one round trip)
+    const size_t efield = B.n_pairs * B.edge_stride;
+    const double* __restrict__ E = B.assoc.edge + pair * B.edge_stride;
+    const uint32_t nc = n_se < kEdgeCache ? n_se : kEdgeCache;
+    for (uint32_t v = lane; v < nc; v += 64) {
+#pragma unroll
+      for (int f = 0; f < 9; f++) s_edge[f][v] = E[f * efield + v];
+    }
+    static_assert(kListCache == 64, "one lane per tile");
+    s_listed[lane] = (uint32_t)lane < B.mom_blocks_per_pair * 4 ? B.flagged_count[pair * B.mom_blocks_per_pair * 4 + lane] : 0u;
+  }
   // ---- the pair's moment matrix: its wavefront tiles in a fixed order
   uint32_t stream = 1u;
   if (S.use_moments) {
@@ -1545,7 +1566,7 @@ __global__ __launch_bounds__(64) void lm_pair_loop_kernel(RegBatch B, RegConfig 
   for (int i = 0; i < 7; i++) x[i] = S.lm.xeval[i];
   wave_lds_fence();
   for (int k = 0; k < 5 && lm_active; k++) {  // iteration-0 evaluation + max_num_iterations = 4 candidates
-    const double v = stream ? stream_eval_wave(B, pair, x, n_se, n_sp) : light_eval(B, pair, x, n_se, n_sp, s_mom, L);
+    const double v = stream ? stream_eval_wave(B, pair, x, n_se, n_sp) : light_eval(B, pair, x, n_se, n_sp, s_mom, L, s_edge, s_listed);
     if (lane < kAccSize) s_acc[lane] = 0.0 + v;
     wave_lds_fence();
     if (lane == 0) {
