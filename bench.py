@@ -48,7 +48,7 @@ VALU_PEAK_GINST = 256 * 4 * 2.4 / VALU_CYCLES_PER_INST
 SEED = 20240311
 H, W = 64, 1024
 SIGMA = 0.01
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
 
 
 def parse_args():
@@ -308,6 +308,15 @@ def main():
                             avg_launch_ms=dk["avg_ms"], algorithmic_bytes_per_launch=dk["algorithmic_bytes_per_launch"],
                             share_of_kernel_time=round(dk["total_ms"] / sum(k["total_ms"] for k in top.values()), 4),
                             measured_over_steps=stat_steps)
+            # `kernel` above is an event SCOPE (one launch of every kernel of the association: k-NN + fit, edge + plane, queue
+            # chain). The rocprofv3 kernel that dominates it — and the whole step — is named here, with its live duration
+            # (HIP events around that launch alone: sub-scope knn_plane_kernel) and, from the committed trace of the same
+            # sources, rocprofv3's own average and share of kernel time
+            if dominant == "associate_kernel" and "knn_plane_kernel" in kern:
+                roofline["dominant_rocprof_kernel"] = {
+                    "name": "associate_knn_mixed_kernel<5, 5>", "avg_us": round(kern["knn_plane_kernel"]["avg_ms"] * 1e3, 1),
+                    "share": round(kern["knn_plane_kernel"]["total_ms"] / sum(k["total_ms"] for k in top.values()), 4),
+                    "measured": "HIP events on the launch stream, this run"}
             # the HBM-bound kernels of the path (the ones north_star prices against the roofline), next to it
             roofline["hbm_bound_kernels"] = {n: kern[n]["hbm_frac"] for n in ("curvature_valid_kernel", "extract_fused_kernel", "sweep_kernel", "moment_kernel") if n in kern}
             # HBM traffic per launch of the dominant scope and the vector-instruction counts of the k-NN kernel come
@@ -319,6 +328,12 @@ def main():
                 if pmc.get("source_sha256") != h_now:
                     roofline["traffic_note"] = f"{os.path.relpath(PMC_FILE, ROOT)} was profiled on other kernel sources ({pmc.get('source_sha256')} vs {h_now}): traffic not reported"
                 elif pmc.get("bench_config", {}).get("pairs_per_gpu") == P:
+                    tr = pmc.get("kernel_trace", {})
+                    if tr and "dominant_rocprof_kernel" in roofline:
+                        big = max(tr, key=lambda n: tr[n]["share"])
+                        roofline["dominant_rocprof_kernel"].update({"rocprofv3_name": big, "rocprofv3_avg_us": tr[big]["avg_us"],
+                                                                    "rocprofv3_share": tr[big]["share"],
+                                                                    "rocprofv3_source": os.path.relpath(PMC_FILE, ROOT)})
                     # an event scope holds one dispatch of every kernel of that family (e.g. associate = kNN + fit,
                     # edge + plane): traffic per scope = sum of the per-dispatch averages
                     names = [k for k in pmc["kernels"] if k.startswith(dominant.replace("_kernel", ""))]

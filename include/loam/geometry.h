@@ -91,7 +91,8 @@ inline std::vector<double> packRows(const Eigen::MatrixXd& points) {
 /** @brief Fits a line to K >= 2 points by PCA (reference geometry.h:102, geometry.cpp:42-59): the line through the
  * centroid along the eigenvector of the largest eigenvalue, as Line(centre + 0.1 dir, centre - 0.1 dir), and the
  * condition number the reference returns — std::numeric_limits<double>::max() always (geometry.cpp:55-56).
- * Runs on the device (loamx_fit_lines); K <= 32. */
+ * Runs on the device (loamx_fit_lines). LIMIT (the reference's Eigen::MatrixXd has none): K <= 32 rows — beyond it
+ * loamx_fit_lines returns LOAMX_ERR_UNSUPPORTED and this throws std::runtime_error. */
 template <typename Points>
 std::pair<Line, double> fitLine(const Points& points) {
   const std::vector<double> xyz = packRows(points);
@@ -102,7 +103,7 @@ std::pair<Line, double> fitLine(const Points& points) {
 
 /** @brief Fits a plane to K >= 3 points: least squares of points * [a b c]^T = 1 by column-pivoted Householder QR,
  * normal = abc / |abc|, d = 1 / |abc|; second = the signed mean of points * normal - d (reference geometry.h:123,
- * geometry.cpp:62-73). Runs on the device (loamx_fit_planes); K <= 32. */
+ * geometry.cpp:62-73). Runs on the device (loamx_fit_planes). LIMIT: K <= 32 rows (std::runtime_error beyond, as fitLine). */
 template <typename Points>
 std::pair<Plane, double> fitPlane(const Points& points) {
   const std::vector<double> xyz = packRows(points);

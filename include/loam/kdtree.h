@@ -60,7 +60,11 @@ class KDTree {
 
 /** @brief Radius limited k nearest neighbour search (reference kdtree.h:49, kdtree.cpp:10-28).
  * @param max_dist: if <= 0 no radius limit; otherwise neighbours with sqrt(d^2) < max_dist are kept (strict).
- * @returns indices into the adaptor's data, ascending distance; fewer than k when the set or the radius gives fewer */
+ * @returns indices into the adaptor's data, ascending distance; fewer than k when the set or the radius gives fewer
+ * LIMITS (the reference, nanoflann's KNNResultSet(k), has none): k <= 16 — beyond it loamx_knn_search returns
+ * LOAMX_ERR_UNSUPPORTED and this throws std::runtime_error; every call is one synchronous host -> device -> host round
+ * trip on the shared default context (it takes that context's mutex): the batch entry points (loamx_knn_search with
+ * many queries, loamx_associate) are the ones to use in a loop. */
 inline std::vector<size_t> knnSearch(const KDTree& tree, const Vector3d& query, const size_t k, const double max_dist = -1) {
   std::vector<uint32_t> idx(k ? k : 1);
   uint32_t count = 0;

@@ -190,7 +190,8 @@ void loamx_target_index_destroy(loamx_ctx* ctx, loamx_target_index* index);
  * Amortised over a map grown scan by scan the rebuilds are O(log n) events. */
 int loamx_target_index_insert(loamx_ctx* ctx, loamx_target_index* index, const double* edge, size_t n_edge,
                               const double* planar, size_t n_planar);
-/* how the index has been maintained so far: full (re)builds of a feature kind's grid / merges into an existing one */
+/* how the index has been maintained so far: full (re)builds of a feature kind's grid (counted per kind: creating an index
+ * with both kinds counts two) / merges into an existing one. A kind that receives no points in an insert is left alone. */
 int loamx_target_index_stats(const loamx_target_index* index, uint64_t* full_builds, uint64_t* merges);
 /* number of edge / planar points in the index (either pointer may be NULL) */
 int loamx_target_index_size(const loamx_target_index* index, size_t* n_edge, size_t* n_planar);
@@ -314,6 +315,19 @@ int loamx_gather_results_dev(loamx_ctx* ctx, loamx_comm* comm, const loamx_reg_r
 /* all ranks wait for each other (1-element all-reduce + stream synchronisation); *max_value, if given, is replaced by
  * the maximum over ranks (the bench's max-over-ranks timing without a second communication library) */
 int loamx_comm_barrier(loamx_ctx* ctx, loamx_comm* comm, double* max_value);
+/* What the two entry points above have really enqueued on this communicator so far, by kind. A one-rank communicator
+ * takes the device-copy shortcut (LOAMX_COMM_STAT_MEMCPY) unless the context's option FORCE_RCCL is set: then the
+ * gather enqueues ncclAllGather AND the grouped ncclBroadcast form (in place, same bytes), the barrier ncclAllReduce —
+ * the pre-flight of a box without a second GPU (tools/multi_gpu_selfcheck.py, tests/test_gpu_multi.py).
+ * Environment LOAMX_RCCL_LIB names the RCCL library to dlopen instead of librccl.so.1 (a missing file: LOAMX_ERR_COMM). */
+enum {
+  LOAMX_COMM_STAT_ALL_GATHER = 0,
+  LOAMX_COMM_STAT_BROADCAST = 1, /* members of the grouped broadcast (one per non-empty shard) */
+  LOAMX_COMM_STAT_ALL_REDUCE = 2,
+  LOAMX_COMM_STAT_MEMCPY = 3, /* one-rank shortcuts: no collective was enqueued */
+  LOAMX_COMM_STAT_COUNT = 4
+};
+int loamx_comm_stats(const loamx_comm* comm, uint64_t counts[LOAMX_COMM_STAT_COUNT]);
 
 /* ---- per-kernel timing (hipEvents on the context stream), for bench.py's roofline object ------- */
 enum {

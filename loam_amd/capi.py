@@ -91,7 +91,7 @@ EXPORTS = [
     "loamx_extract_features_batch_dev_f32", "loamx_register_scan_pairs_dev_f32",
     "loamx_target_index_insert", "loamx_target_index_size",
     "loamx_shard_range", "loamx_comm_get_unique_id", "loamx_comm_create", "loamx_comm_wrap", "loamx_comm_destroy",
-    "loamx_comm_info", "loamx_gather_results_dev", "loamx_comm_barrier", "loamx_ctx_extract_counters",
+    "loamx_comm_info", "loamx_gather_results_dev", "loamx_comm_barrier", "loamx_comm_stats", "loamx_ctx_extract_counters",
     "loamx_ctx_set_option", "loamx_ctx_get_option",
     "loamx_fit_lines", "loamx_fit_planes", "loamx_knn_search", "loamx_associate", "loamx_target_index_stats",
 ]
@@ -183,6 +183,7 @@ def load(build_if_missing=True):
     lib.loamx_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.loamx_gather_results_dev.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, vp]
     lib.loamx_comm_barrier.argtypes = [vp, vp, dp]
+    lib.loamx_comm_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.loamx_ctx_extract_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.loamx_fit_lines.argtypes = [vp, dp, C.c_size_t, C.c_size_t, dp, dp]
     lib.loamx_fit_planes.argtypes = [vp, dp, C.c_size_t, C.c_size_t, dp, dp]
@@ -274,6 +275,13 @@ class Comm:
         v = C.c_double(value)
         self.ctx._check(self.ctx.lib.loamx_comm_barrier(self.ctx.h, self.h, C.byref(v)))
         return v.value
+
+    def stats(self):
+        """what gather_results_dev / barrier have really enqueued so far (loamx_comm_stats): collectives by kind, and the
+        one-rank device-copy shortcuts"""
+        v = (C.c_uint64 * 4)()
+        self.ctx._check(self.ctx.lib.loamx_comm_stats(self.h, v))
+        return dict(ncclAllGather=int(v[0]), ncclBroadcast=int(v[1]), ncclAllReduce=int(v[2]), memcpy=int(v[3]))
 
     def close(self):
         if getattr(self, "h", None):

@@ -90,7 +90,8 @@ struct loamx_target_index {
   GridPoint* sorted2[2] = {nullptr, nullptr};
   float* rel2[2] = {nullptr, nullptr};
   size_t n_at_build[2] = {0, 0};
-  uint64_t full_builds = 0, merges = 0;
+  bool grid_valid[2] = {false, false};  // the kind's cell-sorted arrays + table describe idx->pts[k][0 .. n[k]) (full build or merges since)
+  uint64_t full_builds = 0, merges = 0;  // per kind: a call that rebuilds both kinds counts two
 };
 
 namespace loamx {
@@ -116,7 +117,7 @@ const OptionName kOptionNames[] = {
     {"NO_MOMENTS", false, kRegFlagNoMoments}, {"NO_PACKED_GRID", false, kRegFlagNoPackedGrid}, {"NO_BIG_GRID", false, kRegFlagNoBigGrid},
     {"NO_GRID_SIDE", false, kRegFlagNoGridSide}, {"DEBUG_POISON", false, kRegFlagPoison},
     {"QUEUE_TWO_STAGE", false, kRegFlagQueueTwoStage}, {"QUEUE_ONE_STAGE", false, kRegFlagQueueOneStage},
-    {"NO_MIXED_ASSOC", false, kRegFlagNoMixedAssoc}};
+    {"NO_MIXED_ASSOC", false, kRegFlagNoMixedAssoc}, {"FORCE_RCCL", false, kRegFlagForceRccl}};
 
 int fail(loamx_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->last_error = msg;
@@ -461,10 +462,15 @@ int enqueue_icf_iteration(loamx_ctx* ctx, const RegBatch& B, const RegConfig& C,
 
 // dump != nullptr (loamx_associate): index builds + ONE association pass at the initial estimate, read out into the
 // host arrays of *dump (one pair); no solve, d_results untouched
-int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C, loamx_reg_result* d_results, bool want_iter_info,
+int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C_in, loamx_reg_result* d_results, bool want_iter_info,
                  AfterAssocHook hook, void* hook_user, const loamx_target_index* prebuilt = nullptr, const loamx_assoc_dump* dump = nullptr,
                  size_t dump_n_se = 0, size_t dump_n_sp = 0) {
   if (in.n_pairs == 0) return LOAMX_OK;
+  RegConfig C = C_in;
+  // The reference's associateEdges / associatePlanes (registration.cpp:23-103) do not know max_iterations; here a pair with
+  // max_iterations == 0 is never active (state_init_kernel), so its association kernels would return at once and the dump
+  // would read workspace nobody wrote. One association pass needs one iteration's worth of "active".
+  if (dump && C.max_iterations == 0) C.max_iterations = 1;
   untimed(ctx);
   if (in.n_pairs > 0x7FFFFFFFull / 128) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "too many pairs in one call");
   const size_t np = in.n_pairs, es = in.edge_stride ? in.edge_stride : 1, ps = in.planar_stride ? in.planar_stride : 1;
@@ -1183,7 +1189,7 @@ int index_reserve(loamx_ctx* ctx, loamx_target_index* idx, int k, size_t extra) 
   if (idx->rel2[k]) (void)hipFree(idx->rel2[k]);
   idx->sorted2[k] = nullptr, idx->rel2[k] = nullptr;
   idx->pts[k] = pts, idx->sorted[k] = sorted, idx->rel[k] = rel, idx->cap[k] = cap;
-  idx->n_at_build[k] = 0;  // (the cell-sorted arrays are gone: this kind is rebuilt)
+  idx->n_at_build[k] = 0, idx->grid_valid[k] = false;  // (the cell-sorted arrays are gone: this kind is rebuilt)
   return LOAMX_OK;
 }
 
@@ -1245,8 +1251,7 @@ int index_build(loamx_ctx* ctx, loamx_target_index* idx, unsigned kinds = 3u) {
   if (rc != LOAMX_OK) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(s));
   for (int k = 0; k < 2; k++)
-    if (kinds & (1u << k)) idx->n_at_build[k] = idx->n[k];
-  idx->full_builds++;
+    if (kinds & (1u << k)) idx->n_at_build[k] = idx->n[k], idx->grid_valid[k] = true, idx->full_builds++;
   return LOAMX_OK;
 }
 
@@ -1277,7 +1282,9 @@ int index_append(loamx_ctx* ctx, loamx_target_index* idx, const double* edge, si
   for (int k = 0; k < 2; k++) {
     if (add[k]) HIP_TRY(ctx, hipMemcpyAsync(idx->pts[k] + idx->n[k] * 3, host[k], add[k] * 24, hipMemcpyHostToDevice, s));
     merge[k] = add[k] != 0 && index_can_merge(idx, k, add[k]);
-    if (!merge[k] && (add[k] != 0 || idx->n_at_build[k] != idx->n[k] || idx->full_builds == 0)) rebuild |= 1u << k;
+    // a kind that receives nothing keeps its grid — also one grown by merges since its last full build (the size
+    // at the last full build was compared here, and an edge-only insert re-sorted a million-point planar map)
+    if (!merge[k] && (add[k] != 0 || !idx->grid_valid[k])) rebuild |= 1u << k;
     idx->n[k] += add[k];
   }
   // ---- merges: count the new points per cell (and learn whether they all lie inside the grid), then move + scatter
@@ -1313,7 +1320,7 @@ int index_append(loamx_ctx* ctx, loamx_target_index* idx, const double* edge, si
   for (int k = 0; k < 2; k++) {
     if (!merge[k]) continue;
     if (ctx->h_pinned[32 + k] != 0u) {  // a new point outside the grid: this kind is rebuilt around the larger set
-      merge[k] = false, rebuild |= 1u << k;
+      merge[k] = false, rebuild |= 1u << k, idx->grid_valid[k] = false;
       continue;
     }
     if (!idx->sorted2[k]) {
@@ -1321,7 +1328,7 @@ int index_append(loamx_ctx* ctx, loamx_target_index* idx, const double* edge, si
           hipMalloc(reinterpret_cast<void**>(&idx->rel2[k]), 3 * (idx->cap[k] + kGridPad) * sizeof(float)) != hipSuccess) {
         if (idx->sorted2[k]) (void)hipFree(idx->sorted2[k]);
         idx->sorted2[k] = nullptr, idx->rel2[k] = nullptr;
-        merge[k] = false, rebuild |= 1u << k;  // (no room for the twins: the rebuild needs none)
+        merge[k] = false, rebuild |= 1u << k, idx->grid_valid[k] = false;  // (no room for the twins: the rebuild needs none)
         continue;
       }
     }
@@ -1606,6 +1613,7 @@ struct loamx_comm {
   bool owned = false;
   int world = 1, rank = 0, device = 0;
   double* d_scalar = nullptr;  // barrier / max-reduce scratch (device)
+  uint64_t enqueued[LOAMX_COMM_STAT_COUNT] = {};  // what loamx_gather_results_dev / loamx_comm_barrier really enqueued
 };
 
 namespace {
@@ -1622,10 +1630,18 @@ struct Rccl {
   bool ok = false;
   Rccl() {
     void* h = nullptr;
-    for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+    // LOAMX_RCCL_LIB names the one library to open (a site-specific build; the tests point it at a missing file)
+    const char* forced = getenv("LOAMX_RCCL_LIB");
+    std::string why;
+    for (const char* n : {forced ? forced : "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
       if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+      // dlerror() clears the message it returns: read it ONCE per failed attempt (the first attempt's message is kept)
+      const char* e = dlerror();
+      if (why.empty()) why = std::string(n) + ": " + (e ? e : "?");
+      if (forced) break;
+    }
     if (!h) {
-      error = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?");
+      error = "librccl not found: " + why;
       return;
     }
     bool all = true;
@@ -1751,13 +1767,20 @@ int loamx_gather_results_dev(loamx_ctx* ctx, loamx_comm* c, const loamx_reg_resu
   untimed(ctx);
   hipStream_t s = ctx->stream;
   static_assert(sizeof(loamx_reg_result) == 64, "record size");
-  if (c->world == 1) {
+  // One rank: a device copy — unless option FORCE_RCCL is set, which sends the one-rank communicator through BOTH collective
+  // forms below (the all-gather, then the grouped broadcast in place: same bytes), so that they have executed before
+  // the first multi-GPU node runs them.
+  const bool forced = c->world == 1 && (ctx->reg_flags & kRegFlagForceRccl) != 0;
+  if (c->world == 1 && !forced) {
     if (d_all != d_local) HIP_TRY(ctx, hipMemcpyAsync(d_all, d_local, n_local * sizeof(loamx_reg_result), hipMemcpyDeviceToDevice, s));
+    c->enqueued[LOAMX_COMM_STAT_MEMCPY]++;
     return LOAMX_OK;
   }
   if (total_pairs % (size_t)c->world == 0) {  // equal shards: one all-gather of n_local * 64 bytes per rank
     NCCL_TRY(ctx, rccl().AllGather(d_local, d_all, n_local * sizeof(loamx_reg_result), ncclChar, c->comm, s));
-    return LOAMX_OK;
+    c->enqueued[LOAMX_COMM_STAT_ALL_GATHER]++;
+    if (!forced) return LOAMX_OK;
+    d_local = d_all;  // (forced: the broadcast form runs in place on what the all-gather delivered)
   }
   // uneven shards (sizes differ by one): every rank broadcasts its block to its place, as one grouped operation
   NCCL_TRY(ctx, rccl().GroupStart());
@@ -1771,8 +1794,15 @@ int loamx_gather_results_dev(loamx_ctx* ctx, loamx_comm* c, const loamx_reg_resu
       (void)rccl().GroupEnd();
       return fail(ctx, LOAMX_ERR_COMM, std::string("ncclBroadcast: ") + rccl().GetErrorString(rr));
     }
+    c->enqueued[LOAMX_COMM_STAT_BROADCAST]++;
   }
   NCCL_TRY(ctx, rccl().GroupEnd());
+  return LOAMX_OK;
+}
+
+int loamx_comm_stats(const loamx_comm* c, uint64_t counts[LOAMX_COMM_STAT_COUNT]) {
+  if (!c || !counts) return LOAMX_ERR_BAD_PARAM;
+  for (int i = 0; i < LOAMX_COMM_STAT_COUNT; i++) counts[i] = c->enqueued[i];
   return LOAMX_OK;
 }
 
@@ -1784,8 +1814,13 @@ int loamx_comm_barrier(loamx_ctx* ctx, loamx_comm* c, double* max_value) {
   hipStream_t s = ctx->stream;
   const double v = max_value ? *max_value : 0.0;
   HIP_TRY(ctx, hipMemcpyAsync(c->d_scalar, &v, sizeof(double), hipMemcpyHostToDevice, s));
-  if (c->world > 1) NCCL_TRY(ctx, rccl().AllReduce(c->d_scalar, c->d_scalar + 1, 1, ncclDouble, ncclMax, c->comm, s));
-  else HIP_TRY(ctx, hipMemcpyAsync(c->d_scalar + 1, c->d_scalar, sizeof(double), hipMemcpyDeviceToDevice, s));
+  if (c->world > 1 || (ctx->reg_flags & kRegFlagForceRccl)) {
+    NCCL_TRY(ctx, rccl().AllReduce(c->d_scalar, c->d_scalar + 1, 1, ncclDouble, ncclMax, c->comm, s));
+    c->enqueued[LOAMX_COMM_STAT_ALL_REDUCE]++;
+  } else {
+    HIP_TRY(ctx, hipMemcpyAsync(c->d_scalar + 1, c->d_scalar, sizeof(double), hipMemcpyDeviceToDevice, s));
+    c->enqueued[LOAMX_COMM_STAT_MEMCPY]++;
+  }
   double o = 0.0;
   HIP_TRY(ctx, hipMemcpyAsync(&o, c->d_scalar + 1, sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));

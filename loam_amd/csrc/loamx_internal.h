@@ -112,6 +112,7 @@ constexpr uint32_t kRegFlagNoGridSide = 8u;    // source index builds behind the
 constexpr uint32_t kRegFlagPoison = 16u;       // registration scratch starts as 0xFF bytes
 constexpr uint32_t kRegFlagQueueTwoStage = 32u;  // queue chain: always lean 5x5x5 search + listed leftovers (launch_associate)
 constexpr uint32_t kRegFlagQueueOneStage = 64u;  // queue chain: always the FP64 search over all rounds in one kernel
+constexpr uint32_t kRegFlagForceRccl = 256u;     // a one-rank communicator really enqueues ncclAllGather / ncclBroadcast / ncclAllReduce (host side only)
 constexpr uint32_t kRegFlagNoMixedAssoc = 128u;  // edge and plane first kernels as separate launches on two streams (launch_associate)
 
 // One target feature set's spatial index (device pointers into the workspace)

@@ -59,9 +59,10 @@ def build():
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
+        override = os.environ.get("ORACLE_LIB")  # (tests/test_sanitizers.py: the -fsanitize build)
+        if not override and not os.path.exists(_LIB_PATH):
             build()
-        _lib = C.CDLL(_LIB_PATH)
+        _lib = C.CDLL(override or _LIB_PATH)
         dp = C.POINTER(C.c_double)
         _lib.oracle_quat_angular_distance.restype = C.c_double
         _lib.oracle_point_to_line_distance.restype = C.c_double

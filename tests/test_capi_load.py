@@ -60,3 +60,19 @@ def test_no_cpu_fallback_without_device():
     with pytest.raises(capi.LoamxError) as e:
         capi.Context(0)
     assert e.value.status == capi.ERR_NO_DEVICE
+
+
+def test_missing_rccl_library_is_an_error_code_not_a_crash():
+    """the lazy RCCL loader built its message from two dlerror() calls — the second returns NULL and
+    the process died in std::string. A loader pointed at a library that does not exist must come back with LOAMX_ERR_COMM."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from loam_amd import capi\n"
+            "import ctypes as C\n"
+            "buf = C.create_string_buffer(capi.COMM_ID_BYTES)\n"
+            "print('rc', capi.load().loamx_comm_get_unique_id(buf))\n" % ROOT)
+    env = dict(os.environ, LOAMX_RCCL_LIB="/nonexistent/librccl-not-here.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "rc 7" in out.stdout  # LOAMX_ERR_COMM

@@ -27,7 +27,7 @@ def test_merge_inserts_equal_a_fresh_index_and_the_oracle_tree(oracle):
     base_p, base_e = surface_points(260_000), surface_points(900)
     base_p[:2] = [box_lo - 0.05, box_hi + 0.05]  # the grid's corners: later points stay inside
     idx = c.target_index(base_e, base_p)
-    assert c.target_index_stats(idx) == (1, 0)
+    assert c.target_index_stats(idx) == (2, 0)  # (full builds are counted per feature kind)
     all_p, all_e = [base_p], [base_e]
     for step in range(6):
         add_p, add_e = surface_points(30_000), surface_points(100)
@@ -36,7 +36,7 @@ def test_merge_inserts_equal_a_fresh_index_and_the_oracle_tree(oracle):
     builds, merges = c.target_index_stats(idx)
     # planar: the first insert outgrows the exactly-sized buffers (capacity doubles: a rebuild), then five merges
     # (290 k -> 440 k stays below twice the size at that build); edge (scan-sized): rebuilt every time
-    assert merges == 5 and builds == 1 + 6, (builds, merges)
+    assert merges == 5 and builds == 2 + 6 + 1, (builds, merges)
     cat_p, cat_e = np.concatenate(all_p), np.concatenate(all_e)
     assert c.target_index_size(idx) == (len(cat_e), len(cat_p))
     fresh = c.target_index(cat_e, cat_p)
@@ -66,8 +66,20 @@ def test_merge_inserts_equal_a_fresh_index_and_the_oracle_tree(oracle):
     for i, qq in enumerate(np.concatenate([out_pt + 0.01, q[:50]])):
         assert np.array_equal(got[i], tree2.knn(qq, 5, -1.0).astype(np.uint32))
     # ... and merging goes on afterwards
-    c.target_index_insert(idx, np.zeros((0, 3)), surface_points(10_000))
+    last_p = surface_points(10_000)
+    c.target_index_insert(idx, np.zeros((0, 3)), last_p)
     assert c.target_index_stats(idx) == (b2, m2 + 1)
+    # an edge-only insert rebuilds the (scan-sized) edge kind and leaves the merged planar map alone (the
+    # planar kind's size at its last FULL build differs from its size now, which used to force a full re-sort)
+    more_e = surface_points(50)
+    c.target_index_insert(idx, more_e, np.zeros((0, 3)))
+    assert c.target_index_stats(idx) == (b2 + 1, m2 + 1)
+    got = c.knn_search(idx, 1, q[:50], 5, 2.0)  # (the planar kind still answers: the last merge's points included)
+    tree3 = oracle.KDTree(np.concatenate([cat_p2, last_p]))
+    for i in range(50):
+        assert np.array_equal(got[i], tree3.knn(q[i], 5, 2.0).astype(np.uint32))
+    c.target_index_insert(idx, np.zeros((0, 3)), np.zeros((0, 3)))  # nothing: nothing happens
+    assert c.target_index_stats(idx) == (b2 + 1, m2 + 1)
     c.target_index_destroy(idx)
     c.target_index_destroy(fresh)
 
@@ -98,7 +110,7 @@ def test_insert_cost_is_the_new_points_not_the_map():
         c.target_index_insert(idx, add_e, add_p)
         best = min(best, time.perf_counter() - t0)
     builds, merges = c.target_index_stats(idx)
-    assert merges == 6 and builds == 2
+    assert merges == 6 and builds == 3  # (create: both kinds; the first insert: the planar kind)
     print(f"index create {t_create * 1e3:.2f} ms; insert of 39 k points into a 1.08-1.27 M-point kind: {best * 1e3:.3f} ms wall")
     assert best < 0.5 * t_create and best < 1.5e-3
     c.target_index_destroy(idx)

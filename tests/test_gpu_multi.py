@@ -55,9 +55,19 @@ def test_rccl_gather_behind_the_c_abi_one_rank():
     rec["pose"] = np.arange(35, dtype=np.float64).reshape(5, 7)
     rec["termination"], rec["iterations"] = np.arange(5), 7 - np.arange(5)
     d_local, d_all = c.alloc(5 * 64).upload(rec.view(np.uint8)), c.alloc(5 * 64)
+    # default: a one-rank communicator takes the device-copy shortcut ...
     comm.gather_results_dev(d_local.ptr, 5, 5, d_all.ptr)
     assert comm.barrier(3.5) == 3.5
     assert np.array_equal(d_all.download(np.uint8, 5 * 64), rec.view(np.uint8))
+    assert comm.stats() == dict(ncclAllGather=0, ncclBroadcast=0, ncclAllReduce=0, memcpy=2)
+    # ... FORCE_RCCL: the same calls really enqueue ncclAllGather, the grouped ncclBroadcast (root 0) and
+    # ncclAllReduce on the one-rank communicator, so the three collectives have executed before a multi-GPU node runs them
+    d_all.upload(np.zeros(5 * 64, np.uint8))
+    with option("FORCE_RCCL", 1, c):
+        comm.gather_results_dev(d_local.ptr, 5, 5, d_all.ptr)
+        assert comm.barrier(-2.25) == -2.25
+    assert np.array_equal(d_all.download(np.uint8, 5 * 64), rec.view(np.uint8))
+    assert comm.stats() == dict(ncclAllGather=1, ncclBroadcast=1, ncclAllReduce=1, memcpy=2)
     with pytest.raises(capi.LoamxError):  # not this rank's shard
         comm.gather_results_dev(d_local.ptr, 4, 5, d_all.ptr)
     comm.close()

@@ -82,6 +82,8 @@ def rank_main(args):
     uid = [capi.comm_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(uid, src=0)
     comm = capi.Comm(ctx, uid[0], world, rank)
+    if world == 1:  # one rank: no shortcut — the collectives themselves run on the one-rank communicator (option FORCE_RCCL)
+        ctx.set_option("FORCE_RCCL", 1)
     lidar, fe, reg = capi.LidarParams(H, W, 1.0, 120.0), capi.FeatureExtractionParams(), capi.RegistrationParams()
     N = H * W
     report = {"world_size": world, "rccl_comm_nranks": comm.info()["world_size"], "failures": []}
@@ -104,8 +106,11 @@ def rank_main(args):
         first, count = capi.shard_range(total, world, rank)
         d_xyz, d_res = run_shard(first, count)
         d_all = ctx.alloc(total * 64)
+        before = comm.stats()
         comm.gather_results_dev(d_res.ptr, count, total, d_all.ptr)
         ctx.synchronize()
+        after = comm.stats()
+        enqueued = {k: after[k] - before[k] for k in after if after[k] != before[k]}  # what this call REALLY enqueued
         got = d_all.download(np.uint8, total * 64).copy()
         # (1) every rank holds the same array
         ref = [got.tobytes() if rank == 0 else None]
@@ -123,8 +128,8 @@ def rank_main(args):
             b.free()
         ok = all_ok(same and neighbour and own)
         if rank == 0:
-            report[label] = {"total_pairs": total, "collective": plan(world, total)["collective"], "identical_on_every_rank": ok,
-                             "converged": converged}
+            report[label] = {"total_pairs": total, "planned_collective": plan(world, total)["collective"], "enqueued": enqueued,
+                             "identical_on_every_rank": ok, "converged": converged}
             if not ok:
                 report["failures"].append(label)
         return ok
@@ -178,6 +183,9 @@ def rank_main(args):
         _, cnt = capi.shard_range(args.total_pairs, world, rank)
         ts = timed(cnt, args.total_pairs, True)
         report["strong_scaling_point"] = {"total_pairs": args.total_pairs, "n_gpus": world, "pairs_per_s": round(args.total_pairs * args.steps / ts, 1)}
+    report["enqueued_total"] = comm.stats()
+    if world == 1 and not all(report["enqueued_total"][k] for k in ("ncclAllGather", "ncclBroadcast", "ncclAllReduce")):
+        report["failures"].append("FORCE_RCCL: a collective was not enqueued")
     report["ok"] = not report["failures"]
     if rank == 0:
         print(json.dumps(report), flush=True)

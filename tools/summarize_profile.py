@@ -52,6 +52,7 @@ def main():
     src, dst = sys.argv[1], sys.argv[2]
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     md = ["# rocprofv3 summary (" + os.path.basename(src) + ")", ""]
+    trace_tables = {}
     for sub, log, title in (("trace", "bench_under_rocprof.log", "`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline`"),
                             ("trace_seq", "bench_under_rocprof_seq.log", "the same with `LOAMX_NO_AUX_STREAM=1` (association chains in sequence on one stream: "
                              "per-kernel durations without the inflation that concurrent kernels report)")):
@@ -64,6 +65,8 @@ def main():
             w.writerow(["kernel", "calls", "total_ns", "average_ns", "percentage"])
             for r in rows:
                 w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]])
+        trace_tables[sub] = {short(r["Name"]): {"calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2),
+                                                "share": round(float(r["Percentage"]) / 100.0, 4)} for r in rows}
         md += ["## Kernel time: " + title, "", "| kernel | calls | avg µs | total ms | % |", "|---|---|---|---|---|"]
         for r in rows:
             if float(r["Percentage"]) < 0.01:
@@ -124,14 +127,18 @@ def main():
                       f"{'' if algo is None else f'{algo/1e6:.2f}'} | {'' if ratio is None else f'{ratio:.3f}'} |")
         cfg = bj.get("config", {})
         scopes = {k: v["launches"] for k, v in kern.items()}  # HIP-event scopes of that run (associate = kNN + fit, edge + plane)
-        pmc_json = {"source": os.path.basename(src), "source_sha256": (open(os.path.join(src, "source_sha256.txt")).read().strip() if os.path.exists(os.path.join(src, "source_sha256.txt")) else source_hash()), "bench_config": cfg, "event_scopes": scopes, "kernels": out}
+        pmc_json = {"source": os.path.basename(src), "source_sha256": (open(os.path.join(src, "source_sha256.txt")).read().strip() if os.path.exists(os.path.join(src, "source_sha256.txt")) else source_hash()), "bench_config": cfg, "event_scopes": scopes, "kernels": out,
+                    "kernel_trace": trace_tables.get("trace", {}), "kernel_trace_sequential": trace_tables.get("trace_seq", {})}
         json.dump(pmc_json, open(dst + "_pmc.json", "w"), indent=1)
     # any further counter passes (pmc_x*): per-kernel average per dispatch
     extra = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
     for d in sorted(glob.glob(os.path.join(src, "pmc_x*"))):
         if not os.path.isdir(d):
             continue
-        for r in csv.DictReader(open(one_pass(os.path.join(d, "*", "*_counter_collection.csv"))[0])):
+        files = one_pass(os.path.join(d, "*", "*_counter_collection.csv"))
+        if not files:  # (an aborted rocprofv3 pass leaves the directory without a counter file)
+            continue
+        for r in csv.DictReader(open(files[0])):
             a = extra[short(r["Kernel_Name"])][r["Counter_Name"]]
             a[0] += 1
             a[1] += float(r["Counter_Value"])
