@@ -113,6 +113,7 @@ constexpr uint32_t kRegFlagPoison = 16u;       // registration scratch starts as
 constexpr uint32_t kRegFlagQueueTwoStage = 32u;  // queue chain: always lean 5x5x5 search + listed leftovers (launch_associate)
 constexpr uint32_t kRegFlagQueueOneStage = 64u;  // queue chain: always the FP64 search over all rounds in one kernel
 constexpr uint32_t kRegFlagForceRccl = 256u;     // a one-rank communicator really enqueues ncclAllGather / ncclBroadcast / ncclAllReduce (host side only)
+constexpr uint32_t kRegFlagNoCoopLeft = 512u;    // listed queue leftovers one lane per query (associate_knn_left_kernel, round 3), not one wavefront per query
 constexpr uint32_t kRegFlagNoMixedAssoc = 128u;  // edge and plane first kernels as separate launches on two streams (launch_associate)
 
 // One target feature set's spatial index (device pointers into the workspace)

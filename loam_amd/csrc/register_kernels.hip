@@ -953,7 +953,8 @@ __global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_
 #pragma unroll
     for (int j = 0; j < KM; j++) pos[j] = 0;
     int kept = -1;
-    if (one_stage || (!(entry & kQueueTied) && (lean_set || (entry & kQueueWide)))) {
+    const bool coop = !one_stage && !(C.flags & kRegFlagNoCoopLeft);  // (wide entries: a dense block is the cooperative kernel's business)
+    if (one_stage || (!(entry & kQueueTied) && ((lean_set && !(entry & kQueueWide)) || ((entry & kQueueWide) && !coop)))) {
       const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
       const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));
       if (entry & kQueueWide)
@@ -967,7 +968,13 @@ __global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_
         kept = knn_search_keyed<KM>(g, cs, sp, p, kq, max_dist, pass_max, pos, s_rows + threadIdx.x, kRestThreads);
     }
     rnn[slot] = (uint32_t)kept;
-    if (kept < 0) left[atomicAdd(&B.assoc.n_assoc[8 * pair + (PLANE ? 5 : 4)], 1u)] = t;  // (one stage: counted only)
+    // (one stage: counted only. Two stages: the top bits say how far the leftover's search has to reach — 1: the keys of the
+    // 3x3x3 block tied, 2: the 5x5x5 block's tied or it held more than 63 batches, 3: a dense 3x3x3 block (wide running numbers),
+    // 0: not even the 5x5x5 block held k points closer than its faces: the radius cube)
+    if (kept < 0) {
+      const uint32_t hint = (entry & kQueueTied) ? 1u : ((entry & kQueueWide) ? 3u : (kept == -1 ? 0u : 2u));
+      left[atomicAdd(&B.assoc.n_assoc[8 * pair + (PLANE ? 5 : 4)], 1u)] = t | (hint << 30);
+    }
 #pragma unroll
     for (int j = 0; j < KM; j++) rnn[(1 + j) * field + slot] = pos[j];
   }
@@ -1000,7 +1007,7 @@ __global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_
   const uint32_t t0 = spread ? chunk0 + blocks_per_pair * threadIdx.x : chunk0 * kRestThreads + threadIdx.x;
   const uint32_t dt = spread ? 0xFFFFFFFFu - t0 : blocks_per_pair * kRestThreads;
   for (uint32_t t = t0; t < listed; t += dt) {
-    const uint32_t qpos = left[t], i = rest[qpos] & kQueueIndex;
+    const uint32_t qpos = left[t] & kQueueIndex, i = rest[qpos] & kQueueIndex;
     const size_t slot = pair * stride + qpos;
     const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
     const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));
@@ -1010,6 +1017,214 @@ __global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_
     rnn[slot] = (uint32_t)kept;
 #pragma unroll
     for (int j = 0; j < KM; j++) rnn[(1 + j) * field + slot] = pos[j];
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Wave-cooperative search (round 4): the 64 lanes of a wavefront share ONE query. The listed leftovers of the queue are
+ * the searches one lane cannot do well: isolated queries (the whole radius cube: 81 rows at a quarter-radius cell, nearly
+ * all empty — ~100 dependent round trips for one lane) and, against a map-sized set, queries whose 3x3x3 block holds
+ * thousands of points (one lane walking a thousand batches: associate_knn_rest_kernel took 4 x 1 ms of BASELINE config 5).
+ * Here the rows of the block are dealt out over the lanes (both table entries of up to 64 rows in flight at once), and
+ * every row's candidates are taken 64 at a time, one per lane, coalesced. Each lane keeps its own FP64 keyed collector
+ * (KnnKeys: one double per candidate, distance bits + position); the k + 1 smallest keys of the wavefront are then drawn
+ * from the lanes' lists by k + 1 wave-wide minima. That is the collector's own contract — the k + 1 smallest keys of all
+ * the candidates examined — so knn_done / knn_keys_finish decide exactly as they do for one lane, and the result is the
+ * exact search's (what the keys cannot decide keeps its negative count for the exact collector, as before).
+ * W = half-width of the block in cells: 1 for a query that only ran out of running numbers (its block is dense: the
+ * usual test against the block's faces decides), else ceil(radius / cell): the whole radius cube, after which nothing
+ * unvisited can pass the radius filter. Rows farther than the wave-wide bound (min over the lanes of their own k-th key,
+ * a valid bound on the true k-th distance) or than the radius are skipped; inside a row only the cells the radius reaches.
+ * Returns kept >= 0, -1 undecided, -2 not applicable (no radius and not a dense block, or a cube of more than
+ * kCoopMaxRows rows): the caller falls back to the one-lane search.
+ * ---------------------------------------------------------------------------------------------- */
+constexpr int kCoopMaxRows = 1024;
+
+__device__ __forceinline__ double wave_min_all(double v) {  // (every lane gets the minimum)
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double o = __shfl_xor(v, off);
+    v = knn_key_min(v, o);
+  }
+  return v;
+}
+
+template <int KM>
+__device__ __forceinline__ int knn_coop_search(const GridDesc& g, const uint32_t* __restrict__ cell_start, const GridPoint* __restrict__ sp,
+                                               Vec3 q, int k, double max_dist, double pass_max, int32_t w_hint, uint32_t pos[KM]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < KM; j++) pos[j] = 0;
+  if (g.n_points == 0 || k <= 0) return 0;
+  if (k > KM) k = KM;
+  const int32_t cx = grid_cell_coord(q.x, g.ox, g.inv_h), cy = grid_cell_coord(q.y, g.oy, g.inv_h), cz = grid_cell_coord(q.z, g.oz, g.inv_h);
+  const int32_t out = grid_outside_distance(g, cx, cy, cz);
+  if (max_dist > 0.0 && out >= 1 && (double)(out - 1) * g.h >= max_dist) return 0;
+  int32_t W = w_hint;  // w_hint >= 1: a block of that half-width is believed to do (its faces are tested); 0: the radius cube
+  if (w_hint < 1 || out > w_hint) {
+    if (!(max_dist > 0.0)) return -2;
+    // (+ 1: the faces of the cube lie strictly beyond the radius whatever the query's place in its cell, so knn_done's
+    // shrunken face distances still reach it; + out: a query outside the grid sits `out` cells off the nearest grid cell)
+    const double wf = ceil(max_dist * g.inv_h) + 1.0 + (double)out;
+    if (!(wf < 64.0)) return -2;
+    W = (int32_t)wf < 1 ? 1 : (int32_t)wf;
+  }
+  const int32_t D = 2 * W + 1;
+  const int NR = D * D;
+  if (NR > kCoopMaxRows) return -2;
+  const double r2 = knn_radius_bound(max_dist);
+  double bound = r2;  // wave-uniform: nothing farther than this can be among the k kept
+  KnnKeys<KM> c;
+  knn_init(c, k, g.n_points);
+  // Chunk -1: the nine rows around the query's own (centre, faces, corners), over the whole x extent of the block; then the
+  // other rows of the block, 64 at a time, with the bound the inner rows have left.
+  for (int c0 = -64; c0 < (W > 1 ? NR : 0); c0 += 64) {
+    // ---- lane l owns one row of the block: its slab distance and, for the cells the bound reaches, its range
+    uint32_t rb = 0, re = 0;
+    double s2 = kDblMax;
+    {
+      constexpr int kOrder[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
+      const bool inner_chunk = c0 < 0;
+      const int ri = inner_chunk ? lane : c0 + lane;
+      int32_t dy, dz;
+      if (inner_chunk) dy = kOrder[lane < 9 ? lane : 0] % 3 - 1, dz = kOrder[lane < 9 ? lane : 0] / 3 - 1;
+      else dy = ri % D - W, dz = ri / D - W;
+      const bool mine = inner_chunk ? lane < 9 : (ri < NR && !(dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1));
+      const int32_t iy = cy + dy, iz = cz + dz;
+      if (mine && iy >= 0 && iy <= g.ny - 1 && iz >= 0 && iz <= g.nz - 1) {
+        const double sy = dy == 0 ? 0.0 : slab_dist(q.y, g.oy, g.h, iy), sz = dz == 0 ? 0.0 : slab_dist(q.z, g.oz, g.h, iz);
+        const double rowmin2 = sy * sy + sz * sz;
+        if (rowmin2 <= bound) {
+          int32_t xlo = cx - W < 0 ? 0 : cx - W, xhi = cx + W > g.nx - 1 ? g.nx - 1 : cx + W;
+          if (bound < kDblMax) {  // cells whose x slab is farther than sqrt(bound - rowmin2) cannot contribute (as knn_general_round)
+            const double reach = sqrt(bound - rowmin2) + 1e-9 * g.h;
+            const int32_t xl = grid_cell_coord(q.x - reach, g.ox, g.inv_h), xh = grid_cell_coord(q.x + reach, g.ox, g.inv_h);
+            if (xl > xlo) xlo = xl;
+            if (xh < xhi) xhi = xh;
+          }
+          if (xlo <= xhi) {
+            const uint32_t row = (uint32_t)((iz * g.ny + iy) * g.nx);
+            rb = cell_start_at(cell_start, row + (uint32_t)xlo);
+            re = cell_start_at(cell_start, row + (uint32_t)xhi + 1u);
+            s2 = rowmin2;
+          }
+        }
+      }
+    }
+    // ---- the non-empty rows of this chunk, one after the other, 64 candidates at a time
+    unsigned long long rows = __ballot(rb < re);
+    while (rows) {
+      const int b = __ffsll(rows) - 1;
+      rows &= rows - 1;
+      const uint32_t begin = (uint32_t)__builtin_amdgcn_readlane((int)rb, b), end = (uint32_t)__builtin_amdgcn_readlane((int)re, b);
+      const double rs2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s2), b), __builtin_amdgcn_readlane(__double2loint(s2), b));
+      if (rs2 > bound) continue;  // (the bound has moved since the row was listed)
+      for (uint32_t p0 = begin; p0 < end; p0 += 64) {
+        const uint32_t p = p0 + (uint32_t)lane;
+        const bool real = p < end;
+        const GridPoint t = sp[real ? p : begin];
+        const double dx = q.x - t.x, dy = q.y - t.y, dz = q.z - t.z;
+        const double d2 = dx * dx + dy * dy + dz * dz;  // nanoflann L2_Simple, as knn_scan_batch
+        knn_key_insert(c, knn_key_pack(d2, p, c.mask, real));
+      }
+      if (end - begin >= 32u) {  // a populous row may have moved the bound (a lane with k keys bounds the true k-th distance)
+        const double wb = wave_min_all(knn_bound(c, k));
+        bound = wb < bound ? wb : bound;
+      }
+    }
+    if (c0 < 0 && W > 1) {
+      // the inner rows are done: a bound for the rest of the block. Exact: the k-th smallest head over the lanes is not
+      // available cheaply, but any lane that holds k keys bounds it; with fewer than 64 k candidates so far few lanes do, so
+      // the lanes' keys are pooled first — the k smallest of the wavefront, drawn as at the end (on a copy).
+      KnnKeys<KM> cc = c;
+      double kth = knn_key_empty();
+      for (int t = 0; t < k; t++) {
+        double head = knn_key_empty();
+#pragma unroll
+        for (int j = KM; j >= 0; j--)
+          if (j >= KM - k) head = cc.key[j] < head ? cc.key[j] : head;
+        const double best = wave_min_all(head);
+        kth = best;
+        if (head == best && best < knn_key_empty()) {
+#pragma unroll
+          for (int j = 0; j < KM; j++)
+            if (j >= KM - k) cc.key[j] = cc.key[j + 1];
+          cc.key[KM] = knn_key_empty();
+        }
+      }
+      if (kth < knn_key_empty()) {  // the true d2 of each of the k smallest keys is <= its key with all position bits set
+        const double ub = knn_key_join(knn_key_hi(kth), knn_key_lo(kth) | c.mask);
+        bound = ub < bound ? ub : bound;
+      }
+    }
+  }
+  // ---- the k + 1 smallest keys of the wavefront: k + 1 times the smallest head of the lanes' lists
+  KnnKeys<KM> m;
+  knn_init(m, k, g.n_points);
+#pragma unroll
+  for (int t = 0; t <= KM; t++) {
+    if (t >= KM - k) {  // (slots below hold the sentinel)
+      double head = knn_key_empty();
+#pragma unroll
+      for (int j = KM; j >= 0; j--)
+        if (j >= KM - k) head = c.key[j] < head ? c.key[j] : head;  // the list is ascending: its first real slot — written branch-free
+      const double best = wave_min_all(head);
+      m.key[t] = best;
+      if (head == best && best < knn_key_empty()) {  // the owner drops it (keys of different candidates differ in their position bits)
+#pragma unroll
+        for (int j = 0; j < KM; j++)
+          if (j >= KM - k) c.key[j] = c.key[j + 1];
+        c.key[KM] = knn_key_empty();
+      }
+    }
+  }
+  if (!knn_done(g, q, k, max_dist, cx, cy, cz, m, W)) return -1;
+  return knn_keys_finish(m, k, pass_max, pos);
+}
+
+// The listed leftovers, one WAVEFRONT per entry (see knn_coop_search); an entry the cooperative search does not apply to
+// (no radius limit) is searched by lane 0 alone, as associate_knn_left_kernel does it.
+template <bool PLANE, int KM>
+__global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_coop_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
+  size_t pair;
+  uint32_t chunk0;
+  if (!xcd_pair_map(blockIdx.x, blocks_per_pair, B.n_pairs, pair, chunk0)) return;
+  const PairState& S = B.state[pair];
+  if (!S.active) return;                                              // uniform per workgroup
+  const uint32_t listed = B.assoc.n_assoc[8 * pair + (PLANE ? 5 : 4)];
+  if (listed == 0u) return;                                           // uniform per workgroup
+  __shared__ uint32_t s_rows[kLeanRowWords];
+  const size_t stride = PLANE ? B.planar_stride : B.edge_stride;
+  const size_t field = B.n_pairs * stride;
+  uint32_t* __restrict__ rnn = PLANE ? B.assoc.rnn_plane : B.assoc.rnn_edge;
+  const uint32_t* __restrict__ rest = (PLANE ? B.assoc.rest_plane : B.assoc.rest_edge) + pair * stride;
+  const uint32_t* __restrict__ left = (PLANE ? B.assoc.exact_plane : B.assoc.exact_edge) + pair * stride;
+  const GridSet& gs = PLANE ? B.grid_plane : B.grid_edge;
+  const GridSet& src_gs = PLANE ? B.src_grid_plane : B.src_grid_edge;
+  const GridDesc g = gs.desc[pair];
+  const uint32_t* __restrict__ cs = gs.cell_start + pair * (size_t)(kGridCellsCap + 1);
+  const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
+  const int kq = PLANE ? C.k_plane : C.k_edge;
+  const double max_dist = PLANE ? C.r_plane : C.r_edge, pass_max = PLANE ? C.pass_plane : C.pass_edge;
+  for (uint32_t t = chunk0; t < listed; t += blocks_per_pair) {  // (wave-uniform: one entry per wavefront and turn)
+    const uint32_t listed_entry = left[t], qpos = listed_entry & kQueueIndex, hint = listed_entry >> 30, i = rest[qpos] & kQueueIndex;
+    const size_t slot = pair * stride + qpos;
+    const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
+    const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));
+    uint32_t pos[KM];
+    int kept = knn_coop_search<KM>(g, cs, sp, p, kq, max_dist, pass_max, hint == 3u ? 1 : (int32_t)hint, pos);
+    if (kept == -1 && hint != 0u) kept = knn_coop_search<KM>(g, cs, sp, p, kq, max_dist, pass_max, 0, pos);  // (the block did not reach far enough after all)
+    if (kept == -2) {  // uniform
+      if ((threadIdx.x & 63) == 0) kept = knn_search_keyed<KM>(g, cs, sp, p, kq, max_dist, pass_max, pos, s_rows, 1);
+      kept = __builtin_amdgcn_readfirstlane(kept);
+#pragma unroll
+      for (int j = 0; j < KM; j++) pos[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos[j]);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      rnn[slot] = (uint32_t)kept;
+#pragma unroll
+      for (int j = 0; j < KM; j++) rnn[(1 + j) * field + slot] = pos[j];
+    }
   }
 }
 
@@ -1993,7 +2208,14 @@ constexpr size_t kQueueTwoStageMin = 16u << 20;  // source features in the batch
 static bool queue_one_stage(const RegBatch& B, const RegConfig& C, bool plane) {
   if (C.flags & kRegFlagQueueTwoStage) return false;
   if (C.flags & kRegFlagQueueOneStage) return true;
+  if (!(C.flags & kRegFlagNoCoopLeft)) return false;  // the cooperative leftover kernel is short at every batch size
   return B.n_pairs * (plane ? B.planar_stride : B.edge_stride) < kQueueTwoStageMin;
+}
+// wavefronts per pair of associate_knn_coop_kernel (one listed entry per wavefront and turn): a batch lists 15-35 entries per pair,
+// a single scan-to-map registration up to half of its queries
+static uint32_t coop_blocks(size_t n_pairs) {
+  const size_t want = 32768 / (n_pairs ? n_pairs : 1);
+  return (uint32_t)(want < 32 ? 32 : (want > 8192 ? 8192 : want));
 }
 static uint32_t rest_blocks(size_t n_pairs, uint32_t nblk) {
   const uint32_t cover = nblk * (uint32_t)(kAssocThreads / kRestThreads);  // one pass over a full queue
@@ -2041,8 +2263,14 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
     } else {                                                                                                      \
       launch_kernel((associate_knn_rest_kernel<PL, KMV, false>), dim3((unsigned)(pair_groups * 8 * rblk_)),  \
                          dim3(kRestThreads), 0, (st), B, C, rblk_);                                               \
-      launch_kernel((associate_knn_left_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * rblk_)),         \
-                         dim3(kRestThreads), 0, (st), B, C, rblk_);                                               \
+      if (C.flags & kRegFlagNoCoopLeft) {                                                                         \
+        launch_kernel((associate_knn_left_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * rblk_)),       \
+                           dim3(kRestThreads), 0, (st), B, C, rblk_);                                             \
+      } else {                                                                                                    \
+        const uint32_t cblk_ = coop_blocks(B.n_pairs);                                                            \
+        launch_kernel((associate_knn_coop_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * cblk_)),       \
+                           dim3(kRestThreads), 0, (st), B, C, cblk_);                                             \
+      }                                                                                                           \
     }                                                                                                             \
     launch_kernel((associate_fit_queued_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * rblk_)),         \
                        dim3(kRestThreads), 0, (st), B, C, rblk_);                                                 \

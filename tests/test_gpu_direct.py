@@ -23,7 +23,7 @@ WORST = {}
 
 def note_ratio(kind, err, allowance, where):
     r = float(err) / float(allowance)
-    if r > WORST.get(kind, (0.0, None, 0.0, 0.0))[0]:
+    if r > WORST.get(kind, (-1.0, None, 0.0, 0.0))[0]:
         WORST[kind] = (r, str(where), float(err), float(allowance))
 
 

@@ -162,9 +162,10 @@ def test_lm_loop_streaming_path_agrees_with_the_moment_path(oracle):
 
 
 def test_both_forms_of_the_queue_chain_give_the_same_bits():
-    """The queued k-NN queries are searched in one kernel (small batches) or in two stages (lean search of the 5x5x5 block,
-    then the listed leftovers: batches of ~1 000 pairs). Both are exact searches, so the whole registration must come
-    out bit for bit the same whichever is forced — on a 96-pair batch, every ICF iteration of every pair."""
+    """The queued k-NN queries are searched in one kernel (round 3: small batches) or in two stages: the lean search of the
+    5x5x5 block, then the listed leftovers — one WAVEFRONT per leftover since round 4 (associate_knn_coop_kernel), one lane
+    per leftover with NO_COOP_LEFT. All are exact searches, so the whole registration must come out bit for bit the same
+    whichever is forced — on a 96-pair batch, every ICF iteration of every pair."""
     c = ctx()
     P = 96
     d_xyz, d_res = c.alloc(P * 2 * N * 24), c.alloc(P * 64)
@@ -174,6 +175,9 @@ def test_both_forms_of_the_queue_chain_give_the_same_bits():
     with option("QUEUE_TWO_STAGE"):
         two = _run(c, d_xyz.ptr, P, d_res)
     auto = _run(c, d_xyz.ptr, P, d_res)
+    with option("NO_COOP_LEFT"), option("QUEUE_TWO_STAGE"):
+        lanes = _run(c, d_xyz.ptr, P, d_res)
+    assert np.array_equal(one, lanes)
     with option("NO_MIXED_ASSOC"):  # (edge and plane first kernels as separate launches on two streams instead of one launch each)
         separate = _run(c, d_xyz.ptr, P, d_res)
     d_xyz.free()

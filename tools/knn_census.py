@@ -25,16 +25,12 @@ import oracle_lib  # noqa: E402
 ORDER = (4, 1, 3, 5, 7, 0, 2, 6, 8)
 # (name, cell edge = R / div, census_query arguments, a-priori bound: None | "prev" | "ideal")
 VARIANTS = [
-    ("two(1,2)", 4, dict(scheme="two", a=1, f=2), None),
+    ("prev f=1", 4, dict(scheme="cur", f=1), "prev"),
+    ("prev f=2", 4, dict(scheme="cur", f=2), "prev"),
+    ("prev f=4", 4, dict(scheme="cur", f=4), "prev"),
+    ("ideal f=1", 4, dict(scheme="cur", f=1), "ideal"),
+    ("ideal f=2", 4, dict(scheme="cur", f=2), "ideal"),
     ("dyn(1,2)", 4, dict(scheme="dyn", a=1, f=2), None),
-    ("dyn(1,3)", 4, dict(scheme="dyn", a=1, f=3), None),
-    ("dyn(2,4)", 4, dict(scheme="dyn", a=2, f=4), None),
-    ("R/3.5 dyn(1,2)", 3.5, dict(scheme="dyn", a=1, f=2), None),
-    ("R/3.5 dyn(2,4)", 3.5, dict(scheme="dyn", a=2, f=4), None),
-    ("R/3 dyn(1,2)", 3, dict(scheme="dyn", a=1, f=2), None),
-    ("R/3 dyn(2,4)", 3, dict(scheme="dyn", a=2, f=4), None),
-    ("ideal f=4", 4, dict(scheme="cur", f=4), "ideal"),
-    ("dyn(1,2)+prev", 4, dict(scheme="dyn", a=1, f=2), "prev"),
 ]
 K = 5
 R = 2.0
