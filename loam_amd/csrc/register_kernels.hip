@@ -1031,14 +1031,14 @@ __global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_
  * from the lanes' lists by k + 1 wave-wide minima. That is the collector's own contract — the k + 1 smallest keys of all
  * the candidates examined — so knn_done / knn_keys_finish decide exactly as they do for one lane, and the result is the
  * exact search's (what the keys cannot decide keeps its negative count for the exact collector, as before).
- * W = half-width of the block in cells: 1 for a query that only ran out of running numbers (its block is dense: the
- * usual test against the block's faces decides), else ceil(radius / cell): the whole radius cube, after which nothing
- * unvisited can pass the radius filter. Rows farther than the wave-wide bound (min over the lanes of their own k-th key,
- * a valid bound on the true k-th distance) or than the radius are skipped; inside a row only the cells the radius reaches.
- * Returns kept >= 0, -1 undecided, -2 not applicable (no radius and not a dense block, or a cube of more than
- * kCoopMaxRows rows): the caller falls back to the one-lane search.
+ * The block grows shell by shell as in the one-lane search (knn_rounds): after shell w the wavefront's exact k-th key is
+ * tested against the faces of the visited block (knn_done); the last shell is the cube whose faces lie beyond the radius.
+ * Pieces farther than the bound (the pooled k-th key; within a shell also any lane's own k-th key) or than the radius are
+ * skipped; inside a row only the cells the bound reaches.
+ * Returns kept >= 0, -1 undecided, -2 not applicable (more than kCoopMaxShell shells could be needed): the caller falls
+ * back to the one-lane search.
  * ---------------------------------------------------------------------------------------------- */
-constexpr int kCoopMaxRows = 1024;
+constexpr int32_t kCoopMaxShell = 64;  // shells a cooperative search may walk (a radius of 62 cells; without a radius: grids up to that size)
 
 __device__ __forceinline__ double wave_min_all(double v) {  // (every lane gets the minimum)
 #pragma unroll
@@ -1051,7 +1051,7 @@ __device__ __forceinline__ double wave_min_all(double v) {  // (every lane gets 
 
 template <int KM>
 __device__ __forceinline__ int knn_coop_search(const GridDesc& g, const uint32_t* __restrict__ cell_start, const GridPoint* __restrict__ sp,
-                                               Vec3 q, int k, double max_dist, double pass_max, int32_t w_hint, uint32_t pos[KM]) {
+                                               Vec3 q, int k, double max_dist, double pass_max, uint32_t pos[KM]) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int j = 0; j < KM; j++) pos[j] = 0;
@@ -1060,82 +1060,107 @@ __device__ __forceinline__ int knn_coop_search(const GridDesc& g, const uint32_t
   const int32_t cx = grid_cell_coord(q.x, g.ox, g.inv_h), cy = grid_cell_coord(q.y, g.oy, g.inv_h), cz = grid_cell_coord(q.z, g.oz, g.inv_h);
   const int32_t out = grid_outside_distance(g, cx, cy, cz);
   if (max_dist > 0.0 && out >= 1 && (double)(out - 1) * g.h >= max_dist) return 0;
-  int32_t W = w_hint;  // w_hint >= 1: a block of that half-width is believed to do (its faces are tested); 0: the radius cube
-  if (w_hint < 1 || out > w_hint) {
-    if (!(max_dist > 0.0)) return -2;
-    // (+ 1: the faces of the cube lie strictly beyond the radius whatever the query's place in its cell, so knn_done's
-    // shrunken face distances still reach it; + out: a query outside the grid sits `out` cells off the nearest grid cell)
+  // Shells of growing half-width w, as the one-lane search visits them (knn_rounds): shell 1 = the 3x3x3 block, shell w > 1 =
+  // the cells at Chebyshev distance w. The last shell a radius can need: the cube whose faces lie strictly beyond it
+  // (+ 1: whatever the query's place in its cell; + out: a query outside the grid sits `out` cells off the nearest grid cell).
+  int32_t W = 0x7FFFFFFF;
+  if (max_dist > 0.0) {
     const double wf = ceil(max_dist * g.inv_h) + 1.0 + (double)out;
-    if (!(wf < 64.0)) return -2;
-    W = (int32_t)wf < 1 ? 1 : (int32_t)wf;
+    if (wf < 1.0e6) W = (int32_t)wf;
   }
-  const int32_t D = 2 * W + 1;
-  const int NR = D * D;
-  if (NR > kCoopMaxRows) return -2;
+  if (W > kCoopMaxShell) {  // no radius (or a huge one in cells): only while the grid itself is that small
+    const int32_t span = (g.nx > g.ny ? (g.nx > g.nz ? g.nx : g.nz) : (g.ny > g.nz ? g.ny : g.nz)) + out;
+    if (span > kCoopMaxShell) return -2;
+    W = span;
+  }
   const double r2 = knn_radius_bound(max_dist);
   double bound = r2;  // wave-uniform: nothing farther than this can be among the k kept
   KnnKeys<KM> c;
   knn_init(c, k, g.n_points);
-  // Chunk -1: the nine rows around the query's own (centre, faces, corners), over the whole x extent of the block; then the
-  // other rows of the block, 64 at a time, with the bound the inner rows have left.
-  for (int c0 = -64; c0 < (W > 1 ? NR : 0); c0 += 64) {
-    // ---- lane l owns one row of the block: its slab distance and, for the cells the bound reaches, its range
-    uint32_t rb = 0, re = 0;
-    double s2 = kDblMax;
-    {
-      constexpr int kOrder[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
-      const bool inner_chunk = c0 < 0;
-      const int ri = inner_chunk ? lane : c0 + lane;
-      int32_t dy, dz;
-      if (inner_chunk) dy = kOrder[lane < 9 ? lane : 0] % 3 - 1, dz = kOrder[lane < 9 ? lane : 0] / 3 - 1;
-      else dy = ri % D - W, dz = ri / D - W;
-      const bool mine = inner_chunk ? lane < 9 : (ri < NR && !(dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1));
-      const int32_t iy = cy + dy, iz = cz + dz;
-      if (mine && iy >= 0 && iy <= g.ny - 1 && iz >= 0 && iz <= g.nz - 1) {
-        const double sy = dy == 0 ? 0.0 : slab_dist(q.y, g.oy, g.h, iy), sz = dz == 0 ? 0.0 : slab_dist(q.z, g.oz, g.h, iz);
-        const double rowmin2 = sy * sy + sz * sz;
-        if (rowmin2 <= bound) {
-          int32_t xlo = cx - W < 0 ? 0 : cx - W, xhi = cx + W > g.nx - 1 ? g.nx - 1 : cx + W;
-          if (bound < kDblMax) {  // cells whose x slab is farther than sqrt(bound - rowmin2) cannot contribute (as knn_general_round)
-            const double reach = sqrt(bound - rowmin2) + 1e-9 * g.h;
-            const int32_t xl = grid_cell_coord(q.x - reach, g.ox, g.inv_h), xh = grid_cell_coord(q.x + reach, g.ox, g.inv_h);
-            if (xl > xlo) xlo = xl;
-            if (xh < xhi) xhi = xh;
+  bool done = false;
+  for (int32_t w = 1; w <= W && !done; w++) {
+    // pieces of shell w: the rows at Chebyshev distance w over x in [cx - w, cx + w] (shell 1: all nine rows of the block,
+    // centre first), then for w > 1 the two end cells cx -+ w of every row inside
+    const int ring_rows = w == 1 ? 9 : 8 * w;
+    const int inner_rows = w == 1 ? 0 : (2 * w - 1) * (2 * w - 1);
+    const int pieces = ring_rows + 2 * inner_rows;
+    for (int u0 = 0; u0 < pieces; u0 += 64) {
+      // ---- lane l owns one piece: its distance and, if the bound reaches it, its range
+      uint32_t rb = 0, re = 0;
+      double s2 = kDblMax;
+      {
+        const int u = u0 + lane;
+        int32_t dy = 0, dz = 0, xlo = cx - w, xhi = cx + w;
+        bool cap = false;
+        if (w == 1) {
+          constexpr int kOrder[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
+          const int j = kOrder[u < 9 ? u : 0];
+          dy = j % 3 - 1, dz = j / 3 - 1;
+        } else if (u < ring_rows) {
+          const int side = 2 * w + 1, inner = 2 * w - 1;
+          if (u < side) dy = u - w, dz = -w;
+          else if (u < 2 * side) dy = u - side - w, dz = w;
+          else if (u < 2 * side + inner) dy = -w, dz = u - 2 * side - (w - 1);
+          else dy = w, dz = u - 2 * side - inner - (w - 1);
+        } else {
+          const int v = u - ring_rows, ri = v >> 1, inner = 2 * w - 1;
+          dy = ri % inner - (w - 1), dz = ri / inner - (w - 1);
+          xlo = xhi = (v & 1) ? cx + w : cx - w;
+          cap = true;
+        }
+        const int32_t iy = cy + dy, iz = cz + dz;
+        if (u < pieces && iy >= 0 && iy <= g.ny - 1 && iz >= 0 && iz <= g.nz - 1) {
+          const double sy = dy == 0 ? 0.0 : slab_dist(q.y, g.oy, g.h, iy), sz = dz == 0 ? 0.0 : slab_dist(q.z, g.oz, g.h, iz);
+          double pmin2 = sy * sy + sz * sz;
+          if (cap) {
+            const double sx = slab_dist(q.x, g.ox, g.h, xlo);
+            pmin2 += sx * sx;
           }
-          if (xlo <= xhi) {
-            const uint32_t row = (uint32_t)((iz * g.ny + iy) * g.nx);
-            rb = cell_start_at(cell_start, row + (uint32_t)xlo);
-            re = cell_start_at(cell_start, row + (uint32_t)xhi + 1u);
-            s2 = rowmin2;
+          if (pmin2 <= bound) {
+            if (!cap) {
+              if (xlo < 0) xlo = 0;
+              if (xhi > g.nx - 1) xhi = g.nx - 1;
+              if (bound < kDblMax) {  // cells whose x slab is farther than sqrt(bound - rowmin2) cannot contribute (as knn_general_round)
+                const double reach = sqrt(bound - pmin2) + 1e-9 * g.h;
+                const int32_t xl = grid_cell_coord(q.x - reach, g.ox, g.inv_h), xh = grid_cell_coord(q.x + reach, g.ox, g.inv_h);
+                if (xl > xlo) xlo = xl;
+                if (xh < xhi) xhi = xh;
+              }
+            }
+            if (xlo <= xhi && xlo >= 0 && xhi <= g.nx - 1) {
+              const uint32_t row = (uint32_t)((iz * g.ny + iy) * g.nx);
+              rb = cell_start_at(cell_start, row + (uint32_t)xlo);
+              re = cell_start_at(cell_start, row + (uint32_t)xhi + 1u);
+              s2 = pmin2;
+            }
           }
         }
       }
-    }
-    // ---- the non-empty rows of this chunk, one after the other, 64 candidates at a time
-    unsigned long long rows = __ballot(rb < re);
-    while (rows) {
-      const int b = __ffsll(rows) - 1;
-      rows &= rows - 1;
-      const uint32_t begin = (uint32_t)__builtin_amdgcn_readlane((int)rb, b), end = (uint32_t)__builtin_amdgcn_readlane((int)re, b);
-      const double rs2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s2), b), __builtin_amdgcn_readlane(__double2loint(s2), b));
-      if (rs2 > bound) continue;  // (the bound has moved since the row was listed)
-      for (uint32_t p0 = begin; p0 < end; p0 += 64) {
-        const uint32_t p = p0 + (uint32_t)lane;
-        const bool real = p < end;
-        const GridPoint t = sp[real ? p : begin];
-        const double dx = q.x - t.x, dy = q.y - t.y, dz = q.z - t.z;
-        const double d2 = dx * dx + dy * dy + dz * dz;  // nanoflann L2_Simple, as knn_scan_batch
-        knn_key_insert(c, knn_key_pack(d2, p, c.mask, real));
+      // ---- the non-empty pieces of this turn, one after the other, 64 candidates at a time
+      unsigned long long rows = __ballot(rb < re);
+      while (rows) {
+        const int b = __ffsll(rows) - 1;
+        rows &= rows - 1;
+        const uint32_t begin = (uint32_t)__builtin_amdgcn_readlane((int)rb, b), end = (uint32_t)__builtin_amdgcn_readlane((int)re, b);
+        const double rs2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s2), b), __builtin_amdgcn_readlane(__double2loint(s2), b));
+        if (rs2 > bound) continue;  // (the bound has moved since the piece was listed)
+        for (uint32_t p0 = begin; p0 < end; p0 += 64) {
+          const uint32_t p = p0 + (uint32_t)lane;
+          const bool real = p < end;
+          const GridPoint t = sp[real ? p : begin];
+          const double dx = q.x - t.x, dy = q.y - t.y, dz = q.z - t.z;
+          const double d2 = dx * dx + dy * dy + dz * dz;  // nanoflann L2_Simple, as knn_scan_batch
+          knn_key_insert(c, knn_key_pack(d2, p, c.mask, real));
+        }
+        if (end - begin >= 256u) {  // a populous piece may have moved the bound (a lane with k keys bounds the true k-th distance)
+          const double wb = wave_min_all(knn_bound(c, k));
+          bound = wb < bound ? wb : bound;
+        }
       }
-      if (end - begin >= 32u) {  // a populous row may have moved the bound (a lane with k keys bounds the true k-th distance)
-        const double wb = wave_min_all(knn_bound(c, k));
-        bound = wb < bound ? wb : bound;
-      }
     }
-    if (c0 < 0 && W > 1) {
-      // the inner rows are done: a bound for the rest of the block. Exact: the k-th smallest head over the lanes is not
-      // available cheaply, but any lane that holds k keys bounds it; with fewer than 64 k candidates so far few lanes do, so
-      // the lanes' keys are pooled first — the k smallest of the wavefront, drawn as at the end (on a copy).
+    // ---- is the search over after shell w? The k-th smallest key of the wavefront, drawn from the lanes' lists as at the
+    // end (on a copy), against the faces of the visited block: knn_done's test
+    {
       KnnKeys<KM> cc = c;
       double kth = knn_key_empty();
       for (int t = 0; t < k; t++) {
@@ -1152,12 +1177,18 @@ __device__ __forceinline__ int knn_coop_search(const GridDesc& g, const uint32_t
           cc.key[KM] = knn_key_empty();
         }
       }
-      if (kth < knn_key_empty()) {  // the true d2 of each of the k smallest keys is <= its key with all position bits set
-        const double ub = knn_key_join(knn_key_hi(kth), knn_key_lo(kth) | c.mask);
+      KnnKeys<KM> probe;  // (only slot KM - 1 and the mask are read by knn_bound)
+      probe.mask = c.mask;
+#pragma unroll
+      for (int j = 0; j <= KM; j++) probe.key[j] = kth;
+      if (kth < knn_key_empty()) {
+        const double ub = knn_bound(probe, k);
         bound = ub < bound ? ub : bound;
       }
+      done = knn_done(g, q, k, max_dist, cx, cy, cz, probe, w);  // (wave-uniform)
     }
   }
+  if (!done) return -1;
   // ---- the k + 1 smallest keys of the wavefront: k + 1 times the smallest head of the lanes' lists
   KnnKeys<KM> m;
   knn_init(m, k, g.n_points);
@@ -1178,7 +1209,6 @@ __device__ __forceinline__ int knn_coop_search(const GridDesc& g, const uint32_t
       }
     }
   }
-  if (!knn_done(g, q, k, max_dist, cx, cy, cz, m, W)) return -1;
   return knn_keys_finish(m, k, pass_max, pos);
 }
 
@@ -1212,8 +1242,8 @@ __global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_
     const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
     const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));
     uint32_t pos[KM];
-    int kept = knn_coop_search<KM>(g, cs, sp, p, kq, max_dist, pass_max, hint == 3u ? 1 : (int32_t)hint, pos);
-    if (kept == -1 && hint != 0u) kept = knn_coop_search<KM>(g, cs, sp, p, kq, max_dist, pass_max, 0, pos);  // (the block did not reach far enough after all)
+    (void)hint;  // (what the lean searches found out is what the shells find out again, at one turn each)
+    int kept = knn_coop_search<KM>(g, cs, sp, p, kq, max_dist, pass_max, pos);
     if (kept == -2) {  // uniform
       if ((threadIdx.x & 63) == 0) kept = knn_search_keyed<KM>(g, cs, sp, p, kq, max_dist, pass_max, pos, s_rows, 1);
       kept = __builtin_amdgcn_readfirstlane(kept);
@@ -2215,7 +2245,7 @@ static bool queue_one_stage(const RegBatch& B, const RegConfig& C, bool plane) {
 // a single scan-to-map registration up to half of its queries
 static uint32_t coop_blocks(size_t n_pairs) {
   const size_t want = 32768 / (n_pairs ? n_pairs : 1);
-  return (uint32_t)(want < 32 ? 32 : (want > 8192 ? 8192 : want));
+  return (uint32_t)(want < 32 ? 32 : (want > 4096 ? 4096 : want));
 }
 static uint32_t rest_blocks(size_t n_pairs, uint32_t nblk) {
   const uint32_t cover = nblk * (uint32_t)(kAssocThreads / kRestThreads);  // one pass over a full queue
