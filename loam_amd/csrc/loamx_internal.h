@@ -114,6 +114,7 @@ constexpr uint32_t kRegFlagQueueTwoStage = 32u;  // queue chain: always lean 5x5
 constexpr uint32_t kRegFlagQueueOneStage = 64u;  // queue chain: always the FP64 search over all rounds in one kernel
 constexpr uint32_t kRegFlagForceRccl = 256u;     // a one-rank communicator really enqueues ncclAllGather / ncclBroadcast / ncclAllReduce (host side only)
 constexpr uint32_t kRegFlagNoCoopLeft = 512u;    // listed queue leftovers one lane per query (associate_knn_left_kernel, round 3), not one wavefront per query
+constexpr uint32_t kRegFlagNoRefMoments = 1024u;  // first ICF iteration as in round 3: five sweeps of the records, no moments
 constexpr uint32_t kRegFlagNoMixedAssoc = 128u;  // edge and plane first kernels as separate launches on two streams (launch_associate)
 
 // One target feature set's spatial index (device pointers into the workspace)
@@ -159,6 +160,10 @@ struct PairState {
   uint32_t first_sweep;  // next sweep is the iteration-0 evaluation
   uint32_t stream_planes;  // 1: the next sweep streams this pair's plane records (its moments cannot stand in for them)
   uint32_t use_moments;    // this ICF iteration runs the moment pass for the pair
+  // First ICF iteration (round 4): after its first evaluation (a sweep at the identity update) the moments are taken
+  // relative to the first candidate instead of the identity: mom_ref_on = 1, mom_ref = that candidate (lm_step_pair)
+  uint32_t mom_ref_on;
+  double mom_ref[7];
 };
 
 constexpr int kSweepThreads = 256;
@@ -208,6 +213,7 @@ struct RegBatch {
                                            // sides of kBruteMax, or unknown); 1: grid only; 2: brute force only
   uint32_t assoc_blocks_edge, assoc_blocks_plane;  // workgroups per pair of the association kernels; 0xFFFFFFFF = by capacity
   uint32_t want_nearest;  // 1: a detail hook will read nearest_* (RegistrationDetail pairs); 0: the fit kernels skip that write
+  uint32_t ref_moments;   // 1: the first ICF iteration takes its moments at its first candidate after ONE sweep (enqueue_icf_iteration)
 };
 
 // scratch the multi-workgroup build of a map-sized target set needs per pair (at B.sort_scratch + pair * stride points)

@@ -2138,6 +2138,26 @@ LOAMX_HD bool plane_moments_valid_at(double s0max, double v2max, const double x[
   return s0max + rot * sqrt(v2max) + trans < 0.999;  // (NaN compares false)
 }
 
+// The same relative to a reference candidate r at which every |s_i(r)| <= sref_max is known (first ICF iteration: the
+// moments are taken after the first step, whose motion alone exceeds the bound above):
+// |s_i(x)| <= |s_i(r)| + |pp_i(x) - pp_i(r)|, pp(x) = v + A(x) v + t with A(x) = 2 w [u]x + 2 (u u^T - (u.u) I), hence
+// |pp_i(x) - pp_i(r)| <= |A(x) - A(r)| |v_i| + |t - t_r| and
+// |A(x) - A(r)| <= 2 (|w - w_r| |u| + |w_r| |u - u_r|) + 4 |u - u_r| (|u| + |u_r|)      (|[a]x| = |a|, |a b^T| = |a| |b|).
+LOAMX_HD bool plane_moments_valid_rel(double sref_max, double v2max, const double x[7], const double r[7]) {
+  const double du = sqrt((x[0] - r[0]) * (x[0] - r[0]) + (x[1] - r[1]) * (x[1] - r[1]) + (x[2] - r[2]) * (x[2] - r[2]));
+  const double nu = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]), nr = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  const double rot = 2.0 * (fabs(x[3] - r[3]) * nu + fabs(r[3]) * du) + 4.0 * du * (nu + nr);
+  const double trans = sqrt((x[4] - r[4]) * (x[4] - r[4]) + (x[5] - r[5]) * (x[5] - r[5]) + (x[6] - r[6]) * (x[6] - r[6]));
+  return sref_max + rot * sqrt(v2max) + trans < 0.999;  // (NaN compares false)
+}
+// phi(x) of the comment above: s_i(x) = c_i . phi(x)
+LOAMX_HD void plane_phi(const double x[7], double phi[kMomDim]) {
+  const double ux = x[0], uy = x[1], uz = x[2], w = x[3];
+  phi[0] = 1.0, phi[1] = 2.0 * w * ux, phi[2] = 2.0 * w * uy, phi[3] = 2.0 * w * uz;
+  phi[4] = ux * ux, phi[5] = uy * uy, phi[6] = uz * uz, phi[7] = ux * uy, phi[8] = ux * uz, phi[9] = uy * uz;
+  phi[10] = x[4], phi[11] = x[5], phi[12] = x[6];
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Ceres manifold Plus for the 7 ambient doubles (QuaternionManifold on raw storage read as
  * (W,X,Y,Z), EuclideanManifold<3>)

@@ -621,6 +621,7 @@ __global__ void state_init_kernel(RegBatch B, RegConfig C) {
   S.first_sweep = 0;
   S.stream_planes = 1;
   S.use_moments = 0;
+  S.mom_ref_on = 0;
   S.lm.active = 0;
   for (int c = 0; c < 6; c++) B.assoc.n_assoc[8 * pair + c] = 0;
   if (B.max_counts) {  // the host sizes the association grids by the largest set instead of by the capacity
@@ -1422,6 +1423,7 @@ __global__ __launch_bounds__(64) void lm_begin_kernel(RegBatch B, RegConfig C) {
   }
   lm_init(S.lm);
   S.first_sweep = 1;
+  S.mom_ref_on = 0;  // (the moments of this ICF iteration are taken at the identity update unless lm_step_pair says otherwise)
   if (B.iter_info) {
     loamx_iter_info& I = B.iter_info[pair * C.max_iterations + iteration];
     for (int i = 0; i < 7; i++) I.target_T_source_init[i] = S.est[i];
@@ -1692,11 +1694,24 @@ __device__ __forceinline__ double stream_eval_wave(const RegBatch& B, size_t pai
 __device__ __forceinline__ void lm_step_pair(const RegBatch& B, size_t pair, PairState& S, const double* acc) {
   const double* __restrict__ mom = B.moments + pair * (size_t)(kMomSize + 2);
   LmState lm = S.lm;
-  lm_consume(lm, acc, S.first_sweep != 0);
+  const bool first = S.first_sweep != 0;
+  lm_consume(lm, acc, first);
   S.lm = lm;
   S.first_sweep = 0;
+  if (first && B.ref_moments && !S.use_moments && lm.active) {
+    // First ICF iteration, after its evaluation at the identity update: the rest of the solve runs off moments taken AT the
+    // first candidate (moment_kernel next, then lm_pair_loop_kernel). At the identity the bound of plane_moments_valid_at
+    // fails for every later candidate (the first step moves far points by more than the Huber threshold); relative to the
+    // first candidate the later ones are refinements.
+    S.use_moments = 1u, S.mom_ref_on = 1u;
+    for (int i = 0; i < 7; i++) S.mom_ref[i] = lm.xeval[i];
+    S.stream_planes = 1u;  // (decided by lm_pair_loop_kernel once the moments exist)
+    return;
+  }
   // the next sweep: may the moments stand in for the plane records at the new candidate?
-  S.stream_planes = (!S.use_moments || (lm.active && !plane_moments_valid_at(mom[kMomSize], mom[kMomSize + 1], lm.xeval))) ? 1u : 0u;
+  const bool valid = S.mom_ref_on ? plane_moments_valid_rel(mom[kMomSize], mom[kMomSize + 1], lm.xeval, S.mom_ref)
+                                  : plane_moments_valid_at(mom[kMomSize], mom[kMomSize + 1], lm.xeval);
+  S.stream_planes = (!S.use_moments || (lm.active && !valid)) ? 1u : 0u;
 }
 
 __global__ __launch_bounds__(64) void lm_step_kernel(RegBatch B) {  // one wavefront: the 6x6 solve may use the whole register file
@@ -1802,7 +1817,8 @@ __global__ __launch_bounds__(64) void lm_pair_loop_kernel(RegBatch B, RegConfig 
     for (int c = 0; c < kMomSize / 64; c++) mom[c * 64 + lane] = v[c], s_mom[c * 64 + lane] = v[c];
     if (lane == 0) mom[kMomSize] = s0max, mom[kMomSize + 1] = v2max, s_mom[kMomSize] = s0max, s_mom[kMomSize + 1] = v2max;
     const double ident[7] = {0, 0, 0, 1, 0, 0, 0};
-    stream = plane_moments_valid_at(s0max, v2max, ident) ? 0u : 1u;
+    // (first ICF iteration: the moments were taken at the candidate this loop starts with — S.mom_ref == S.lm.xeval)
+    stream = (S.mom_ref_on ? plane_moments_valid_rel(s0max, v2max, S.lm.xeval, S.mom_ref) : plane_moments_valid_at(s0max, v2max, ident)) ? 0u : 1u;
   }
   if (lane == 0) S.stream_planes = stream;
   uint32_t lm_active = 1u;
@@ -1867,6 +1883,15 @@ __global__ __launch_bounds__(64) void moment_kernel(RegBatch B) {  // one wavefr
   for (int j = kMomDim; j < kMomStride; j++) tile[j][lane] = 0.0;  // padding rows
   v4f64 acc = {0.0, 0.0, 0.0, 0.0};
   double s0max = 0.0, v2max = 0.0;
+  // the candidate the moments are taken at: the identity update (s_i = c_i[0]), or — first ICF iteration — the first candidate
+  const bool ref_on = S.mom_ref_on != 0u;  // uniform
+  double phi_ref[kMomDim];
+  {
+    double xr[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) xr[i] = ref_on ? S.mom_ref[i] : (i == 3 ? 1.0 : 0.0);
+    plane_phi(xr, phi_ref);
+  }
   // the wavefront's own list of flagged slots (a quarter of the workgroup's chunk of capacity), in slot order
   uint32_t* __restrict__ flist = B.flagged_list + ((pair * B.mom_blocks_per_pair + blk) * 4 + wave) * (size_t)(kSweepChunk / 4);
   uint32_t n_flagged = 0;  // uniform in the wavefront
@@ -1893,7 +1918,13 @@ __global__ __launch_bounds__(64) void moment_kernel(RegBatch B) {  // one wavefr
     if (cur.in && cur.f[0] == cur.f[0]) {  // NaN in field 0 marks an invalid slot
       const Vec3 v = v3(cur.f[0], cur.f[1], cur.f[2]);
       plane_coeffs(v, v3(cur.f[3], cur.f[4], cur.f[5]), cur.f[6], c);
-      const double a0 = fabs(c[0]), vv = vdot(v, v);
+      double sref = c[0];
+      if (ref_on) {  // s_i at the reference candidate
+        sref = 0.0;
+#pragma unroll
+        for (int j = 0; j < kMomDim; j++) sref += c[j] * phi_ref[j];
+      }
+      const double a0 = fabs(sref), vv = vdot(v, v);
       // a record that starts far from its plane may reach the Huber threshold: it stays out of the moments and
       // is listed (in slot order) for the sweeps, which evaluate the listed records one by one
       flagged = !(a0 <= kMomInlier);
