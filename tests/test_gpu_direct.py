@@ -186,6 +186,51 @@ def test_associate_fuzz_lists_and_fits(oracle, seed):
         check_kind(oracle, f"plane {seed} {stage}", dump, src_p, tgt_p, pose, True, oreg, ties=tie_p)
 
 
+@pytest.mark.parametrize("case", ["dense", "isolated", "no_radius", "mixed"])
+def test_cooperative_leftover_search_on_the_queries_it_exists_for(oracle, case):
+    """associate_knn_coop_kernel (round 4): one wavefront per listed leftover of the queue. Scenes made of the leftovers it
+    exists for — dense blocks (more than 63 batches in the 3x3x3 block: wide running numbers), isolated queries (the
+    radius cube, shell by shell), a search without a radius (not applicable: lane 0 falls back to the one-lane search),
+    and a mix with exact ties — for k = 5, 8 and 16, against the oracle's KD-tree lists and fits; the one-lane leftover
+    kernel (NO_COOP_LEFT) must produce the same dump."""
+    rng = np.random.default_rng({"dense": 1, "isolated": 2, "no_radius": 3, "mixed": 4}[case])
+    if case == "dense":      # ~25 000 points in a 1.2 m cube inside a 100 m bounding box (three outliers): the cell table's cap
+        # makes the cells 2.5 m wide, so every 3x3x3 block around the cube holds all of it
+        tgt_p = np.concatenate([rng.uniform(-0.6, 0.6, (25000, 3)) + np.array([3.0, -2.0, 1.0]), [[50.0, 50, 50], [-50, -50, -50], [50, -50, 0]]])
+        src_p = tgt_p[rng.choice(len(tgt_p), 1500, replace=False)] + rng.normal(size=(1500, 3)) * 0.01
+        radius = 2.0
+    elif case == "isolated":  # a sparse shell: most queries find fewer than k points within the radius, many none in 5x5x5
+        tgt_p = rng.uniform(-15, 15, (3000, 3))
+        src_p = rng.uniform(-15, 15, (1200, 3))
+        radius = 2.0
+    elif case == "no_radius":
+        tgt_p = rng.uniform(-10, 10, (2500, 3))
+        src_p = rng.uniform(-40, 40, (600, 3))  # (most queries lie cells away from the grid: neither lean search applies)
+        radius = -1.0
+    else:                     # a dense wall, a sparse room, and a lattice (equidistant neighbours)
+        wall = np.column_stack([rng.uniform(-4, 4, 12000), np.full(12000, 5.0) + rng.normal(size=12000) * 0.003, rng.uniform(-1, 2, 12000)])
+        room = rng.uniform(-8, 8, (1500, 3))
+        g = np.stack(np.meshgrid(np.arange(12) * 0.2, np.arange(12) * 0.2, np.arange(12) * 0.2), -1).reshape(-1, 3) + np.array([-6.0, -6.0, -1.0])
+        tgt_p = np.concatenate([wall, room, g])
+        src_p = np.concatenate([wall[::10] + rng.normal(size=(1200, 3)) * 0.01, rng.uniform(-8, 8, (500, 3)), g[::3] + 0.05])
+        radius = 1.5
+    tgt_p, src_p = np.ascontiguousarray(tgt_p), np.ascontiguousarray(src_p)
+    none = np.zeros((0, 3))
+    for k in (5, 8, 16):
+        reg, oreg = capi.RegistrationParams(), oracle.RegParams()
+        reg.num_plane_neighbors = oreg.num_plane_neighbors = k
+        reg.max_plane_neighbor_dist = oreg.max_plane_neighbor_dist = radius
+        with option("QUEUE_TWO_STAGE"):
+            dump = ctx().associate(none, src_p, none, tgt_p, IDENT, reg)
+            with option("NO_COOP_LEFT"):
+                lanes = ctx().associate(none, src_p, none, tgt_p, IDENT, reg)
+        queued, listed = dump["plane"]["queued"]
+        assert queued > 20 and listed > 5, (case, k, queued, listed)  # (the leftover kernel really had work)
+        check_kind(oracle, f"plane coop-{case}-{k}", dump, src_p, tgt_p, IDENT, True, oreg, ties=(case == "mixed"))
+        assert all(np.array_equal(a, b) for a, b in zip(dump["plane"]["nn"], lanes["plane"]["nn"])) or case == "mixed"
+        assert np.array_equal(dump["plane"]["valid"], lanes["plane"]["valid"])
+
+
 def test_fit_entry_points_against_the_oracle(oracle):
     """geometry_internal::fitLine / fitPlane (geometry.h:102, :123) through loamx_fit_lines / loamx_fit_planes: every k
     the reference accepts up to 32, including the k > 8 route the association kernels never take"""
