@@ -704,6 +704,38 @@ void hostcheck_plane_moments(const double* v, const double* n, const double* d, 
   bound_inputs[0] = s0max, bound_inputs[1] = plane_moments_valid_at(s0max, v2max, x) ? 1.0 : 0.0;
 }
 
+// the relative validity bound of the first ICF iteration's moments (plane_moments_valid_rel) and the residuals it speaks about:
+// out[0] = the bound's verdict (1 / 0), out[1] = max |s_i(r)| over the records with |s_i(r)| <= kMomInlier (what moment_kernel
+// hands the bound), out[2] = max |s_i(x)| over the same records (what the bound must keep below the Huber threshold),
+// out[3] = largest |c_i . phi(x) - s_i(x)| (the moment form of a residual against residual_accumulate's own point formula)
+void hostcheck_moments_rel(const double* v, const double* n, const double* d, uint64_t count, const double x[7], const double r[7],
+                           double out[4]) {
+  double phi_x[kMomDim], phi_r[kMomDim];
+  plane_phi(x, phi_x), plane_phi(r, phi_r);
+  double sref_max = 0.0, v2max = 0.0, sx_max = 0.0, form_err = 0.0;
+  auto residual = [](Vec3 vv, Vec3 nn, double dd, const double* xx) {
+    const Vec3 u = v3(xx[0], xx[1], xx[2]);
+    Vec3 uv = vcross(u, vv);
+    uv = vadd(uv, uv);
+    const Vec3 pp = vadd(vadd(vadd(vv, vscale(xx[3], uv)), vcross(u, uv)), v3(xx[4], xx[5], xx[6]));  // as residual_accumulate
+    return vdot(nn, pp) - dd;
+  };
+  for (uint64_t i = 0; i < count; i++) {
+    const Vec3 vv = v3(v[3 * i], v[3 * i + 1], v[3 * i + 2]), nn = v3(n[3 * i], n[3 * i + 1], n[3 * i + 2]);
+    double c[kMomDim];
+    plane_coeffs(vv, nn, d[i], c);
+    double sr = 0.0, sx = 0.0;
+    for (int j = 0; j < kMomDim; j++) sr += c[j] * phi_r[j], sx += c[j] * phi_x[j];
+    form_err = std::max(form_err, fabs(sx - residual(vv, nn, d[i], x)));
+    if (!(fabs(sr) <= kMomInlier)) continue;  // flagged: stays out of the moments
+    sref_max = std::max(sref_max, fabs(sr));
+    v2max = std::max(v2max, vdot(vv, vv));
+    sx_max = std::max(sx_max, fabs(residual(vv, nn, d[i], x)));
+  }
+  out[0] = plane_moments_valid_rel(sref_max, v2max, x, r) ? 1.0 : 0.0;
+  out[1] = sref_max, out[2] = sx_max, out[3] = form_err;
+}
+
 int hostcheck_register(const double* src_edge, uint64_t n_se, const double* src_planar, uint64_t n_sp,
                        const double* tgt_edge, uint64_t n_te, const double* tgt_planar, uint64_t n_tp,
                        const double init[7], const loamx_reg_params* prm, loamx_reg_result* out,

@@ -217,3 +217,11 @@ def plane_moments(v, n, d, x):
     a, b, bi = np.zeros(30), np.zeros(30), np.zeros(2)
     lib().hostcheck_plane_moments(_dp(v), _dp(n), _dp(d), C.c_uint64(len(d)), _dp(x), _dp(a), _dp(b), _dp(bi))
     return a[:29], b[:29], bi[0], bool(bi[1])
+
+
+def moments_rel(v, n, d, x, r):
+    """(bound says valid, max |s_i(r)| over unflagged records, max |s_i(x)| over them, largest moment-form error)"""
+    v, n, d, x, r = (np.ascontiguousarray(a, dtype=np.float64) for a in (v, n, d, x, r))
+    out = np.zeros(4)
+    lib().hostcheck_moments_rel(_dp(v), _dp(n), _dp(d), C.c_uint64(len(d)), _dp(x), _dp(r), _dp(out))
+    return bool(out[0]), float(out[1]), float(out[2]), float(out[3])

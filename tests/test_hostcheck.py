@@ -235,6 +235,53 @@ def test_plane_moments_equal_per_record_sums():
     assert not Hc.plane_moments(v, n, d2, [0, 0, 0, 1, 0, 0, 0])[3]
 
 
+def test_relative_moment_bound_is_rigorous():
+    """plane_moments_valid_rel (round 4: the first ICF iteration's moments are taken at its first candidate r): whenever it
+    says yes for a candidate x, every record the moments hold (|s_i(r)| <= 0.5) has |s_i(x)| below the Huber threshold — on
+    random records, reference candidates of the size of a first LOAM update (<= 0.1 rad, <= 0.5 m), refinements and wild
+    steps around them, unit and slightly non-unit quaternions. And it is not vacuous: it says yes for the refinements a
+    solve really makes. The moment form c_i . phi(x) of a residual agrees with the point formula to rounding."""
+    rng = np.random.default_rng(5)
+    said_yes = said_no = 0
+    for trial in range(400):
+        N = 400
+        v = rng.normal(size=(N, 3)) * rng.uniform(2, 15)
+        n = rng.normal(size=(N, 3))
+        n /= np.linalg.norm(n, axis=1)[:, None]
+
+        def quat(angle, scale=1.0):
+            ax = rng.normal(size=3)
+            ax /= np.linalg.norm(ax)
+            return np.concatenate([np.sin(angle / 2) * ax, [np.cos(angle / 2)]]) * scale
+
+        r = np.concatenate([quat(rng.uniform(0, 0.1), rng.choice([1.0, 1.0 + 1e-6, 0.9999])), rng.normal(size=3) * rng.uniform(0, 0.3)])
+        # planes through the points as moved by r, give or take the noise of a scan: small residuals AT r, large ones at 0
+        u, w = r[:3], r[3]
+        t = 2.0 * np.cross(u, v)
+        moved = v + w * t + np.cross(u, t) + r[4:]
+        d = (moved * n).sum(1) + rng.normal(size=N) * rng.choice([0.01, 0.05, 0.3])
+        kind = trial % 3
+        if kind == 0:    # a refinement of r
+            dq = quat(rng.uniform(0, 0.01))
+            x = np.concatenate([r[:4] + dq[:4] * 0 + rng.normal(size=4) * rng.uniform(0, 3e-3), r[4:] + rng.normal(size=3) * rng.uniform(0, 0.03)])
+        elif kind == 1:  # anything between the identity and twice r
+            s_ = rng.uniform(0, 2)
+            x = np.array([0, 0, 0, 1.0, 0, 0, 0]) * (1 - s_) + r * s_
+        else:            # r itself
+            x = r.copy()
+        ok, sref, sx, form_err = Hc.moments_rel(v, n, d, x, r)
+        assert form_err <= 1e-9 * (1.0 + np.abs(v).max() ** 2)
+        assert sref <= 0.5
+        if ok:
+            said_yes += 1
+            assert sx < 1.0, (trial, sref, sx)
+        else:
+            said_no += 1
+        if kind == 2:
+            assert ok  # at the reference itself the bound is max |s_i(r)| <= 0.5
+    assert said_yes > 150 and said_no > 30, (said_yes, said_no)
+
+
 @pytest.mark.parametrize("case", K.REGISTRATION_CASES, ids=lambda c: c["name"])
 def test_registration_math_on_reference_scenes(oracle, case):
     tgt_e, tgt_p = K.registration_scene()
