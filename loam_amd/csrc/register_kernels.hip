@@ -969,13 +969,7 @@ __global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_
         kept = knn_search_keyed<KM>(g, cs, sp, p, kq, max_dist, pass_max, pos, s_rows + threadIdx.x, kRestThreads);
     }
     rnn[slot] = (uint32_t)kept;
-    // (one stage: counted only. Two stages: the top bits say how far the leftover's search has to reach — 1: the keys of the
-    // 3x3x3 block tied, 2: the 5x5x5 block's tied or it held more than 63 batches, 3: a dense 3x3x3 block (wide running numbers),
-    // 0: not even the 5x5x5 block held k points closer than its faces: the radius cube)
-    if (kept < 0) {
-      const uint32_t hint = (entry & kQueueTied) ? 1u : ((entry & kQueueWide) ? 3u : (kept == -1 ? 0u : 2u));
-      left[atomicAdd(&B.assoc.n_assoc[8 * pair + (PLANE ? 5 : 4)], 1u)] = t | (hint << 30);
-    }
+    if (kept < 0) left[atomicAdd(&B.assoc.n_assoc[8 * pair + (PLANE ? 5 : 4)], 1u)] = t;  // (one stage: counted only)
 #pragma unroll
     for (int j = 0; j < KM; j++) rnn[(1 + j) * field + slot] = pos[j];
   }
@@ -1008,7 +1002,7 @@ __global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_
   const uint32_t t0 = spread ? chunk0 + blocks_per_pair * threadIdx.x : chunk0 * kRestThreads + threadIdx.x;
   const uint32_t dt = spread ? 0xFFFFFFFFu - t0 : blocks_per_pair * kRestThreads;
   for (uint32_t t = t0; t < listed; t += dt) {
-    const uint32_t qpos = left[t] & kQueueIndex, i = rest[qpos] & kQueueIndex;
+    const uint32_t qpos = left[t], i = rest[qpos] & kQueueIndex;
     const size_t slot = pair * stride + qpos;
     const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
     const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));
@@ -1238,12 +1232,11 @@ __global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_
   const int kq = PLANE ? C.k_plane : C.k_edge;
   const double max_dist = PLANE ? C.r_plane : C.r_edge, pass_max = PLANE ? C.pass_plane : C.pass_edge;
   for (uint32_t t = chunk0; t < listed; t += blocks_per_pair) {  // (wave-uniform: one entry per wavefront and turn)
-    const uint32_t listed_entry = left[t], qpos = listed_entry & kQueueIndex, hint = listed_entry >> 30, i = rest[qpos] & kQueueIndex;
+    const uint32_t qpos = left[t], i = rest[qpos] & kQueueIndex;
     const size_t slot = pair * stride + qpos;
     const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
     const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));
     uint32_t pos[KM];
-    (void)hint;  // (what the lean searches found out is what the shells find out again, at one turn each)
     int kept = knn_coop_search<KM>(g, cs, sp, p, kq, max_dist, pass_max, pos);
     if (kept == -2) {  // uniform
       if ((threadIdx.x & 63) == 0) kept = knn_search_keyed<KM>(g, cs, sp, p, kq, max_dist, pass_max, pos, s_rows, 1);
