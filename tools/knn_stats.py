@@ -38,7 +38,10 @@ def main():
                                 C.c_double(R), cand.ctypes.data_as(C.POINTER(C.c_uint32)),
                                 rows.ctypes.data_as(C.POINTER(C.c_uint32)), grid.ctypes.data_as(C.POINTER(C.c_double)),
                                 blockpts.ctypes.data_as(C.POINTER(C.c_uint32)))
-        print(f"{name}: {len(tgt)} targets, {len(src)} queries, grid {grid[:3].astype(int)} h={grid[3]:.3f} R={R}")
+        general = rows >> 16  # (hostcheck packs the number of general rounds into the upper half)
+        rows = rows & 0xFFFF
+        print(f"{name}: {len(tgt)} targets, {len(src)} queries, grid {grid[:3].astype(int)} h={grid[3]:.3f} R={R}; "
+              f"{(general > 0).mean() * 100:.1f} % of the queries need rounds beyond the 3x3x3 block")
         print("  candidates/query: mean %.1f median %d p90 %d p99 %d max %d" % (
             cand.mean(), np.median(cand), np.percentile(cand, 90), np.percentile(cand, 99), cand.max()))
         print("  rows/query: mean %.2f" % rows.mean())
