@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libloamx.so")
 SOURCES = ["loamx_api.hip", "extract_kernels.hip", "register_kernels.hip", "synth_kernels.hip"]
-HEADERS = ["loamx_internal.h", "extract_math.h", "reg_math.h", "synth.h", os.path.join("..", "..", "include", "loamx.h")]
+HEADERS = ["loamx_internal.h", "extract_math.h", "select_rows.h", "reg_math.h", "synth.h", os.path.join("..", "..", "include", "loamx.h")]
 # -ffp-contract=off: the reference's x86-64 build has no FMA; curvature bits must match
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 

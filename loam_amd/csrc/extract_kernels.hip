@@ -906,6 +906,8 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
   (void)select_line<R, TWO>(lane, line, W, CH, ch_magic, s_c, m_c, m_i, V, P, st, fz);
 }
 
+#include "select_rows.h"
+
 /* ------------------------------------------------------------------------------------------------
  * extract_fused_kernel — rows a5-a10 in ONE pass over the scan (round 2): curvature + validity, selection and
  * compaction without the 9 B/point of curvature / mask ever reaching HBM.
@@ -1127,6 +1129,30 @@ static void launch_select_mis(const double* d_curv, const uint8_t* d_mask, size_
   else launch_select_mis2<R, false>(d_curv, d_mask, n_lines, P, st, fz, s);
 }
 
+// Four scan lines per wavefront (select_rows.h) where the parameters allow; false: nothing was launched.
+template <int R>
+static void launch_select_rows_r(const double* d_curv, const uint8_t* d_mask, size_t n_lines, const ExtractParams& P, const ExtractStage& st,
+                                 const ExtractFused& fz, const RowSelGeom& G, hipStream_t s) {
+  const dim3 grid((unsigned)((n_lines + 15) / 16));
+  if (R == 2 && G.ch == 11)
+    launch_kernel((select_rows_kernel<R, R == 2 ? 11 : 0>), grid, dim3(256), (size_t)G.bytes * 4, s, d_curv, d_mask, n_lines, P, st, fz, G);
+  else
+    launch_kernel((select_rows_kernel<R, 0>), grid, dim3(256), (size_t)G.bytes * 4, s, d_curv, d_mask, n_lines, P, st, fz, G);
+}
+static bool launch_select_rows(const double* d_curv, const uint8_t* d_mask, size_t n_lines, const ExtractParams& P, const ExtractStage& st,
+                               const ExtractFused& fz, hipStream_t s) {
+  RowSelGeom G;
+  if (!row_select_geom(P, G) || (reinterpret_cast<uintptr_t>(d_mask) & 15u) != 0 || n_lines % 4 != 0) return false;
+  if (fz.fuse && P.W > 65535) return false;
+  switch ((int)P.np - 1) {
+    case 1: launch_select_rows_r<1>(d_curv, d_mask, n_lines, P, st, fz, G, s); break;
+    case 2: launch_select_rows_r<2>(d_curv, d_mask, n_lines, P, st, fz, G, s); break;
+    case 3: launch_select_rows_r<3>(d_curv, d_mask, n_lines, P, st, fz, G, s); break;
+    default: launch_select_rows_r<4>(d_curv, d_mask, n_lines, P, st, fz, G, s); break;
+  }
+  return true;
+}
+
 bool launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, const ExtractParams& P,
                    const ExtractStage& st, const ExtractFused* fused, hipStream_t s) {
   const size_t n_lines = n_scans * P.H;
@@ -1143,6 +1169,7 @@ bool launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, 
   const uint32_t picks = (longest + R) / (R + 1);  // most picks a sector can yield
   const bool mis_ok = R >= 1 && R <= 4 && CH >= R && CH + 2 * R <= 64 &&
                       (picks <= 64 || (picks <= 128 && P.cap_edge <= 64 && P.cap_planar <= 64));
+  if (!(P.flags & (kFlagNoMisSelect | kFlagNoRowSelect)) && launch_select_rows(d_curv, d_mask, n_lines, P, st, fz, s)) return fuse;
   if (mis_ok && !(P.flags & kFlagNoMisSelect)) {
     switch (R) {
       case 1: launch_select_mis<1>(d_curv, d_mask, n_lines, P, st, fz, s); return fuse;

@@ -38,7 +38,8 @@ enum : uint32_t {
   kFlagCurvV1 = 4u,          // one-column curvature kernel instead of curvature_valid2_kernel<3>
   kFlagNoFusedCompact = 8u,  // selection writes stage + counts only, compact_kernel gathers
   kFlagNoMisSelect = 16u,    // arg-max fallback select_kernel for every scan
-  kFlagFusedExtract = 32u    // one-pass extract_fused_kernel where the parameters allow
+  kFlagFusedExtract = 32u,   // one-pass extract_fused_kernel where the parameters allow
+  kFlagNoRowSelect = 64u     // one scan line per wavefront (select_mis_kernel) instead of four (select_rows_kernel)
 };
 
 // features-inl.h:66-67 / features.cpp:22: col < np || col >= W - np in size_t arithmetic.
