@@ -33,7 +33,8 @@ struct RowSelGeom {
   uint32_t pitch;      // doubles per row of the curvature buffer (odd: rows fall on different banks)
   uint32_t vw;         // dwords per row of the validity bits
   uint32_t cap_e, cap_p;  // picks kept per sector at most (<= 64)
-  uint32_t pk_stride;  // uint16 entries per row of the pick lists: S * (cap_e + cap_p)
+  uint32_t pk_stride;  // entries per row of the pick lists: S * (cap_e + cap_p)
+  uint32_t pk8;        // 1: the lists hold bytes (a sector position fits), 0: 16-bit words
   uint32_t off_vb, off_sl, off_tk, off_pk, off_cnt;  // byte offsets inside a wavefront's LDS block
   uint32_t bytes;      // LDS bytes per wavefront (multiple of 16)
   int32_t kbase_e, kbase_p;  // hi-word bases of the 32-bit keys
@@ -57,12 +58,14 @@ __host__ inline bool row_select_geom(const ExtractParams& P, RowSelGeom& G) {
   auto up16 = [](uint32_t x) { return (x + 15u) & ~15u; };
   uint32_t o = up16(4 * G.pitch * 8);
   G.off_vb = o, o = up16(o + 4 * G.vw * 4);
-  G.off_sl = o, o = up16(o + 4 * 64 * 8);
+  G.off_sl = o, o = up16(o + 4 * 64 * 4);
   G.off_tk = o, o = up16(o + 4 * 8);
-  G.off_pk = o, o = up16(o + 4 * G.pk_stride * 2);
+  G.pk8 = G.ib <= 8 ? 1u : 0u;
+  G.off_pk = o, o = up16(o + 4 * G.pk_stride * (G.pk8 ? 1 : 2));
   G.off_cnt = o, o = up16(o + 4 * 32 * 2);
   G.bytes = o;
   if (G.bytes * 4 > 64 * 1024) return false;
+  if (24 * longest + 64 * 24 > G.off_sl) return false;  // the copy phase's buffers (a sector's points + 64 picked points) reuse the curvature buffer
   // keys: kb = 32 - ib bits of (hi word - base). Planar candidates lie below their threshold: the top of the range is
   // the threshold's hi word; edge candidates lie above theirs: the bottom of the range is the threshold's hi word.
   auto hi_word = [](double v) {
@@ -261,20 +264,23 @@ struct RowSelCtx {  // per-lane constants of a wavefront's four lines
   int CH, W;
   uint32_t cm;          // the CH own bits of a lane
   const double* cp;     // LDS: curvature at sector position l * CH - R (window value 0)
-  uint32_t* sl;         // LDS: the row's 64 key slots (8 bytes each)
+  const double* crow;   // LDS: curvature at sector position -R of my row
+  uint32_t* sl;         // LDS: the row's 64 key slots (4 bytes each)
   uint32_t* tk;         // LDS: the row's cap threshold key (8 bytes)
-  uint16_t* pk;         // LDS: the row's pick lists
-  uint32_t ib;
+  uint32_t ib, pk8;     // bits of a sector position; pick lists hold bytes (1) or 16-bit words (0)
   int32_t kbase_e, kbase_p, kmax;
 };
 
 // One pass (edge or planar) over the current sector of the four lines. V: validity of the lane's CH points (bit j =
 // sector position l * CH + j), T: candidates by threshold, sm: positions inside the sector. Returns the picks kept by the
 // lane's row; tie: row-uniform, set when std::sort's order on equal curvatures could decide something.
-template <int R, bool EDGE>
+// hiw: (compile-time CH) the hi words of the lane's own CH curvatures, in registers: the keys of all own points are then
+// built up front by straight code instead of one dependent LDS read per pick. pk_list: the row's pick list of this
+// (sector, kind): sector positions of the kept picks in output order.
+template <int R, bool EDGE, int CHT>
 __device__ __forceinline__ uint32_t row_pass(const RowSelCtx& X, uint32_t& V, uint32_t T, uint32_t sm, const uint32_t gt[R],
                                              const uint32_t eqm[R], bool have_eq, bool& tie, uint32_t cap, int start,
-                                             uint32_t line_base, uint32_t* __restrict__ stage, uint16_t* pk_list) {
+                                             uint32_t line_base, uint32_t* __restrict__ stage, void* pk_list, const int32_t* hiw) {
   const int l = X.l, CH = X.CH;
   uint32_t U = V & T & sm;
   if (__ballot(U != 0) == 0) return 0;
@@ -307,19 +313,30 @@ __device__ __forceinline__ uint32_t row_pass(const RowSelCtx& X, uint32_t& V, ui
   const uint32_t kept = total < cap ? total : cap;  // features-inl.h:155 / :177: at most max + 1 picks
   const uint32_t pmask = (1u << X.ib) - 1u;
   const int32_t kbase = EDGE ? X.kbase_e : X.kbase_p;
-  // 32-bit key of the pick at own bit j
-  auto key32 = [&](int j) -> uint32_t {
-    const int32_t hi = reinterpret_cast<const int32_t*>(X.cp)[2 * (j + R) + 1];
+  // 32-bit key of the own point j from the hi word of its curvature
+  auto make_key = [&](int32_t hi, int j) -> uint32_t {
     int32_t kx = hi - kbase;
     kx = kx < 0 ? 0 : (kx > X.kmax ? X.kmax : kx);
     const uint32_t k = ((uint32_t)kx << X.ib) | (uint32_t)(l * CH + j);
     return EDGE ? ~k : k;
   };
+  auto key32 = [&](int j) -> uint32_t { return make_key(reinterpret_cast<const int32_t*>(X.cp)[2 * (j + R) + 1], j); };
+  auto put_pick = [&](uint32_t q, uint32_t pos) {  // kept pick of output rank q at sector position pos
+    stage[q] = line_base + (uint32_t)start + pos;
+    if (X.pk8) static_cast<uint8_t*>(pk_list)[q] = (uint8_t)pos;
+    else static_cast<uint16_t*>(pk_list)[q] = (uint16_t)pos;
+  };
   uint32_t K = Pk;
   bool undecided;
   {
     uint32_t slot = incl - cnt;
-    for (uint32_t bits = Pk; bits; bits &= bits - 1) X.sl[slot++] = key32(__ffs((int)bits) - 1);
+    if constexpr (CHT != 0) {
+#pragma unroll
+      for (int j = 0; j < CHT; j++)
+        if ((Pk >> j) & 1u) X.sl[slot++] = make_key(hiw[j], j);
+    } else {
+      for (uint32_t bits = Pk; bits; bits &= bits - 1) X.sl[slot++] = key32(__ffs((int)bits) - 1);
+    }
     wave_lds_sync();
     const uint4 kv = *reinterpret_cast<const uint4*>(X.sl + 4 * l);
     wave_lds_sync();
@@ -336,13 +353,8 @@ __device__ __forceinline__ uint32_t row_pass(const RowSelCtx& X, uint32_t& V, ui
     if (!undecided) {
       const uint32_t kk[4] = {k0, k1, k2, k3};
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        if (q0 + (uint32_t)r < kept) {
-          const uint32_t col = (uint32_t)start + ((EDGE ? ~kk[r] : kk[r]) & pmask);
-          stage[q0 + r] = line_base + col;
-          pk_list[q0 + r] = (uint16_t)col;
-        }
-      }
+      for (int r = 0; r < 4; r++)
+        if (q0 + (uint32_t)r < kept) put_pick(q0 + r, (EDGE ? ~kk[r] : kk[r]) & pmask);
       if (__ballot(kept < total) != 0) {  // the cap binds in some row: its picks after the last kept one do not suppress
 #pragma unroll
         for (int r = 0; r < 4; r++)
@@ -350,10 +362,17 @@ __device__ __forceinline__ uint32_t row_pass(const RowSelCtx& X, uint32_t& V, ui
         wave_lds_sync();
         if (kept < total) {
           const uint32_t tk = X.tk[0];
-          K = 0;
-          for (uint32_t bits = Pk; bits; bits &= bits - 1) {
-            const int j = __ffs((int)bits) - 1;
-            if (key32(j) <= tk) K |= 1u << j;
+          if constexpr (CHT != 0) {
+            uint32_t le = 0;
+#pragma unroll
+            for (int j = 0; j < CHT; j++) le |= (uint32_t)(make_key(hiw[j], j) <= tk) << j;
+            K = Pk & le;
+          } else {
+            K = 0;
+            for (uint32_t bits = Pk; bits; bits &= bits - 1) {
+              const int j = __ffs((int)bits) - 1;
+              if (key32(j) <= tk) K |= 1u << j;
+            }
           }
         }
         wave_lds_sync();
@@ -364,27 +383,28 @@ __device__ __forceinline__ uint32_t row_pass(const RowSelCtx& X, uint32_t& V, ui
     // ---- the exact pass: curvature and position folded into one double (low IB mantissa bits replaced by the position;
     // edge keys negated, padding = +inf), as select_mis_kernel sorts. Picks whose truncated curvatures still collide, or a
     // pick that is not finite: the order among them is std::sort's — the line is replayed (tie).
-    auto key64 = [&](int j, bool& finite) -> double {
-      const double c = X.cp[j + R];
+    auto key64 = [&](uint32_t pos, bool& finite) -> double {  // pos: sector position
+      const double c = X.crow[pos + R];
       finite = c <= 1.7976931348623157e308;
-      const double k = __hiloint2double(__double2hiint(c), (int)(((uint32_t)__double2loint(c) & ~pmask) | (uint32_t)(l * CH + j)));
+      const double k = __hiloint2double(__double2hiint(c), (int)(((uint32_t)__double2loint(c) & ~pmask) | pos));
       return EDGE ? -k : k;
     };
-    double* sl64 = reinterpret_cast<double*>(X.sl);
-    bool all_finite = true;
     {
       uint32_t slot = incl - cnt;
-      for (uint32_t bits = Pk; bits; bits &= bits - 1) {
-        bool fin;
-        sl64[slot++] = key64(__ffs((int)bits) - 1, fin);
-        all_finite = all_finite && fin;
-      }
+      for (uint32_t bits = Pk; bits; bits &= bits - 1) X.sl[slot++] = (uint32_t)(l * CH + __ffs((int)bits) - 1);
     }
     wave_lds_sync();
     const uint32_t q0 = 4u * (uint32_t)l;
+    const uint4 pv = *reinterpret_cast<const uint4*>(X.sl + 4 * l);
+    const uint32_t pp[4] = {pv.x, pv.y, pv.z, pv.w};
     double key[4];
+    bool all_finite = true;
 #pragma unroll
-    for (int r = 0; r < 4; r++) key[r] = q0 + (uint32_t)r < total ? sl64[q0 + r] : __builtin_huge_val();
+    for (int r = 0; r < 4; r++) {
+      bool fin = true;
+      key[r] = q0 + (uint32_t)r < total ? key64(pp[r], fin) : __builtin_huge_val();
+      all_finite = all_finite && fin;
+    }
     wave_lds_sync();
     row_sort64_f64(key, n2, l);
     auto same = [&](double a, double b) {
@@ -395,13 +415,8 @@ __device__ __forceinline__ uint32_t row_pass(const RowSelCtx& X, uint32_t& V, ui
                       (q0 + 3 < total && same(key[2], key[3])) || (q0 + 4 < total && same(key[3], nx));
     if (row_any(coll, X.lane)) tie = true;  // (the values written below are then unused: replay_kernel rewrites the line)
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      if (q0 + (uint32_t)r < kept) {
-        const uint32_t col = (uint32_t)start + ((uint32_t)__double2loint(key[r]) & pmask);
-        stage[q0 + r] = line_base + col;
-        pk_list[q0 + r] = (uint16_t)col;
-      }
-    }
+    for (int r = 0; r < 4; r++)
+      if (q0 + (uint32_t)r < kept) put_pick(q0 + r, (uint32_t)__double2loint(key[r]) & pmask);
     if (__ballot(kept < total) != 0) {
       double* tk64 = reinterpret_cast<double*>(X.tk);
 #pragma unroll
@@ -414,7 +429,7 @@ __device__ __forceinline__ uint32_t row_pass(const RowSelCtx& X, uint32_t& V, ui
         for (uint32_t bits = Pk; bits; bits &= bits - 1) {
           const int j = __ffs((int)bits) - 1;
           bool fin;
-          if (key64(j, fin) <= tk) K |= 1u << j;
+          if (key64((uint32_t)(l * CH + j), fin) <= tk) K |= 1u << j;
         }
       }
       wave_lds_sync();
@@ -429,7 +444,7 @@ __device__ __forceinline__ uint32_t row_pass(const RowSelCtx& X, uint32_t& V, ui
 // CHT: points per lane as a compile-time constant (11 for 64 x 1024 / 6 sectors: the loops over a lane's points unroll),
 // 0 = G.ch.
 template <int R, int CHT>
-__global__ __launch_bounds__(256) void select_rows_kernel(const double* __restrict__ curv, const uint8_t* __restrict__ mask, size_t n_lines,
+__global__ __launch_bounds__(256, 4) void select_rows_kernel(const double* __restrict__ curv, const uint8_t* __restrict__ mask, size_t n_lines,
                                                           ExtractParams P, ExtractStage st, ExtractFused fz, RowSelGeom G) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row = lane >> 4, l = lane & 15;
@@ -444,10 +459,11 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const double* __restri
   X.lane = lane, X.row = row, X.l = l, X.CH = CH, X.W = W;
   X.cm = (1u << CH) - 1u;
   X.cp = cbuf + (size_t)row * G.pitch + l * CH;
-  X.sl = reinterpret_cast<uint32_t*>(blk + G.off_sl) + row * 128;
+  X.crow = cbuf + (size_t)row * G.pitch;
+  X.sl = reinterpret_cast<uint32_t*>(blk + G.off_sl) + row * 64;
   X.tk = reinterpret_cast<uint32_t*>(blk + G.off_tk) + row * 2;
-  X.pk = reinterpret_cast<uint16_t*>(blk + G.off_pk) + (size_t)row * G.pk_stride;
-  X.ib = G.ib, X.kbase_e = G.kbase_e, X.kbase_p = G.kbase_p, X.kmax = (int32_t)((1u << (32 - G.ib)) - 1u);
+  unsigned char* pk_row = blk + G.off_pk + ((size_t)row * G.pk_stride << (G.pk8 ? 0 : 1));
+  X.ib = G.ib, X.pk8 = G.pk8, X.kbase_e = G.kbase_e, X.kbase_p = G.kbase_p, X.kmax = (int32_t)((1u << (32 - G.ib)) - 1u);
   uint16_t* cnt = reinterpret_cast<uint16_t*>(blk + G.off_cnt) + row * 32;  // picks kept per (sector, kind) of my line
   const size_t line = line0 + row;
 #ifdef LOAMX_ROWS_PROFILE
@@ -463,6 +479,21 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const double* __restri
 #define ROWS_STAMP(i)
 #endif
 
+  const double kNaN = __longlong_as_double(0x7FF8000000000000ll);
+  // curvature at staged position lane + 64 i of (sector s, row rr); line ends and positions outside the line are never
+  // valid: NaN keeps them out of every comparison
+  auto fetch_curv = [&](uint32_t s, int rr, int i) -> double {
+    const int col = (int)(s * P.pps) + lane + 64 * i - R;
+    return (lane + 64 * i < BLu && col >= np && col + np < W) ? curv[(line0 + rr) * (size_t)W + col] : kNaN;
+  };
+  constexpr int NL = CHT ? (16 * CHT + 3 * R + 63) / 64 : 1;
+  double pre[4][NL];
+  if constexpr (CHT != 0) {
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+      for (int i = 0; i < NL; i++) pre[rr][i] = fetch_curv(0, rr, i);
+  }
   // ---- validity bytes (0 / 1, written by the curvature kernels) -> one bit per point
   for (int rr = 0; rr < 4; rr++) {
     const uint8_t* __restrict__ mrow = mask + (line0 + rr) * (size_t)W;
@@ -479,21 +510,6 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const double* __restri
   uint32_t tot_e = 0, tot_p = 0;  // picks of my row's line so far
   bool tie = false;               // row-uniform
   const double thr_e = P.edge_thr, thr_p = P.planar_thr;
-  const double kNaN = __longlong_as_double(0x7FF8000000000000ll);
-  // curvature at staged position lane + 64 i of (sector s, row rr); line ends and positions outside the line are never
-  // valid: NaN keeps them out of every comparison
-  auto fetch_curv = [&](uint32_t s, int rr, int i) -> double {
-    const int col = (int)(s * P.pps) + lane + 64 * i - R;
-    return (lane + 64 * i < BLu && col >= np && col + np < W) ? curv[(line0 + rr) * (size_t)W + col] : kNaN;
-  };
-  constexpr int NL = CHT ? (16 * CHT + 3 * R + 63) / 64 : 1;
-  double pre[4][NL];
-  if constexpr (CHT != 0) {
-#pragma unroll
-    for (int rr = 0; rr < 4; rr++)
-#pragma unroll
-      for (int i = 0; i < NL; i++) pre[rr][i] = fetch_curv(0, rr, i);
-  }
   for (uint32_t s = 0; s < P.S; s++) {
     const int start = (int)(s * P.pps);
     const int len = (s == P.S - 1) ? W - start : (int)P.pps;  // features-inl.h:31-35
@@ -519,6 +535,7 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const double* __restri
     ROWS_STAMP(1)
     // ---- the lane's comparison masks. Window bit t <-> sector position l * CH - R + t; own bit j <-> window bit j + R.
     uint32_t gt[R], eqm[R], ET = 0, PT = 0;
+    int32_t hiw[CHT ? CHT : 1];  // (compile-time CH) hi words of my own curvatures: the sort keys come from them
     bool anyeq = false;
 #pragma unroll
     for (int d = 0; d < R; d++) gt[d] = 0, eqm[d] = 0;
@@ -534,7 +551,10 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const double* __restri
           push_gt(gt[d - 1], w[0], w[d]);
           anyeq = anyeq || w[0] == w[d];
         }
-        if (t >= R && t < R + CH) push_gt(ET, w[0], thr_e), push_lt(PT, w[0], thr_p);
+        if (t >= R && t < R + CH) {
+          push_gt(ET, w[0], thr_e), push_lt(PT, w[0], thr_p);
+          if constexpr (CHT != 0) hiw[t - R] = __double2hiint(w[0]);
+        }
 #pragma unroll
         for (int d = R; d >= 1; d--) w[d] = w[d - 1];
       }
@@ -557,11 +577,11 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const double* __restri
     nb = nb < 0 ? 0 : (nb > CH ? CH : nb);
     const uint32_t sm = (1u << nb) - 1u;
     const size_t group = line * P.S + s;
-    uint16_t* pk_s = X.pk + s * (G.cap_e + G.cap_p);
-    const uint32_t ne = row_pass<R, true>(X, V, ET, sm, gt, eqm, have_eq, tie, G.cap_e, start, line_base, st.edge_stage + group * P.cap_edge, pk_s);
+    unsigned char* pk_s = pk_row + ((size_t)s * (G.cap_e + G.cap_p) << (G.pk8 ? 0 : 1));
+    const uint32_t ne = row_pass<R, true, CHT>(X, V, ET, sm, gt, eqm, have_eq, tie, G.cap_e, start, line_base, st.edge_stage + group * P.cap_edge, pk_s, hiw);
     ROWS_STAMP(3)
-    const uint32_t npl = row_pass<R, false>(X, V, PT, sm, gt, eqm, have_eq, tie, G.cap_p, start, line_base, st.planar_stage + group * P.cap_planar,
-                                            pk_s + G.cap_e);
+    const uint32_t npl = row_pass<R, false, CHT>(X, V, PT, sm, gt, eqm, have_eq, tie, G.cap_p, start, line_base, st.planar_stage + group * P.cap_planar,
+                                                 pk_s + ((size_t)G.cap_e << (G.pk8 ? 0 : 1)), hiw);
     ROWS_STAMP(4)
     if (l == 0) {
       st.edge_cnt[group] = ne, st.planar_cnt[group] = npl;
@@ -635,6 +655,7 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const double* __restri
     double* __restrict__ xe = fz.edge_xyz ? fz.edge_xyz + scan * fz.edge_stride * 3 : nullptr;
     double* __restrict__ xp = fz.planar_xyz ? fz.planar_xyz + scan * fz.planar_stride * 3 : nullptr;
     const size_t scan_pt0 = scan * (size_t)P.H * P.W;  // first point of the scan
+    const uint32_t longest = P.W - (P.S - 1) * P.pps;
     uint32_t run_e[4], run_p[4];
     bool rgo[4];
 #pragma unroll
@@ -642,9 +663,9 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const double* __restri
       run_e[r] = (uint32_t)__builtin_amdgcn_readlane((int)base_e, 16 * r), run_p[r] = (uint32_t)__builtin_amdgcn_readlane((int)base_p, 16 * r);
       rgo[r] = __builtin_amdgcn_readlane((int)go, 16 * r) != 0;
     }
-    double* xbuf = cbuf;                                          // 3 * len doubles of one line's sector
-    double* obuf = reinterpret_cast<double*>(blk + G.off_sl);     // 64 picked points on their way out
-    const uint16_t* pk_all = reinterpret_cast<const uint16_t*>(blk + G.off_pk);
+    double* xbuf = cbuf;                        // 3 * len doubles of one line's sector (the selection's buffers are free now)
+    double* obuf = cbuf + 3 * (size_t)longest;  // 64 picked points on their way out (row_select_geom: both fit below off_sl)
+    const unsigned char* pk_all = blk + G.off_pk;
     const uint16_t* cnt_all = reinterpret_cast<const uint16_t*>(blk + G.off_cnt);
     constexpr int NI = CHT ? (3 * 16 * CHT + 63) / 64 : 1;  // scalars per lane of a sector's points (compile-time CH: prefetched)
     double nx[NI];
@@ -663,6 +684,14 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const double* __restri
       const int start = (int)(s * P.pps), len = (s == P.S - 1) ? W - start : (int)P.pps;
 #pragma unroll
       for (int rr = 0; rr < 4; rr++) {
+        // (reads that do not depend on the staged points first)
+        const uint32_t ce = cnt_all[rr * 32 + 2 * s], cq = cnt_all[rr * 32 + 2 * s + 1];  // (uniform)
+        const unsigned char* pk_s = pk_all + (((size_t)rr * G.pk_stride + (size_t)s * (G.cap_e + G.cap_p)) << (G.pk8 ? 0 : 1));
+        auto pick_pos = [&](uint32_t i) -> uint32_t {  // sector position of the i-th pick of (s, rr): edge picks first
+          const uint32_t e = (i < ce ? i : i - ce + G.cap_e);
+          return G.pk8 ? (uint32_t)pk_s[e] : (uint32_t)reinterpret_cast<const uint16_t*>(pk_s)[e];
+        };
+        uint32_t pos0 = (uint32_t)lane < ce + cq ? pick_pos((uint32_t)lane) : 0u;
         wave_lds_sync();
         if constexpr (CHT != 0) {
 #pragma unroll
@@ -676,24 +705,22 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const double* __restri
           for (int i = 0; lane + 64 * i < 3 * len; i++) xbuf[lane + 64 * i] = fetch(s, rr, i);
         }
         wave_lds_sync();
-        const uint32_t ce = cnt_all[rr * 32 + 2 * s], cq = cnt_all[rr * 32 + 2 * s + 1];  // (uniform)
         if (rgo[rr]) {
-          const uint16_t* pk_s = pk_all + (size_t)rr * G.pk_stride + s * (G.cap_e + G.cap_p);
-          const uint32_t lb = (li0 + (uint32_t)rr) * P.W;
+          const uint32_t lb = (li0 + (uint32_t)rr) * P.W + (uint32_t)start;
           for (uint32_t i0 = 0; i0 < ce + cq; i0 += 64) {
             const uint32_t i = i0 + (uint32_t)lane;
             const bool on = i < ce + cq, edge = i < ce;
             const uint32_t jj = edge ? i : i - ce;
-            const uint32_t col = on ? (uint32_t)pk_s[(edge ? 0u : G.cap_e) + jj] : (uint32_t)start;
-            const double* src = xbuf + 3 * ((int)col - start);
+            const uint32_t pos = i0 == 0 ? pos0 : (on ? pick_pos(i) : 0u);
+            const double* src = xbuf + 3 * pos;
             const double x = src[0], y = src[1], z = src[2];
-            if (on) (edge ? oe : op)[(edge ? run_e[rr] : run_p[rr]) + jj] = lb + col;
+            if (on) (edge ? oe : op)[(edge ? run_e[rr] : run_p[rr]) + jj] = lb + pos;
             obuf[3 * lane] = x, obuf[3 * lane + 1] = y, obuf[3 * lane + 2] = z;
             wave_lds_sync();
-            // this round holds the edge picks [e0, e0 + ne) and the planar picks [p0, p0 + npk) of the sector, edge first
+            // this round holds the edge picks [e0, e0 + ne) and the planar picks [p0, ...) of the sector, edge first
             const uint32_t e0 = i0 < ce ? i0 : ce, p0 = (i0 > ce ? i0 : ce) - ce;
             const uint32_t n_here = ce + cq - i0 < 64 ? ce + cq - i0 : 64;
-            const uint32_t ne = ce - e0 < n_here ? ce - e0 : n_here, npk = n_here - ne;
+            const uint32_t ne = ce - e0 < n_here ? ce - e0 : n_here;
             for (uint32_t t = (uint32_t)lane; t < 3 * n_here; t += 64) {
               const double v = obuf[t];
               if (t < 3 * ne) {
@@ -702,7 +729,6 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const double* __restri
                 xp[3 * (size_t)(run_p[rr] + p0) + (t - 3 * ne)] = v;
               }
             }
-            (void)npk;
             wave_lds_sync();
           }
         }
