@@ -908,6 +908,32 @@ __global__ __launch_bounds__(WAVES * 64) void select_mis_kernel(const double* __
 
 #include "select_rows.h"
 
+// The fused form of select_rows_kernel never writes curvature or validity to HBM; replay_kernel (row a7: std::sort's order on
+// equal curvatures) needs both for the scan lines that were marked as tied. This kernel, launched behind the fused one,
+// recomputes exactly those lines into the workspace (curvature_line_tiles: the arithmetic of curvature_valid2_kernel); every
+// workgroup leaves after one load when no line is tied.
+template <int NP, typename T>
+__global__ __launch_bounds__(64) void curvature_tied_kernel(const T* __restrict__ xyz, size_t n_lines, ExtractParams P,
+                                                            const unsigned long long* __restrict__ line_tot, const uint32_t* __restrict__ flags,
+                                                            double* __restrict__ curv_ws, uint8_t* __restrict__ mask_ws) {
+  if ((__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kFlagTie) == 0u) return;  // uniform
+  using G = Curv2<NP, 64>;
+  __shared__ __align__(16) double s_p[3][G::kLoc];
+  __shared__ double s_r[G::kLoc];
+  __shared__ unsigned long long s_bits[4][G::kWords];
+  const int W = (int)P.W;
+  for (size_t line = blockIdx.x; line < n_lines; line += gridDim.x) {
+    if ((__hip_atomic_load(line_tot + line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kLineTied) == 0ull) continue;  // uniform
+    wave_lds_sync();
+    curvature_line_tiles<NP, 64, T>(xyz + line * (size_t)W * 3, P, 0, (W + G::kTileC - 1) / G::kTileC, s_p, s_r, s_bits,
+                                    [&](int c0, const double cv[2], const bool ok[2]) {
+#pragma unroll
+                                      for (int col = 0; col < 2; col++)
+                                        if (c0 + col < W) curv_ws[line * (size_t)W + c0 + col] = cv[col], mask_ws[line * (size_t)W + c0 + col] = ok[col] ? 1 : 0;
+                                    });
+  }
+}
+
 /* ------------------------------------------------------------------------------------------------
  * extract_fused_kernel — rows a5-a10 in ONE pass over the scan (round 2): curvature + validity, selection and
  * compaction without the 9 B/point of curvature / mask ever reaching HBM.
@@ -1150,6 +1176,27 @@ static bool launch_select_rows(const double* d_curv, const uint8_t* d_mask, size
     case 3: launch_select_rows_r<3>(d_curv, d_mask, n_lines, P, st, fz, G, s); break;
     default: launch_select_rows_r<4>(d_curv, d_mask, n_lines, P, st, fz, G, s); break;
   }
+  return true;
+}
+
+// Opt-in (context option FUSED_ROWS): rows a5-a10 in one kernel, four scan lines per wavefront (select_rows_kernel<.., FUSED>): for the reference's default
+// neighbor_points on sectors of 161-174 points (64 x 1024 scans in 6 sectors). false: not applicable, nothing was launched.
+bool launch_extract_rows_fused(const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, const ExtractStage& st,
+                               const ExtractFused& fz_in, double* d_curv, uint8_t* d_mask, hipStream_t s) {
+  const size_t n_lines = n_scans * P.H;
+  if (n_lines == 0 || P.W == 0 || (P.flags & (kFlagNoMisSelect | kFlagNoRowSelect | kFlagFusedExtract)) || !(P.flags & kFlagFusedRows)) return false;
+  RowSelGeom G;
+  if (P.np != 3 || !fz_in.line_tot || !fz_in.error || !row_select_geom(P, G, true) || G.ch != 11 || n_lines % 4 != 0) return false;
+  ExtractFused fz = fz_in;
+  fz.fuse = (P.S <= 64 && !(P.flags & kFlagNoFusedCompact)) ? 1u : 0u;
+  fz.xyz = d_xyz, fz.f32 = f32 ? 1u : 0u;
+  launch_kernel((select_rows_kernel<2, 11, true>), dim3((unsigned)((n_lines + 7) / 8)), dim3(128), (size_t)G.bytes * 2, s,
+                static_cast<const double*>(nullptr), static_cast<const uint8_t*>(nullptr), n_lines, P, st, fz, G);
+  const unsigned grid = (unsigned)(n_lines < 4096 ? n_lines : 4096);
+  if (f32)
+    launch_kernel((curvature_tied_kernel<3, float>), dim3(grid), dim3(64), 0, s, static_cast<const float*>(d_xyz), n_lines, P, fz.line_tot, fz.error, d_curv, d_mask);
+  else
+    launch_kernel((curvature_tied_kernel<3, double>), dim3(grid), dim3(64), 0, s, static_cast<const double*>(d_xyz), n_lines, P, fz.line_tot, fz.error, d_curv, d_mask);
   return true;
 }
 

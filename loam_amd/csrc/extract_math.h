@@ -39,7 +39,8 @@ enum : uint32_t {
   kFlagNoFusedCompact = 8u,  // selection writes stage + counts only, compact_kernel gathers
   kFlagNoMisSelect = 16u,    // arg-max fallback select_kernel for every scan
   kFlagFusedExtract = 32u,   // one-pass extract_fused_kernel where the parameters allow
-  kFlagNoRowSelect = 64u     // one scan line per wavefront (select_mis_kernel) instead of four (select_rows_kernel)
+  kFlagNoRowSelect = 64u,    // one scan line per wavefront (select_mis_kernel) instead of four (select_rows_kernel)
+  kFlagFusedRows = 128u      // opt-in: the fused form of select_rows_kernel (curvature + validity inside it) instead of the two kernels
 };
 
 // features-inl.h:66-67 / features.cpp:22: col < np || col >= W - np in size_t arithmetic.

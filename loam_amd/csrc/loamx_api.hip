@@ -114,7 +114,7 @@ struct OptionName {
 const OptionName kOptionNames[] = {
     {"FORCE_TIE_REPLAY", true, kFlagForceReplay}, {"FORCE_SCAN_GIVEUP", true, kFlagForceGiveUp}, {"CURV_V1", true, kFlagCurvV1},
     {"NO_FUSED_COMPACT", true, kFlagNoFusedCompact}, {"NO_MIS_SELECT", true, kFlagNoMisSelect}, {"FUSED_EXTRACT", true, kFlagFusedExtract},
-    {"NO_ROW_SELECT", true, kFlagNoRowSelect},
+    {"NO_ROW_SELECT", true, kFlagNoRowSelect}, {"FUSED_ROWS", true, kFlagFusedRows},
     {"NO_MOMENTS", false, kRegFlagNoMoments}, {"NO_PACKED_GRID", false, kRegFlagNoPackedGrid}, {"NO_BIG_GRID", false, kRegFlagNoBigGrid},
     {"NO_GRID_SIDE", false, kRegFlagNoGridSide}, {"DEBUG_POISON", false, kRegFlagPoison},
     {"QUEUE_TWO_STAGE", false, kRegFlagQueueTwoStage}, {"QUEUE_ONE_STAGE", false, kRegFlagQueueOneStage},
@@ -342,6 +342,18 @@ int extract_dev(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_scans, con
       launch_compact(d_xyz, f32, n_scans, P, st, d_edge_idx, d_n_edge, d_edge_xyz, edge_capacity(P), d_planar_idx, d_n_planar,
                      d_planar_xyz, planar_capacity(P), ctx->stream, d_gave_up, d_events + 1);
       return check_launch(ctx, "extract_fused_kernel");
+    }
+  }
+  {
+    // rows a5-a10 in one kernel, four scan lines per wavefront (round 5; select_rows.h) — opt-in (context option FUSED_ROWS):
+    // bit-identical, but measured slower than the two kernels (EXPERIMENTS.md round 5)
+    TimedScope t(ctx, LOAMX_K_EXTRACT_FUSED, (double)n_scans * (double)N * (f32 ? 12.0 : 24.0), true);
+    if (launch_extract_rows_fused(d_xyz, f32, n_scans, P, st, fz, wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), ctx->stream)) {
+      const bool fused_compact = P.S <= 64 && !(P.flags & kFlagNoFusedCompact);
+      launch_replay(wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), n_scans, P, st, fz, ctx->stream);
+      launch_compact(d_xyz, f32, n_scans, P, st, d_edge_idx, d_n_edge, d_edge_xyz, edge_capacity(P), d_planar_idx, d_n_planar,
+                     d_planar_xyz, planar_capacity(P), ctx->stream, fused_compact ? d_gave_up : nullptr, fused_compact ? d_events + 1 : nullptr);
+      return check_launch(ctx, "select_rows_kernel (fused)");
     }
   }
   {

@@ -84,6 +84,10 @@ bool launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, 
 // rows a5-a10 in one kernel (extract_fused_kernel); false: not applicable to these parameters, nothing was launched
 bool launch_extract_fused(const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, const ExtractStage& st,
                           const ExtractFused& fz, double* d_curv, uint8_t* d_mask, hipStream_t s);
+// rows a5-a10 in one kernel, four scan lines per wavefront (opt-in: context option FUSED_ROWS). false: not requested or not
+// applicable to these parameters, nothing was launched
+bool launch_extract_rows_fused(const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, const ExtractStage& st,
+                               const ExtractFused& fz, double* d_curv, uint8_t* d_mask, hipStream_t s);
 // the tie path: scan lines the selection kernel marked are redone in the reference's std::sort order (stage + counts)
 void launch_replay(const double* d_curv, const uint8_t* d_mask, size_t n_scans, const ExtractParams& P, const ExtractStage& st,
                    const ExtractFused& fz, hipStream_t s);

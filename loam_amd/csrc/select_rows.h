@@ -36,11 +36,13 @@ struct RowSelGeom {
   uint32_t pk_stride;  // entries per row of the pick lists: S * (cap_e + cap_p)
   uint32_t pk8;        // 1: the lists hold bytes (a sector position fits), 0: 16-bit words
   uint32_t off_vb, off_sl, off_tk, off_pk, off_cnt;  // byte offsets inside a wavefront's LDS block
+  uint32_t off_xa, off_sr, off_vs;  // fused form: one line's staged points of a sector, their ranges, the sector's validity words
+  uint32_t nx;         // fused form: points staged per line and sector
   uint32_t bytes;      // LDS bytes per wavefront (multiple of 16)
   int32_t kbase_e, kbase_p;  // hi-word bases of the 32-bit keys
 };
 
-__host__ inline bool row_select_geom(const ExtractParams& P, RowSelGeom& G) {
+__host__ inline bool row_select_geom(const ExtractParams& P, RowSelGeom& G, bool fused = false) {
   const int R = (int)P.np - 1;
   if (R < 1 || R > 4 || P.H % 4 != 0 || P.S == 0 || P.S > 16 || P.W % 16 != 0 || P.pps == 0) return false;
   const uint32_t longest = P.W - (P.S - 1) * P.pps;
@@ -63,8 +65,14 @@ __host__ inline bool row_select_geom(const ExtractParams& P, RowSelGeom& G) {
   G.pk8 = G.ib <= 8 ? 1u : 0u;
   G.off_pk = o, o = up16(o + 4 * G.pk_stride * (G.pk8 ? 1 : 2));
   G.off_cnt = o, o = up16(o + 4 * 32 * 2);
+  if (fused) {  // + one line's points of a sector with the halo of the curvature sum and the validity windows
+    G.nx = 16 * ch + 3 * (uint32_t)R + 2 * P.np;
+    G.off_xa = o, o = up16(o + G.nx * 24);
+    G.off_sr = o, o = up16(o + G.nx * 8);
+    G.off_vs = o, o = up16(o + 4 * 32);
+  }
   G.bytes = o;
-  if (G.bytes * 4 > 64 * 1024) return false;
+  if (G.bytes * (fused ? 2 : 4) > 64 * 1024) return false;
   if (24 * longest + 64 * 24 > G.off_sl) return false;  // the copy phase's buffers (a sector's points + 64 picked points) reuse the curvature buffer
   // keys: kb = 32 - ib bits of (hi word - base). Planar candidates lie below their threshold: the top of the range is
   // the threshold's hi word; edge candidates lie above theirs: the bottom of the range is the threshold's hi word.
@@ -443,12 +451,12 @@ __device__ __forceinline__ uint32_t row_pass(const RowSelCtx& X, uint32_t& V, ui
 
 // CHT: points per lane as a compile-time constant (11 for 64 x 1024 / 6 sectors: the loops over a lane's points unroll),
 // 0 = G.ch.
-template <int R, int CHT>
-__global__ __launch_bounds__(256, 4) void select_rows_kernel(const double* __restrict__ curv, const uint8_t* __restrict__ mask, size_t n_lines,
+template <int R, int CHT, bool FUSED = false>
+__global__ __launch_bounds__(FUSED ? 128 : 256, FUSED ? 3 : 4) void select_rows_kernel(const double* __restrict__ curv, const uint8_t* __restrict__ mask, size_t n_lines,
                                                           ExtractParams P, ExtractStage st, ExtractFused fz, RowSelGeom G) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row = lane >> 4, l = lane & 15;
-  const size_t line0 = ((size_t)blockIdx.x * 4 + wave) * 4;  // four consecutive lines of one scan (H % 4 == 0)
+  const size_t line0 = ((size_t)blockIdx.x * (FUSED ? 2 : 4) + wave) * 4;  // four consecutive lines of one scan (H % 4 == 0)
   if (line0 >= n_lines) return;  // whole wavefront leaves; no workgroup barrier below
   const int W = (int)P.W, CH = CHT ? CHT : (int)G.ch, np = (int)P.np;
   const int BLu = 16 * CH + 3 * R;  // staged positions of a sector per row: -R .. 16 CH + 2R - 1
@@ -486,24 +494,50 @@ __global__ __launch_bounds__(256, 4) void select_rows_kernel(const double* __res
     const int col = (int)(s * P.pps) + lane + 64 * i - R;
     return (lane + 64 * i < BLu && col >= np && col + np < W) ? curv[(line0 + rr) * (size_t)W + col] : kNaN;
   };
-  constexpr int NL = CHT ? (16 * CHT + 3 * R + 63) / 64 : 1;
+  constexpr int NL = (CHT && !FUSED) ? (16 * CHT + 3 * R + 63) / 64 : 1;
   double pre[4][NL];
-  if constexpr (CHT != 0) {
+  // ---- fused form (rows a5 + a6 inside this kernel: curvature and validity never reach HBM). A sector of ONE line at a
+  // time: its points, with the halo of the curvature sum and of the validity windows, are staged in LDS by all 64 lanes
+  // (xa: NX points as they lie in the scan), then: range of every point (sr), the four invalidation codes as wavefront
+  // ballots, the validity of the sector's points from those bit strings in scalar registers (features.cpp:20-68 as the
+  // gather extract_math.h describes), the curvature of the sector's positions into the row's curvature buffer.
+  constexpr int NP = R + 1;
+  constexpr int NX = FUSED ? 16 * CHT + 3 * R + 2 * NP : 1;  // columns start - R - NP .. start + 16 CH + 2R + NP - 1
+  constexpr int NIA = FUSED ? (3 * NX + 63) / 64 : 1, NRND = FUSED ? (NX + 63) / 64 : 1;
+  double* xa = reinterpret_cast<double*>(blk + G.off_xa);
+  double* sr = reinterpret_cast<double*>(blk + G.off_sr);
+  uint32_t* vsec = reinterpret_cast<uint32_t*>(blk + G.off_vs);
+  double nxa[NIA];
+  auto fetch_xa = [&](uint32_t s, int rr, int i) -> double {  // scalar lane + 64 i of the staged points of (sector s, row rr)
+    const int k = lane + 64 * i;
+    const long e = 3l * ((long)(s * P.pps) - R - NP) + k;  // element of the line
+    if (k >= 3 * NX || e < 0 || e >= 3l * W) return 0.0;
+    const size_t g = (line0 + rr) * (size_t)W * 3 + (size_t)e;
+    return fz.f32 ? (double)static_cast<const float*>(fz.xyz)[g] : static_cast<const double*>(fz.xyz)[g];
+  };
+  if constexpr (FUSED) {
+    static_assert(!FUSED || CHT != 0, "the fused form needs the lane chunk at compile time");
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++)
+    for (int i = 0; i < NIA; i++) nxa[i] = fetch_xa(0, 0, i);
+    for (int k = lane; k < 4 * (int)G.vw; k += 64) vb[k] = 0;  // fused form: vb holds the SUPPRESSED points of the four lines
+  } else {
+    if constexpr (CHT != 0) {
 #pragma unroll
-      for (int i = 0; i < NL; i++) pre[rr][i] = fetch_curv(0, rr, i);
-  }
-  // ---- validity bytes (0 / 1, written by the curvature kernels) -> one bit per point
-  for (int rr = 0; rr < 4; rr++) {
-    const uint8_t* __restrict__ mrow = mask + (line0 + rr) * (size_t)W;
-    uint16_t* vrow = reinterpret_cast<uint16_t*>(vb + rr * G.vw);
-    for (int c0 = lane * 16; c0 < W; c0 += 1024) {
-      const uint4 m = *reinterpret_cast<const uint4*>(mrow + c0);
-      auto nib = [](uint32_t w) { return (w | (w >> 7) | (w >> 14) | (w >> 21)) & 0xFu; };
-      vrow[c0 >> 4] = (uint16_t)(nib(m.x) | (nib(m.y) << 4) | (nib(m.z) << 8) | (nib(m.w) << 12));
+      for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+        for (int i = 0; i < NL; i++) pre[rr][i] = fetch_curv(0, rr, i);
     }
-    for (int k = (W >> 4) + lane; k < 2 * (int)G.vw; k += 64) vrow[k] = 0;  // bits past the line's end
+    // ---- validity bytes (0 / 1, written by the curvature kernels) -> one bit per point
+    for (int rr = 0; rr < 4; rr++) {
+      const uint8_t* __restrict__ mrow = mask + (line0 + rr) * (size_t)W;
+      uint16_t* vrow = reinterpret_cast<uint16_t*>(vb + rr * G.vw);
+      for (int c0 = lane * 16; c0 < W; c0 += 1024) {
+        const uint4 m = *reinterpret_cast<const uint4*>(mrow + c0);
+        auto nib = [](uint32_t w) { return (w | (w >> 7) | (w >> 14) | (w >> 21)) & 0xFu; };
+        vrow[c0 >> 4] = (uint16_t)(nib(m.x) | (nib(m.y) << 4) | (nib(m.z) << 8) | (nib(m.w) << 12));
+      }
+      for (int k = (W >> 4) + lane; k < 2 * (int)G.vw; k += 64) vrow[k] = 0;  // bits past the line's end
+    }
   }
   ROWS_STAMP(0)
   const uint32_t line_base = (uint32_t)(line % P.H) * P.W;
@@ -515,7 +549,102 @@ __global__ __launch_bounds__(256, 4) void select_rows_kernel(const double* __res
     const int len = (s == P.S - 1) ? W - start : (int)P.pps;  // features-inl.h:31-35
     // ---- stage the sector's curvature of the four lines (compile-time CH: it was fetched during the previous sector)
     wave_lds_sync();
-    if constexpr (CHT != 0) {
+    if constexpr (FUSED) {
+#pragma unroll 1
+      for (int rr = 0; rr < 4; rr++) {
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < NIA; i++)
+          if (lane + 64 * i < 3 * NX) xa[lane + 64 * i] = nxa[i];
+        wave_lds_sync();
+        {  // the next line's (or the next sector's first line's) points fly during this line's arithmetic
+          const uint32_t s2 = rr == 3 ? s + 1 : s;
+          if (s2 < P.S) {
+#pragma unroll
+            for (int i = 0; i < NIA; i++) nxa[i] = fetch_xa(s2, (rr + 1) & 3, i);
+          }
+        }
+        const int c_lo = start - R - NP;  // column of staged point 0
+        // ranges (common.h:81-86)
+#pragma unroll
+        for (int i = 0; i < NRND; i++) {
+          const int li = lane + 64 * i;
+          if (li < NX) sr[li] = point_range(xa[3 * li], xa[3 * li + 1], xa[3 * li + 2]);
+        }
+        wave_lds_sync();
+        // invalidation codes of the interior points as bit strings over the staged points (bit li of word li / 64), one kind
+        // at a time (each is three scalar register pairs):
+        // invalid = line end | code 1 within +-NP | code 2 at 1..NP points before | code 3 at 0..NP-1 points after | code 4
+        // (extract_math.h: valid_from_codes), on the bit strings: scalar shifts and ors
+        uint8_t code[NRND];
+        unsigned long long inv[NRND];
+#pragma unroll
+        for (int i = 0; i < NRND; i++) {
+          const int li = lane + 64 * i, col = c_lo + li;
+          const bool inside = li < NX && col >= NP && col + NP < W;  // not a line end (features-inl.h:66-67), inside the line
+          code[i] = kCodeNone;
+          if (inside && li >= 1 && li + 1 < NX) code[i] = point_code(sr[li - 1], sr[li], sr[li + 1], P);
+          inv[i] = __ballot(!inside || code[i] == kCodeParallel);
+        }
+        {
+          unsigned long long m[NRND];
+#pragma unroll
+          for (int i = 0; i < NRND; i++) m[i] = __ballot(code[i] == kCodeRange), inv[i] |= m[i];
+#pragma unroll
+          for (int d = 1; d <= NP; d++)
+#pragma unroll
+            for (int i = 0; i < NRND; i++)
+              inv[i] |= (m[i] << d) | (i > 0 ? m[i - 1] >> (64 - d) : 0ull) | (m[i] >> d) | (i + 1 < NRND ? m[i + 1] << (64 - d) : 0ull);
+#pragma unroll
+          for (int i = 0; i < NRND; i++) m[i] = __ballot(code[i] == kCodeOcc1);
+#pragma unroll
+          for (int d = 1; d <= NP; d++)
+#pragma unroll
+            for (int i = 0; i < NRND; i++) inv[i] |= (m[i] << d) | (i > 0 ? m[i - 1] >> (64 - d) : 0ull);  // code at li - d
+#pragma unroll
+          for (int i = 0; i < NRND; i++) m[i] = __ballot(code[i] == kCodeOcc2), inv[i] |= m[i];
+#pragma unroll
+          for (int d = 1; d <= NP - 1; d++)
+#pragma unroll
+            for (int i = 0; i < NRND; i++) inv[i] |= (m[i] >> d) | (i + 1 < NRND ? m[i + 1] << (64 - d) : 0ull);  // code at li + d
+        }
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < NRND; i++) {
+            vsec[rr * 8 + 2 * i] = (uint32_t)~inv[i], vsec[rr * 8 + 2 * i + 1] = (uint32_t)(~inv[i] >> 32);
+          }
+#pragma unroll
+          for (int i = 2 * NRND; i < 8; i++) vsec[rr * 8 + i] = 0;
+        }
+        // curvature of the sector's positions -R .. 16 CH + 2R - 1 (features-inl.h:73-82, the association order of curvature_at):
+        // three consecutive positions per lane, one coordinate at a time
+        {
+          const int k0 = 3 * lane;  // buffer index k <-> staged point k + NP <-> column start - R + k
+          if (k0 < BLu) {
+            double d[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+              double w[2 * NP + 3];
+#pragma unroll
+              for (int u = 0; u < 2 * NP + 3; u++) w[u] = k0 + u < NX ? xa[3 * (k0 + u) + a] : 0.0;
+#pragma unroll
+              for (int i = 0; i < 3; i++) {
+                double acc = -(2.0 * NP) * w[NP + i];
+#pragma unroll
+                for (int n = 1; n <= NP; n++) acc = acc + w[NP + i - n] + w[NP + i + n];
+                d[i][a] = acc;
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+              const int col = start - R + k0 + i;
+              const double cv = d[i][0] * d[i][0] + d[i][1] * d[i][1] + d[i][2] * d[i][2];
+              if (k0 + i < BLu) cbuf[(size_t)rr * G.pitch + k0 + i] = (col >= NP && col + NP < W) ? cv : kNaN;
+            }
+          }
+        }
+      }
+    } else if constexpr (CHT != 0) {
 #pragma unroll
       for (int rr = 0; rr < 4; rr++)
 #pragma unroll
@@ -571,7 +700,12 @@ __global__ __launch_bounds__(256, 4) void select_rows_kernel(const double* __res
     // ---- the line's current validity bits of my CH points (one unaligned two-word read)
     const uint32_t o = (uint32_t)(start + l * CH), wv = o >> 5, sh = o & 31u;
     const uint32_t* vrow = vb + row * G.vw;
-    const uint32_t V0 = __builtin_amdgcn_alignbit(vrow[wv + 1], vrow[wv], sh) & X.cm;
+    uint32_t V0 = __builtin_amdgcn_alignbit(vrow[wv + 1], vrow[wv], sh) & X.cm;
+    if constexpr (FUSED) {  // valid by the codes of this sector's staged points, and not suppressed by an earlier pick of the line
+      const uint32_t bo = (uint32_t)(l * CH + R + NP);  // staged point of my first position
+      const uint32_t* vs = vsec + row * 8 + (bo >> 5);
+      V0 = __builtin_amdgcn_alignbit(vs[1], vs[0], bo & 31u) & X.cm & ~V0;
+    }
     uint32_t V = V0;
     int nb = len - l * CH;
     nb = nb < 0 ? 0 : (nb > CH ? CH : nb);
@@ -593,8 +727,13 @@ __global__ __launch_bounds__(256, 4) void select_rows_kernel(const double* __res
     if (clr) {
       const unsigned long long mm = (unsigned long long)clr << sh;
       uint32_t* vw_ = vb + row * G.vw + wv;
-      if ((uint32_t)mm) __hip_atomic_fetch_and(vw_, ~(uint32_t)mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if ((uint32_t)(mm >> 32)) __hip_atomic_fetch_and(vw_ + 1, ~(uint32_t)(mm >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if constexpr (FUSED) {
+        if ((uint32_t)mm) __hip_atomic_fetch_or(vw_, (uint32_t)mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((uint32_t)(mm >> 32)) __hip_atomic_fetch_or(vw_ + 1, (uint32_t)(mm >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        if ((uint32_t)mm) __hip_atomic_fetch_and(vw_, ~(uint32_t)mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((uint32_t)(mm >> 32)) __hip_atomic_fetch_and(vw_ + 1, ~(uint32_t)(mm >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
     }
   }
   wave_lds_sync();

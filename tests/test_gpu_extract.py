@@ -356,6 +356,43 @@ def test_fused_extraction_with_the_rare_paths_forced(oracle):
         b_.free()
 
 
+@pytest.mark.parametrize("form", ["rows", "NO_ROW_SELECT", "FUSED_ROWS"])
+@pytest.mark.parametrize("forced", [None, "FORCE_TIE_REPLAY", "FORCE_SCAN_GIVEUP", "NO_FUSED_COMPACT"])
+def test_selection_forms_against_the_oracle(oracle, form, forced):
+    """Round 5: the selection with four scan lines per wavefront (select_rows_kernel, the default), one line per wavefront
+    (NO_ROW_SELECT: select_mis_kernel) and the opt-in fused form that computes curvature and validity itself (FUSED_ROWS; its
+    tied lines are recomputed by curvature_tied_kernel for the std::sort replay): double and float input, one noise-free scan
+    (ties in most lines), the rare paths forced — index sequences and point copies are the oracle's."""
+    import contextlib
+    H, W, ns = 64, 1024, 3
+    c = ctx()
+    lidar, fe = capi.LidarParams(H, W, 1.0, 120.0), capi.FeatureExtractionParams()
+    scans = np.stack([capi.synth_scan_host(300 + s, 0, s & 1, H, W, 0.0 if s == 2 else 0.01) for s in range(ns)])  # scan 2: noise free (ties)
+    ecap, pcap = c.edge_capacity(lidar, fe), c.planar_capacity(lidar, fe)
+    for f32 in (False, True):
+        data = scans.astype(np.float32) if f32 else scans
+        wide = data.astype(np.float64)
+        d_xyz = c.alloc(data.nbytes).upload(data)
+        d_ei, d_pi, d_ne, d_np = c.alloc(ns * ecap * 4), c.alloc(ns * pcap * 4), c.alloc(ns * 4), c.alloc(ns * 4)
+        d_ex, d_px = c.alloc(ns * ecap * 24), c.alloc(ns * pcap * 24)
+        r0 = c.extract_counters()[0]
+        with (option(form) if form != "rows" else contextlib.nullcontext()), (option(forced) if forced else contextlib.nullcontext()):
+            c.extract_features_batch_dev(d_xyz.ptr, ns, lidar, fe, d_ei.ptr, d_ne.ptr, d_ex.ptr, d_pi.ptr, d_np.ptr, d_px.ptr, f32=f32)
+            c.synchronize()
+        assert c.extract_counters()[0] > r0  # the noise-free scan has tied lines
+        ne, npl = d_ne.download(np.uint32, ns), d_np.download(np.uint32, ns)
+        ei = d_ei.download(np.uint32, ns * ecap).reshape(ns, ecap)
+        pi = d_pi.download(np.uint32, ns * pcap).reshape(ns, pcap)
+        ex = d_ex.download(np.float64, ns * ecap * 3).reshape(ns, ecap, 3)
+        px = d_px.download(np.float64, ns * pcap * 3).reshape(ns, pcap, 3)
+        for s in range(ns):
+            oe, op = oracle.extract_features(wide[s], H, W, 1.0, 120.0)
+            assert np.array_equal(ei[s, :ne[s]], oe) and np.array_equal(pi[s, :npl[s]], op), (form, forced, f32, s)
+            assert np.array_equal(ex[s, :ne[s]], wide[s][oe]) and np.array_equal(px[s, :npl[s]], wide[s][op])
+        for b_ in (d_xyz, d_ei, d_pi, d_ne, d_np, d_ex, d_px):
+            b_.free()
+
+
 def test_context_options_are_per_context_and_named():
     """loamx_ctx_set_option: unknown names are refused, a switch lives on the context it was set on, and the
     environment is not consulted after loamx_ctx_create."""
