@@ -1200,8 +1200,14 @@ bool launch_extract_rows_fused(const void* d_xyz, bool f32, size_t n_scans, cons
   return true;
 }
 
+bool launch_select_takes_boxes(const ExtractParams& P) {
+  RowSelGeom G;
+  return !(P.flags & (kFlagNoMisSelect | kFlagNoRowSelect | kFlagNoFusedCompact | kFlagFusedExtract)) && P.S <= 64 && row_select_geom(P, G);
+}
+
 bool launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, const ExtractParams& P,
-                   const ExtractStage& st, const ExtractFused* fused, hipStream_t s) {
+                   const ExtractStage& st, const ExtractFused* fused, hipStream_t s, bool* rows_ran) {
+  if (rows_ran) *rows_ran = false;
   const size_t n_lines = n_scans * P.H;
   if (n_lines == 0 || P.W == 0) return false;
   // the fused compaction keeps the per-sector counts of a line on the lanes of its wavefront
@@ -1216,7 +1222,10 @@ bool launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, 
   const uint32_t picks = (longest + R) / (R + 1);  // most picks a sector can yield
   const bool mis_ok = R >= 1 && R <= 4 && CH >= R && CH + 2 * R <= 64 &&
                       (picks <= 64 || (picks <= 128 && P.cap_edge <= 64 && P.cap_planar <= 64));
-  if (!(P.flags & (kFlagNoMisSelect | kFlagNoRowSelect)) && launch_select_rows(d_curv, d_mask, n_lines, P, st, fz, s)) return fuse;
+  if (!(P.flags & (kFlagNoMisSelect | kFlagNoRowSelect)) && launch_select_rows(d_curv, d_mask, n_lines, P, st, fz, s)) {
+    if (rows_ran) *rows_ran = true;
+    return fuse;
+  }
   if (mis_ok && !(P.flags & kFlagNoMisSelect)) {
     switch (R) {
       case 1: launch_select_mis<1>(d_curv, d_mask, n_lines, P, st, fz, s); return fuse;

@@ -25,7 +25,7 @@ enum WsId {
   WS_XYZ = 0, WS_CURV, WS_MASK, WS_EDGE_STAGE, WS_PLANAR_STAGE, WS_EDGE_CNT, WS_PLANAR_CNT,
   WS_EDGE_IDX, WS_PLANAR_IDX, WS_N_EDGE, WS_N_PLANAR, WS_EDGE_XYZ, WS_PLANAR_XYZ,
   WS_GRID_DESC_E, WS_GRID_DESC_P, WS_CELLS_E, WS_CELLS_P, WS_SORTED_E, WS_SORTED_P, WS_REL_E, WS_REL_P,
-  WS_SGRID_DESC_E, WS_SGRID_DESC_P, WS_SCELLS_E, WS_SCELLS_P, WS_SSORTED_E, WS_SSORTED_P, WS_SORT_SCRATCH, WS_SORT_SCRATCH_SRC, WS_ASSOC_E, WS_ASSOC_P, WS_NN_E, WS_NN_P, WS_RNN_E, WS_RNN_P, WS_NEAREST_E, WS_NEAREST_P, WS_REST_E, WS_REST_P, WS_EXACT_E, WS_EXACT_P, WS_NASSOC, WS_STATE, WS_PARTIALS, WS_MOM_PARTIALS, WS_MOMENTS, WS_FLAGGED_LIST, WS_FLAGGED_COUNT, WS_LINE_TOT, WS_EXTRACT_EVENTS,
+  WS_SGRID_DESC_E, WS_SGRID_DESC_P, WS_SCELLS_E, WS_SCELLS_P, WS_SSORTED_E, WS_SSORTED_P, WS_SORT_SCRATCH, WS_SORT_SCRATCH_SRC, WS_ASSOC_E, WS_ASSOC_P, WS_NN_E, WS_NN_P, WS_RNN_E, WS_RNN_P, WS_NEAREST_E, WS_NEAREST_P, WS_REST_E, WS_REST_P, WS_EXACT_E, WS_EXACT_P, WS_NASSOC, WS_STATE, WS_PARTIALS, WS_MOM_PARTIALS, WS_MOMENTS, WS_FLAGGED_LIST, WS_FLAGGED_COUNT, WS_LINE_TOT, WS_EXTRACT_EVENTS, WS_BOX,
   WS_COUNTERS, WS_ITERINFO, WS_DUMP_E, WS_DUMP_P, WS_FIT_IN, WS_FIT_OUT, WS_SRC_E, WS_SRC_P, WS_TGT_E, WS_TGT_P, WS_FCOUNTS, WS_RESULTS, WS_INIT,
   WS_COUNT
 };
@@ -119,7 +119,8 @@ const OptionName kOptionNames[] = {
     {"NO_GRID_SIDE", false, kRegFlagNoGridSide}, {"DEBUG_POISON", false, kRegFlagPoison},
     {"QUEUE_TWO_STAGE", false, kRegFlagQueueTwoStage}, {"QUEUE_ONE_STAGE", false, kRegFlagQueueOneStage},
     {"NO_MIXED_ASSOC", false, kRegFlagNoMixedAssoc}, {"FORCE_RCCL", false, kRegFlagForceRccl},
-    {"NO_COOP_LEFT", false, kRegFlagNoCoopLeft}, {"NO_REF_MOMENTS", false, kRegFlagNoRefMoments}};
+    {"NO_COOP_LEFT", false, kRegFlagNoCoopLeft}, {"NO_REF_MOMENTS", false, kRegFlagNoRefMoments},
+    {"NO_EXTRACT_BOXES", false, kRegFlagNoExtractBoxes}};
 
 int fail(loamx_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->last_error = msg;
@@ -282,12 +283,21 @@ int make_reg_config(loamx_ctx* ctx, const loamx_reg_params* r, RegConfig& C) {
 size_t edge_capacity(const ExtractParams& P) { return (size_t)P.H * P.S * P.cap_edge; }
 size_t planar_capacity(const ExtractParams& P) { return (size_t)P.H * P.S * P.cap_planar; }
 
+// Bounding boxes of the feature sets of every scan, taken by the selection's copy phase (select_rows_kernel with the fused
+// compaction): min / max[scan][kind][axis] as ordered keys; valid while *bad == 0 (a tied or given-up line sends its scan through
+// compact_kernel, which takes no boxes). All nullptr when the extraction went another way.
+struct ExtractBoxes {
+  const unsigned long long *min = nullptr, *max = nullptr;
+  const uint32_t* bad = nullptr;
+};
+
 // extraction over device-resident scans ------------------------------------------------------------------
 // d_xyz: double, or float when f32 (FP32-input path)
 int extract_dev(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, uint32_t* d_edge_idx,
                 uint32_t* d_n_edge, double* d_edge_xyz, uint32_t* d_planar_idx, uint32_t* d_n_planar,
-                double* d_planar_xyz, bool only_curvature_mask) {
+                double* d_planar_xyz, bool only_curvature_mask, ExtractBoxes* boxes = nullptr) {
   const size_t N = (size_t)P.H * P.W;
+  if (boxes) *boxes = ExtractBoxes{};
   if (n_scans == 0) return LOAMX_OK;
   untimed(ctx);
   if (N == 0) {
@@ -330,8 +340,15 @@ int extract_dev(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_scans, con
   HIP_TRY(ctx, hipMemsetAsync(ctx->ws[WS_LINE_TOT].p, 0, (n_lines + 1) * sizeof(unsigned long long), ctx->stream));
   uint32_t* d_gave_up = reinterpret_cast<uint32_t*>(wsp<unsigned long long>(ctx, WS_LINE_TOT) + n_lines);
   unsigned long long* d_events = wsp<unsigned long long>(ctx, WS_EXTRACT_EVENTS);
-  const ExtractFused fz{wsp<unsigned long long>(ctx, WS_LINE_TOT), 0u, d_xyz, f32 ? 1u : 0u, d_edge_idx, d_n_edge, d_edge_xyz,
-                        edge_capacity(P), d_planar_idx, d_n_planar, d_planar_xyz, planar_capacity(P), d_gave_up, d_events};
+  ExtractFused fz{wsp<unsigned long long>(ctx, WS_LINE_TOT), 0u, d_xyz, f32 ? 1u : 0u, d_edge_idx, d_n_edge, d_edge_xyz,
+                  edge_capacity(P), d_planar_idx, d_n_planar, d_planar_xyz, planar_capacity(P), d_gave_up, d_events, nullptr, nullptr};
+  if (boxes && d_edge_xyz && d_planar_xyz && launch_select_takes_boxes(P)) {
+    ENSURE(ctx, WS_BOX, 2 * n_scans * 6 * sizeof(unsigned long long));
+    fz.box_min = wsp<unsigned long long>(ctx, WS_BOX), fz.box_max = fz.box_min + n_scans * 6;
+    untimed(ctx);
+    HIP_TRY(ctx, hipMemsetAsync(fz.box_min, 0xFF, n_scans * 6 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(fz.box_max, 0x00, n_scans * 6 * sizeof(unsigned long long), ctx->stream));
+  }
   {
     // rows a5-a10 in one pass over the scan — opt-in (context option FUSED_EXTRACT; the two kernels below are the default,
     // see launch_extract_fused) and only where the parameters allow: 24 B/point read + (4 + 24) B per feature written;
@@ -361,10 +378,10 @@ int extract_dev(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_scans, con
     launch_curvature_valid(d_xyz, f32, n_scans, P, wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), ctx->stream);
   }
   CHECK_LAUNCH(ctx, "curvature_valid_kernel");
-  bool fused = false;
+  bool fused = false, rows_ran = false;
   {
     TimedScope t(ctx, LOAMX_K_SELECT, (double)n_scans * (double)N * 9.0, true);
-    fused = launch_select(wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), n_scans, P, st, &fz, ctx->stream);
+    fused = launch_select(wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), n_scans, P, st, &fz, ctx->stream, &rows_ran);
     // scan lines on which a curvature tie can decide something: again, in the reference's std::sort order (a no-op without)
     launch_replay(wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), n_scans, P, st, fz, ctx->stream);
     // A scan line whose wavefront gave up waiting for the lines before it (bounded wait: unusual scheduling) left its
@@ -375,6 +392,7 @@ int extract_dev(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_scans, con
                      d_planar_xyz, planar_capacity(P), ctx->stream, d_gave_up, d_events + 1);
   }
   CHECK_LAUNCH(ctx, "select_kernel");
+  if (fused && rows_ran && boxes && fz.box_min) boxes->min = fz.box_min, boxes->max = fz.box_max, boxes->bad = d_gave_up;
   if (fused) return LOAMX_OK;
   {
     TimedScope t(ctx, LOAMX_K_COMPACT, 0.0, true);
@@ -392,6 +410,7 @@ struct RegInputs {
   const double *src_edge, *src_planar, *tgt_edge, *tgt_planar;
   const uint32_t *n_src_edge, *n_src_planar, *n_tgt_edge, *n_tgt_planar;
   const double* init;
+  ExtractBoxes boxes;  // (optional) bounding boxes of the sets, left by the extraction that produced them
 };
 
 // host-side hook called after the association kernels of iteration `it` (detail capture)
@@ -506,6 +525,7 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C_in, loa
   B.src_edge = in.src_edge, B.n_src_edge = in.n_src_edge, B.src_planar = in.src_planar, B.n_src_planar = in.n_src_planar;
   B.tgt_edge = in.tgt_edge, B.n_tgt_edge = in.n_tgt_edge, B.tgt_planar = in.tgt_planar, B.n_tgt_planar = in.n_tgt_planar;
   B.init = in.init;
+  if (!(C.flags & kRegFlagNoExtractBoxes)) B.box_min = in.boxes.min, B.box_max = in.boxes.max, B.box_bad = in.boxes.bad;
   ENSURE(ctx, WS_GRID_DESC_E, np * sizeof(GridDesc));
   ENSURE(ctx, WS_GRID_DESC_P, np * sizeof(GridDesc));
   ENSURE(ctx, WS_CELLS_E, (np * (size_t)(kGridCellsCap + 1) + 4) * sizeof(uint32_t));  // (+4: the search reads four entries at a time)
@@ -1492,12 +1512,14 @@ static int register_scan_pairs(loamx_ctx* ctx, const void* d_xyz, bool f32, size
   ENSURE(ctx, WS_N_PLANAR, n_scans * sizeof(uint32_t));
   ENSURE(ctx, WS_EDGE_XYZ, n_scans * ecap * 3 * sizeof(double));
   ENSURE(ctx, WS_PLANAR_XYZ, n_scans * pcap * 3 * sizeof(double));
+  ExtractBoxes boxes;
   rc = extract_dev(ctx, d_xyz, f32, n_scans, P, wsp<uint32_t>(ctx, WS_EDGE_IDX), wsp<uint32_t>(ctx, WS_N_EDGE),
                    wsp<double>(ctx, WS_EDGE_XYZ), wsp<uint32_t>(ctx, WS_PLANAR_IDX), wsp<uint32_t>(ctx, WS_N_PLANAR),
-                   wsp<double>(ctx, WS_PLANAR_XYZ), false);
+                   wsp<double>(ctx, WS_PLANAR_XYZ), false, &boxes);
   if (rc != LOAMX_OK) return rc;
   // scan 2p = target, scan 2p+1 = source (interleaved => in_pitch 2)
   RegInputs in{};
+  in.boxes = boxes;
   in.n_pairs = n_pairs, in.edge_stride = ecap, in.planar_stride = pcap, in.in_pitch = 2;
   in.tgt_edge = wsp<double>(ctx, WS_EDGE_XYZ), in.src_edge = in.tgt_edge + ecap * 3;
   in.tgt_planar = wsp<double>(ctx, WS_PLANAR_XYZ), in.src_planar = in.tgt_planar + pcap * 3;

@@ -72,14 +72,29 @@ struct ExtractFused {
                     // lines before it (or they are tied): the fallback compaction gathers the batch from the stage arrays;
                     // bit 1: some line is tied (replay_kernel has work)
   unsigned long long* events;  // [3] cumulative: scan lines replayed in the reference's tie order, give-up fallbacks taken, features written by the fused path
+  // optional (select_rows_kernel with the fused compaction only): bounding boxes of every scan's edge / planar features as ordered
+  // keys (dbl_key), box_min / box_max[scan][kind][axis], kind 0 = edge, 1 = planar; the caller presets them (all ones / zero).
+  // Complete iff the flag word *error stays zero (no line gave up or was tied: those scans went through compact_kernel).
+  unsigned long long* box_min;
+  unsigned long long* box_max;
 };
+// doubles as unsigned keys with the same order (for atomicMin / atomicMax)
+__device__ __forceinline__ unsigned long long dbl_key(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_dbl(unsigned long long k) {
+  return __longlong_as_double((long long)((k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k));
+}
 
 void launch_curvature_valid(const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, double* d_curv,
                             uint8_t* d_mask, hipStream_t s);
 // fz != nullptr: the selection may also write the final feature arrays (returns true if it did: no
 // launch_compact needed); otherwise, or when it returns false, stage + counts only.
 bool launch_select(const double* d_curv, const uint8_t* d_mask, size_t n_scans, const ExtractParams& P,
-                   const ExtractStage& st, const ExtractFused* fz, hipStream_t s);
+                   const ExtractStage& st, const ExtractFused* fz, hipStream_t s, bool* rows_ran = nullptr);
+// will launch_select run the kernel that fills ExtractFused::box_* (select_rows_kernel with the fused compaction)?
+bool launch_select_takes_boxes(const ExtractParams& P);
 // edge_stride / planar_stride: entries per scan in the output arrays
 // rows a5-a10 in one kernel (extract_fused_kernel); false: not applicable to these parameters, nothing was launched
 bool launch_extract_fused(const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, const ExtractStage& st,
@@ -119,6 +134,7 @@ constexpr uint32_t kRegFlagQueueOneStage = 64u;  // queue chain: always the FP64
 constexpr uint32_t kRegFlagForceRccl = 256u;     // a one-rank communicator really enqueues ncclAllGather / ncclBroadcast / ncclAllReduce (host side only)
 constexpr uint32_t kRegFlagNoCoopLeft = 512u;    // listed queue leftovers one lane per query (associate_knn_left_kernel, round 3), not one wavefront per query
 constexpr uint32_t kRegFlagNoRefMoments = 1024u;  // first ICF iteration as in round 3: five sweeps of the records, no moments
+constexpr uint32_t kRegFlagNoExtractBoxes = 2048u;  // the index builds take their bounding boxes themselves even when the extraction left them
 constexpr uint32_t kRegFlagNoMixedAssoc = 128u;  // edge and plane first kernels as separate launches on two streams (launch_associate)
 
 // One target feature set's spatial index (device pointers into the workspace)
@@ -218,6 +234,12 @@ struct RegBatch {
   uint32_t assoc_blocks_edge, assoc_blocks_plane;  // workgroups per pair of the association kernels; 0xFFFFFFFF = by capacity
   uint32_t want_nearest;  // 1: a detail hook will read nearest_* (RegistrationDetail pairs); 0: the fit kernels skip that write
   uint32_t ref_moments;   // 1: the first ICF iteration takes its moments at its first candidate after ONE sweep (enqueue_icf_iteration)
+  // optional: bounding boxes of the input feature sets, computed by the extraction that produced them (ExtractFused::box_*):
+  // [scan][kind][axis] keys, scan = pair * in_pitch (+ 1 for the source scan of interleaved pairs). Used by the index builds
+  // in place of their own read pass while *box_bad == 0; nullptr: the builds compute the boxes.
+  const unsigned long long* box_min;
+  const unsigned long long* box_max;
+  const uint32_t* box_bad;
 };
 
 // scratch the multi-workgroup build of a map-sized target set needs per pair (at B.sort_scratch + pair * stride points)

@@ -57,7 +57,8 @@ template <bool ORDERED, bool PACKED>
 __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double* __restrict__ pts_base,
                                                                    const uint32_t* __restrict__ n_pts, size_t stride,
                                                                    uint32_t in_pitch, double max_dist, GridSet gs, GridPoint* __restrict__ scratch,
-                                                                   unsigned long long* __restrict__ bytes) {
+                                                                   unsigned long long* __restrict__ bytes, const unsigned long long* __restrict__ box_min,
+                                                                   const unsigned long long* __restrict__ box_max, const uint32_t* __restrict__ box_bad) {
   __shared__ uint32_t s_cells[PACKED ? kGridLdsCells / 2 : kGridLdsCells];
   auto cell_get = [&](uint32_t c) -> uint32_t { return PACKED ? (s_cells[c >> 1] >> ((c & 1u) * 16u)) & 0xFFFFu : s_cells[c]; };
   auto cell_add = [&](uint32_t c) -> uint32_t {  // returns the value before the increment
@@ -87,26 +88,38 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
 #endif
   STAMP();
 
-  double lx = kDblMax, ly = kDblMax, lz = kDblMax, hx = -kDblMax, hy = -kDblMax, hz = -kDblMax;
+  // The bounding box: handed over by the extraction that produced the set (round 5: select_rows_kernel's copy phase takes
+  // the minima / maxima of the points it copies — the same six numbers, min and max are exact), or one read pass here.
+  const bool have_box = box_min != nullptr && __hip_atomic_load(box_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;  // uniform
+  if (!have_box) {
+    double lx = kDblMax, ly = kDblMax, lz = kDblMax, hx = -kDblMax, hy = -kDblMax, hz = -kDblMax;
 #pragma unroll 4
-  for (uint32_t i = tid; i < n; i += kBuildThreads) {
-    const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
-    lx = fmin(lx, x), ly = fmin(ly, y), lz = fmin(lz, z);
-    hx = fmax(hx, x), hy = fmax(hy, y), hz = fmax(hz, z);
+    for (uint32_t i = tid; i < n; i += kBuildThreads) {
+      const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+      lx = fmin(lx, x), ly = fmin(ly, y), lz = fmin(lz, z);
+      hx = fmax(hx, x), hy = fmax(hy, y), hz = fmax(hz, z);
+    }
+    lx = wave_min(lx), ly = wave_min(ly), lz = wave_min(lz);
+    hx = wave_max(hx), hy = wave_max(hy), hz = wave_max(hz);
+    if (lane == 0) {
+      s_red[0][wave] = lx, s_red[1][wave] = ly, s_red[2][wave] = lz;
+      s_red[3][wave] = hx, s_red[4][wave] = hy, s_red[5][wave] = hz;
+    }
   }
   STAMP();  // bbox loads
-  lx = wave_min(lx), ly = wave_min(ly), lz = wave_min(lz);
-  hx = wave_max(hx), hy = wave_max(hy), hz = wave_max(hz);
-  if (lane == 0) {
-    s_red[0][wave] = lx, s_red[1][wave] = ly, s_red[2][wave] = lz;
-    s_red[3][wave] = hx, s_red[4][wave] = hy, s_red[5][wave] = hz;
-  }
   __syncthreads();
   if (tid == 0) {
     double a[6];
-    for (int k = 0; k < 6; k++) {
-      a[k] = s_red[k][0];
-      for (int w = 1; w < kBuildThreads / 64; w++) a[k] = k < 3 ? fmin(a[k], s_red[k][w]) : fmax(a[k], s_red[k][w]);
+    if (have_box) {
+      for (int k = 0; k < 3; k++) {
+        a[k] = n ? key_dbl(box_min[(pair * in_pitch) * 6 + k]) : kDblMax;
+        a[3 + k] = n ? key_dbl(box_max[(pair * in_pitch) * 6 + k]) : -kDblMax;
+      }
+    } else {
+      for (int k = 0; k < 6; k++) {
+        a[k] = s_red[k][0];
+        for (int w = 1; w < kBuildThreads / 64; w++) a[k] = k < 3 ? fmin(a[k], s_red[k][w]) : fmax(a[k], s_red[k][w]);
+      }
     }
     GridDesc g;
     if (ORDERED) grid_choose_morton(g, v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), n);
@@ -286,14 +299,6 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
 constexpr int kBigThreads = 256, kBigItems = 16, kBigChunk = kBigThreads * kBigItems;
 constexpr size_t kBigScratchBytes = kGridBigScratchBytes;  // per pair: box keys, cursors (loamx_internal.h)
 
-// doubles as unsigned keys with the same order (for atomicMin / atomicMax)
-__device__ __forceinline__ unsigned long long dbl_key(double v) {
-  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double key_dbl(unsigned long long k) {
-  return __longlong_as_double((long long)((k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k));
-}
 __device__ __forceinline__ unsigned char* big_scratch(GridPoint* scratch, size_t pair, size_t stride) {
   return reinterpret_cast<unsigned char*>(scratch + pair * stride);
 }
@@ -2188,9 +2193,12 @@ static void debug_ptr(const char* what, const void* p, size_t need) {
           (e != hipSuccess || off + need > size) ? "  <-- TOO SMALL / INVALID" : "");
 }
 
+// box_min / box_max: the sets' bounding boxes as the extraction left them (keys; entry [pair * in_pitch][axis] of the arrays
+// passed here, i.e. already offset to the scan role and feature kind), valid while *box_bad == 0; nullptr: none
 template <bool ORDERED>
 static void launch_grid_build(size_t n_pairs, const double* pts, const uint32_t* n_pts, size_t stride, uint32_t in_pitch,
-                              double max_dist, const GridSet& gs, GridPoint* scratch, uint32_t flags, hipStream_t s, unsigned long long* bytes) {
+                              double max_dist, const GridSet& gs, GridPoint* scratch, uint32_t flags, hipStream_t s, unsigned long long* bytes,
+                              const unsigned long long* box_min = nullptr, const unsigned long long* box_max = nullptr, const uint32_t* box_bad = nullptr) {
   if (g_debug_sync) {
     fprintf(stderr, "[loamx]   grid build ORDERED=%d n_pairs %zu stride %zu in_pitch %u gs.stride %zu\n", (int)ORDERED, n_pairs, stride, in_pitch, gs.stride);
     debug_ptr("pts", pts, n_pairs * in_pitch * stride * 24);
@@ -2207,16 +2215,19 @@ static void launch_grid_build(size_t n_pairs, const double* pts, const uint32_t*
   }
   if (grid_small(stride, flags))
     launch_kernel((grid_build_kernel<ORDERED, true>), dim3((unsigned)n_pairs), dim3(kBuildThreads), 0, s, pts, n_pts, stride,
-                       in_pitch, max_dist, gs, scratch, bytes);
+                       in_pitch, max_dist, gs, scratch, bytes, box_min, box_max, box_bad);
   else
     launch_kernel((grid_build_kernel<ORDERED, false>), dim3((unsigned)n_pairs), dim3(kBuildThreads), 0, s, pts, n_pts, stride,
-                       in_pitch, max_dist, gs, scratch, bytes);
+                       in_pitch, max_dist, gs, scratch, bytes, box_min, box_max, box_bad);
 }
 
 void launch_grid_build_target(const RegBatch& B, const RegConfig& C, bool plane, hipStream_t s) {
   if (B.n_pairs == 0) return;
-  if (plane) launch_grid_build<false>(B.n_pairs, B.tgt_planar, B.n_tgt_planar, B.planar_stride, B.in_pitch, C.r_plane, B.grid_plane, B.sort_scratch, C.flags, s, B.grid_bytes);
-  else launch_grid_build<false>(B.n_pairs, B.tgt_edge, B.n_tgt_edge, B.edge_stride, B.in_pitch, C.r_edge, B.grid_edge, B.sort_scratch, C.flags, s, B.grid_bytes);
+  // (boxes: [scan][kind][axis]; the target scan of pair p is scan p * in_pitch of the arrays in B)
+  const unsigned long long* bmin = B.box_min ? B.box_min + (plane ? 3 : 0) : nullptr;
+  const unsigned long long* bmax = B.box_max ? B.box_max + (plane ? 3 : 0) : nullptr;
+  if (plane) launch_grid_build<false>(B.n_pairs, B.tgt_planar, B.n_tgt_planar, B.planar_stride, B.in_pitch, C.r_plane, B.grid_plane, B.sort_scratch, C.flags, s, B.grid_bytes, bmin, bmax, B.box_bad);
+  else launch_grid_build<false>(B.n_pairs, B.tgt_edge, B.n_tgt_edge, B.edge_stride, B.in_pitch, C.r_edge, B.grid_edge, B.sort_scratch, C.flags, s, B.grid_bytes, bmin, bmax, B.box_bad);
 }
 void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   launch_grid_build_target(B, C, false, s);
@@ -2232,8 +2243,11 @@ void launch_grid_build_source(const RegBatch& B, const RegConfig& C, bool plane,
   const size_t stride = plane ? B.planar_stride : B.edge_stride;
   const uint32_t* n_src = plane ? B.n_src_planar : B.n_src_edge;
   const GridSet& gs = plane ? B.src_grid_plane : B.src_grid_edge;
+  // (boxes: the source scan of an interleaved pair is the scan behind its target scan)
+  const unsigned long long* bmin = (B.box_min && B.in_pitch == 2) ? B.box_min + 6 + (plane ? 3 : 0) : nullptr;
+  const unsigned long long* bmax = (B.box_max && B.in_pitch == 2) ? B.box_max + 6 + (plane ? 3 : 0) : nullptr;
   launch_grid_build<true>(B.n_pairs, plane ? B.src_planar : B.src_edge, n_src, stride, B.in_pitch, plane ? C.r_plane : C.r_edge, gs,
-                          B.sort_scratch_src, C.flags, s, B.grid_bytes);
+                          B.sort_scratch_src, C.flags, s, B.grid_bytes, bmin, bmax, B.box_bad);
   if (stride && !grid_small(stride, C.flags))
     launch_kernel(grid_rank_kernel, dim3((unsigned)((stride + kRankThreads - 1) / kRankThreads), (unsigned)B.n_pairs), dim3(kRankThreads), 0, s,
                   n_src, stride, B.in_pitch, gs, B.sort_scratch_src);

@@ -802,6 +802,14 @@ __global__ __launch_bounds__(FUSED ? 128 : 256, FUSED ? 3 : 4) void select_rows_
       run_e[r] = (uint32_t)__builtin_amdgcn_readlane((int)base_e, 16 * r), run_p[r] = (uint32_t)__builtin_amdgcn_readlane((int)base_p, 16 * r);
       rgo[r] = __builtin_amdgcn_readlane((int)go, 16 * r) != 0;
     }
+    // bounding boxes of the scan's edge / planar features (ExtractFused::box_*): every lane keeps the minima / maxima of the
+    // picks it copies; one reduction and twelve atomics per wavefront at the end
+    const bool want_box = fz.box_min != nullptr;  // uniform
+    double bmin[2][3], bmax[2][3];
+#pragma unroll
+    for (int kd = 0; kd < 2; kd++)
+#pragma unroll
+      for (int a = 0; a < 3; a++) bmin[kd][a] = 1.7976931348623157e308, bmax[kd][a] = -1.7976931348623157e308;
     double* xbuf = cbuf;                        // 3 * len doubles of one line's sector (the selection's buffers are free now)
     double* obuf = cbuf + 3 * (size_t)longest;  // 64 picked points on their way out (row_select_geom: both fit below off_sl)
     const unsigned char* pk_all = blk + G.off_pk;
@@ -854,6 +862,15 @@ __global__ __launch_bounds__(FUSED ? 128 : 256, FUSED ? 3 : 4) void select_rows_
             const double* src = xbuf + 3 * pos;
             const double x = src[0], y = src[1], z = src[2];
             if (on) (edge ? oe : op)[(edge ? run_e[rr] : run_p[rr]) + jj] = lb + pos;
+            if (want_box && on) {
+              if (edge) {
+                bmin[0][0] = fmin(bmin[0][0], x), bmin[0][1] = fmin(bmin[0][1], y), bmin[0][2] = fmin(bmin[0][2], z);
+                bmax[0][0] = fmax(bmax[0][0], x), bmax[0][1] = fmax(bmax[0][1], y), bmax[0][2] = fmax(bmax[0][2], z);
+              } else {
+                bmin[1][0] = fmin(bmin[1][0], x), bmin[1][1] = fmin(bmin[1][1], y), bmin[1][2] = fmin(bmin[1][2], z);
+                bmax[1][0] = fmax(bmax[1][0], x), bmax[1][1] = fmax(bmax[1][1], y), bmax[1][2] = fmax(bmax[1][2], z);
+              }
+            }
             obuf[3 * lane] = x, obuf[3 * lane + 1] = y, obuf[3 * lane + 2] = z;
             wave_lds_sync();
             // this round holds the edge picks [e0, e0 + ne) and the planar picks [p0, ...) of the sector, edge first
@@ -873,6 +890,20 @@ __global__ __launch_bounds__(FUSED ? 128 : 256, FUSED ? 3 : 4) void select_rows_
         }
         run_e[rr] += ce, run_p[rr] += cq;
       }
+    }
+    if (want_box) {  // (the four lines belong to one scan)
+#pragma unroll
+      for (int kd = 0; kd < 2; kd++)
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          double lo = bmin[kd][a], hi = bmax[kd][a];
+#pragma unroll
+          for (int off = 32; off >= 1; off >>= 1) lo = fmin(lo, __shfl_xor(lo, off)), hi = fmax(hi, __shfl_xor(hi, off));
+          if (lane == 0 && lo <= hi) {
+            atomicMin(fz.box_min + scan * 6 + kd * 3 + a, dbl_key(lo));
+            atomicMax(fz.box_max + scan * 6 + kd * 3 + a, dbl_key(hi));
+          }
+        }
     }
     ROWS_STAMP(6)
 #ifdef LOAMX_ROWS_PROFILE

@@ -186,6 +186,31 @@ def test_both_forms_of_the_queue_chain_give_the_same_bits():
     assert (one.view(capi.RESULT_DTYPE)["termination"] == capi.CONVERGED).all()
 
 
+def test_index_builds_with_the_extraction_s_bounding_boxes_give_the_same_bits():
+    """Round 5: in the scan-pair entry point the selection's copy phase hands the bounding boxes of every
+    scan's feature sets to the index builds, which then skip their own read pass. Minima and maxima are exact, so the grids,
+    and with them every result bit, are those of the builds that take the boxes themselves (NO_EXTRACT_BOXES) — also on a batch
+    with a noise-free scan, whose tied lines send the extraction through the fallback compaction (boxes withdrawn)."""
+    c = ctx()
+    P = 24
+    d_xyz, d_res = c.alloc(P * 2 * N * 24), c.alloc(P * 64)
+    c.synth_scan_pairs_dev(SEED, 4100, P, H, W, 0.01, d_xyz.ptr)
+    for tied in (False, True):
+        if tied:  # scan 5 (the source of pair 2) without noise
+            scans = d_xyz.download(np.float64, P * 2 * N * 3).reshape(P * 2, N, 3)
+            scans[5] = capi.synth_scan_host(302, 0, 0, H, W, 0.0)
+            d_xyz.upload(scans)
+        r0 = c.extract_counters()[0]
+        with option("NO_EXTRACT_BOXES"):
+            own = _run(c, d_xyz.ptr, P, d_res)
+        handed = _run(c, d_xyz.ptr, P, d_res)
+        if tied:
+            assert c.extract_counters()[0] > r0  # lines were replayed: the boxes were withdrawn on the device
+        assert np.array_equal(own, handed), tied
+    d_xyz.free()
+    d_res.free()
+
+
 def test_128_beam_batch_source_and_target_builds_do_not_share_scratch(oracle):
     """Feature sets above 20 480 points (128-beam scans: ~34 k planar features) take the index builds that need scratch
     memory — the multi-workgroup build of the target sets and the ordered single-workgroup build + rank of the source
