@@ -132,10 +132,24 @@ int loamx_ctx_extract_counters(loamx_ctx* ctx, uint64_t* tie_replays, uint64_t* 
 /* Debug / measurement switches of ONE context (no reference counterpart). loamx_ctx_create reads the environment
  * variables LOAMX_<NAME> once as the defaults (set = 1); no entry point looks at the environment afterwards, and a
  * switch only ever affects the context it was set on. None changes a result beyond the summation order of
- * NO_MOMENTS. Names (DESIGN.md section 5 describes each): FORCE_TIE_REPLAY, FORCE_SCAN_GIVEUP, CURV_V1,
- * NO_FUSED_COMPACT, NO_MIS_SELECT, FUSED_EXTRACT, NO_MOMENTS, NO_PACKED_GRID, NO_BIG_GRID, NO_GRID_SIDE,
- * DEBUG_POISON, QUEUE_TWO_STAGE, QUEUE_ONE_STAGE, NO_MIXED_ASSOC, MAP_CELLS_LOG2 (a number: 0 = default). Unknown
- * name: LOAMX_ERR_BAD_PARAM. */
+ * NO_MOMENTS (and CHECK_FINITE, which only adds a refusal). Names — the complete list; DESIGN.md section 5 describes each:
+ *   extraction:    FORCE_TIE_REPLAY, FORCE_SCAN_GIVEUP, CURV_V1, NO_FUSED_COMPACT, NO_MIS_SELECT, NO_ROW_SELECT, FUSED_EXTRACT,
+ *                  FUSED_ROWS
+ *   registration:  NO_MOMENTS, NO_REF_MOMENTS, NO_PACKED_GRID, NO_BIG_GRID, NO_GRID_SIDE, NO_EXTRACT_BOXES, DEBUG_POISON,
+ *                  QUEUE_TWO_STAGE, QUEUE_ONE_STAGE, NO_COOP_LEFT, NO_MIXED_ASSOC, MAP_CELLS_LOG2 (a number: 0 = default)
+ *   multi-GPU:     FORCE_RCCL (a one-rank communicator really enqueues the RCCL collectives)
+ *   input checks:  CHECK_FINITE (see "Non-finite input" below)
+ * Unknown name: LOAMX_ERR_BAD_PARAM.
+ *
+ * Non-finite input. The reference is undefined on NaN / Inf coordinates (loam/include/loam/features-inl.h:38 sorts on
+ * curvatures computed from them; a NaN range passes every comparison of loam/src/features.cpp:30-68; nanoflann and Ceres
+ * receive them as they are). Here: every HOST entry point (loamx_compute_curvature / _valid_points, loamx_extract_features,
+ * loamx_register_features / _indexed, loamx_associate, loamx_fit_lines / _planes, loamx_knn_search, loamx_target_index_create /
+ * _insert, and their _f32 forms) refuses such input with LOAMX_ERR_BAD_PARAM before anything is launched (an index is left
+ * as it was). The "_dev" entry points (loamx_extract_features_batch_dev, loamx_register_features_batch_dev,
+ * loamx_register_scan_pairs_dev, and their _f32 forms) do not look unless the context option CHECK_FINITE is set: then one
+ * small kernel and a 4-byte read-back precede the call (it synchronises) and non-finite input is refused the same way.
+ * Without it their result on such input is unspecified, as the reference's. */
 int loamx_ctx_set_option(loamx_ctx* ctx, const char* name, int value);
 int loamx_ctx_get_option(loamx_ctx* ctx, const char* name, int* value);
 

@@ -25,7 +25,7 @@ enum WsId {
   WS_XYZ = 0, WS_CURV, WS_MASK, WS_EDGE_STAGE, WS_PLANAR_STAGE, WS_EDGE_CNT, WS_PLANAR_CNT,
   WS_EDGE_IDX, WS_PLANAR_IDX, WS_N_EDGE, WS_N_PLANAR, WS_EDGE_XYZ, WS_PLANAR_XYZ,
   WS_GRID_DESC_E, WS_GRID_DESC_P, WS_CELLS_E, WS_CELLS_P, WS_SORTED_E, WS_SORTED_P, WS_REL_E, WS_REL_P,
-  WS_SGRID_DESC_E, WS_SGRID_DESC_P, WS_SCELLS_E, WS_SCELLS_P, WS_SSORTED_E, WS_SSORTED_P, WS_SORT_SCRATCH, WS_SORT_SCRATCH_SRC, WS_ASSOC_E, WS_ASSOC_P, WS_NN_E, WS_NN_P, WS_RNN_E, WS_RNN_P, WS_NEAREST_E, WS_NEAREST_P, WS_REST_E, WS_REST_P, WS_EXACT_E, WS_EXACT_P, WS_NASSOC, WS_STATE, WS_PARTIALS, WS_MOM_PARTIALS, WS_MOMENTS, WS_FLAGGED_LIST, WS_FLAGGED_COUNT, WS_LINE_TOT, WS_EXTRACT_EVENTS, WS_BOX,
+  WS_SGRID_DESC_E, WS_SGRID_DESC_P, WS_SCELLS_E, WS_SCELLS_P, WS_SSORTED_E, WS_SSORTED_P, WS_SORT_SCRATCH, WS_SORT_SCRATCH_SRC, WS_ASSOC_E, WS_ASSOC_P, WS_NN_E, WS_NN_P, WS_RNN_E, WS_RNN_P, WS_NEAREST_E, WS_NEAREST_P, WS_REST_E, WS_REST_P, WS_EXACT_E, WS_EXACT_P, WS_NASSOC, WS_STATE, WS_PARTIALS, WS_MOM_PARTIALS, WS_MOMENTS, WS_FLAGGED_LIST, WS_FLAGGED_COUNT, WS_LINE_TOT, WS_EXTRACT_EVENTS, WS_BOX, WS_FINITE_FLAG,
   WS_COUNTERS, WS_ITERINFO, WS_DUMP_E, WS_DUMP_P, WS_FIT_IN, WS_FIT_OUT, WS_SRC_E, WS_SRC_P, WS_TGT_E, WS_TGT_P, WS_FCOUNTS, WS_RESULTS, WS_INIT,
   WS_COUNT
 };
@@ -120,7 +120,7 @@ const OptionName kOptionNames[] = {
     {"QUEUE_TWO_STAGE", false, kRegFlagQueueTwoStage}, {"QUEUE_ONE_STAGE", false, kRegFlagQueueOneStage},
     {"NO_MIXED_ASSOC", false, kRegFlagNoMixedAssoc}, {"FORCE_RCCL", false, kRegFlagForceRccl},
     {"NO_COOP_LEFT", false, kRegFlagNoCoopLeft}, {"NO_REF_MOMENTS", false, kRegFlagNoRefMoments},
-    {"NO_EXTRACT_BOXES", false, kRegFlagNoExtractBoxes}};
+    {"NO_EXTRACT_BOXES", false, kRegFlagNoExtractBoxes}, {"CHECK_FINITE", false, kRegFlagCheckFinite}};
 
 int fail(loamx_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->last_error = msg;
@@ -153,6 +153,24 @@ int ensure(loamx_ctx* ctx, int id, size_t bytes) {
     if (rc_ != LOAMX_OK) return rc_;                 \
   } while (0)
 
+// ---- non-finite input (loamx.h: "Non-finite input") -------------------------------------------------------------------
+// The reference is undefined on NaN / Inf coordinates (features-inl.h:38 sorts on curvatures computed from them; nanoflann and
+// Ceres receive them as they are). Host entry points refuse such input; "_dev" entry points look only when the context option
+// CHECK_FINITE is set (one small kernel + a 4-byte read-back).
+const char* const kNonFiniteMsg = "non-finite coordinate in the input (the reference's behaviour is undefined there)";
+bool host_all_finite(const void* p, bool f32, size_t n_scalars) {
+  if (!p) return true;
+  if (f32) {
+    const float* v = static_cast<const float*>(p);
+    float acc = 0.0f;
+    for (size_t i = 0; i < n_scalars; i++) acc += v[i] * 0.0f;  // 0 unless some v[i] is NaN or infinite
+    return acc == 0.0f;
+  }
+  const double* v = static_cast<const double*>(p);
+  double acc = 0.0;
+  for (size_t i = 0; i < n_scalars; i++) acc += v[i] * 0.0;
+  return acc == 0.0;
+}
 template <typename T>
 T* wsp(loamx_ctx* ctx, int id) {
   return reinterpret_cast<T*>(ctx->ws[id].p);
@@ -213,6 +231,20 @@ struct TimedScope {
 };
 // call before enqueueing anything outside a TimedScope: the next scope must record its own start
 inline void untimed(loamx_ctx* ctx) { ctx->tail_fresh = false; }
+
+// d_n == nullptr: `stride` points per set
+int dev_check_finite(loamx_ctx* ctx, const void* d_pts, bool f32, const uint32_t* d_n, size_t n_sets, size_t stride, uint32_t pitch) {
+  if (!(ctx->reg_flags & kRegFlagCheckFinite) || !d_pts || n_sets == 0 || stride == 0) return LOAMX_OK;
+  ENSURE(ctx, WS_FINITE_FLAG, 16);
+  untimed(ctx);
+  HIP_TRY(ctx, hipMemsetAsync(ctx->ws[WS_FINITE_FLAG].p, 0, 16, ctx->stream));
+  launch_check_finite(d_pts, f32, d_n, n_sets, stride, pitch, static_cast<uint32_t*>(ctx->ws[WS_FINITE_FLAG].p), ctx->stream);
+  uint32_t bad = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&bad, ctx->ws[WS_FINITE_FLAG].p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return bad ? fail(ctx, LOAMX_ERR_BAD_PARAM, kNonFiniteMsg) : LOAMX_OK;
+}
+
 
 int check_launch(loamx_ctx* ctx, const char* what) {
   hipError_t e = hipGetLastError();
@@ -926,6 +958,8 @@ static int host_curv_mask(loamx_ctx* ctx, const void* xyz, bool f32, size_t n_po
   ExtractParams P;
   int rc = make_extract_params(ctx, lidar, fe, P);
   if (rc != LOAMX_OK) return rc;
+  if (!xyz) return fail(ctx, LOAMX_ERR_BAD_PARAM, "null argument");
+  if (!host_all_finite(xyz, f32, n_points * 3)) return fail(ctx, LOAMX_ERR_BAD_PARAM, kNonFiniteMsg);
   const size_t scalar = f32 ? sizeof(float) : sizeof(double);
   ENSURE(ctx, WS_XYZ, n_points * 3 * scalar);
   HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_XYZ].p, xyz, n_points * 3 * scalar, hipMemcpyHostToDevice, ctx->stream));
@@ -979,6 +1013,8 @@ static int host_extract(loamx_ctx* ctx, const void* xyz, bool f32, size_t n_poin
   if (rc != LOAMX_OK) return rc;
   const size_t ecap = edge_capacity(P), pcap = planar_capacity(P);
   const size_t scalar = f32 ? sizeof(float) : sizeof(double);
+  if (!xyz) return fail(ctx, LOAMX_ERR_BAD_PARAM, "null argument");
+  if (!host_all_finite(xyz, f32, n_points * 3)) return fail(ctx, LOAMX_ERR_BAD_PARAM, kNonFiniteMsg);
   ENSURE(ctx, WS_XYZ, n_points * 3 * scalar);
   ENSURE(ctx, WS_EDGE_IDX, ecap * sizeof(uint32_t));
   ENSURE(ctx, WS_PLANAR_IDX, pcap * sizeof(uint32_t));
@@ -1064,6 +1100,9 @@ static int register_features_impl(loamx_ctx* ctx, const loamx_target_index* inde
   }
   const size_t es = n_se > n_te ? n_se : n_te, ps = n_sp > n_tp ? n_sp : n_tp;
   if (es > 0x3FFFFFFFull || ps > 0x3FFFFFFFull) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "feature set too large");  // (queue entries: 30-bit query index + 2 flags)
+  if (!host_all_finite(src_edge, false, n_se * 3) || !host_all_finite(src_planar, false, n_sp * 3) || !host_all_finite(tgt_edge, false, n_te * 3) ||
+      !host_all_finite(tgt_planar, false, n_tp * 3) || !host_all_finite(init_pose, false, 7))
+    return fail(ctx, LOAMX_ERR_BAD_PARAM, kNonFiniteMsg);
   hipStream_t s = ctx->stream;
   const size_t esz = (es ? es : 1) * 3 * sizeof(double), psz = (ps ? ps : 1) * 3 * sizeof(double);
   ENSURE(ctx, WS_SRC_E, esz);
@@ -1138,6 +1177,7 @@ static int fit_sets(loamx_ctx* ctx, bool plane, const double* points, size_t n_s
   if (k > (size_t)kFitMaxK) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "point sets of more than 32 points are not supported by the fit kernels");
   if (n_sets > 0x7FFFFFFFull / 64) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "too many point sets in one call");
   const size_t pw = plane ? 4 : 6;
+  if (!host_all_finite(points, false, n_sets * k * 3)) return fail(ctx, LOAMX_ERR_BAD_PARAM, kNonFiniteMsg);
   untimed(ctx);
   ENSURE(ctx, WS_FIT_IN, n_sets * k * 24);
   ENSURE(ctx, WS_FIT_OUT, n_sets * (pw + 1) * sizeof(double));
@@ -1174,6 +1214,7 @@ int loamx_knn_search(loamx_ctx* ctx, const loamx_target_index* index, int which_
   }
   if (k > (size_t)kMaxK) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "k > 16 neighbours not supported by the search kernels");
   if (n_queries > 0x7FFFFFFFull / 64) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "too many queries in one call");
+  if (!host_all_finite(queries, false, n_queries * 3)) return fail(ctx, LOAMX_ERR_BAD_PARAM, kNonFiniteMsg);
   untimed(ctx);
   ENSURE(ctx, WS_FIT_IN, n_queries * 24);
   ENSURE(ctx, WS_FIT_OUT, n_queries * (k + 1) * sizeof(uint32_t));
@@ -1317,6 +1358,7 @@ int index_append(loamx_ctx* ctx, loamx_target_index* idx, const double* edge, si
   for (int k = 0; k < 2; k++) {
     if (idx->n[k] + add[k] > 0x0FFFFFFFull) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "feature set too large");
     if (add[k] && !host[k]) return fail(ctx, LOAMX_ERR_BAD_PARAM, "null point array");
+    if (!host_all_finite(host[k], false, add[k] * 3)) return fail(ctx, LOAMX_ERR_BAD_PARAM, kNonFiniteMsg);  // (the index stays as it was)
   }
   for (int k = 0; k < 2; k++) {  // all the room first: a failed allocation leaves the index as it was
     int rc = index_reserve(ctx, idx, k, add[k]);
@@ -1459,6 +1501,8 @@ static int extract_batch_dev(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t
   ExtractParams P;
   int rc = make_extract_params(ctx, lidar, fe, P);
   if (rc != LOAMX_OK) return rc;
+  rc = dev_check_finite(ctx, d_xyz, f32, nullptr, n_scans, (size_t)P.H * P.W, 1);
+  if (rc != LOAMX_OK) return rc;
   return extract_dev(ctx, d_xyz, f32, n_scans, P, d_edge_idx, d_n_edge, d_edge_xyz, d_planar_idx, d_n_planar, d_planar_xyz, false);
 }
 
@@ -1490,6 +1534,18 @@ int loamx_register_features_batch_dev(loamx_ctx* ctx, size_t n_pairs, const doub
   if (rc != LOAMX_OK) return rc;
   RegInputs in{n_pairs, edge_stride, planar_stride, 1, d_src_edge, d_src_planar, d_tgt_edge, d_tgt_planar,
                d_n_src_edge, d_n_src_planar, d_n_tgt_edge, d_n_tgt_planar, d_init};
+  if (ctx->reg_flags & kRegFlagCheckFinite) {
+    const struct { const double* p; const uint32_t* n; size_t stride; } sets[4] = {{d_src_edge, d_n_src_edge, edge_stride}, {d_src_planar, d_n_src_planar, planar_stride},
+                                                                                   {d_tgt_edge, d_n_tgt_edge, edge_stride}, {d_tgt_planar, d_n_tgt_planar, planar_stride}};
+    for (const auto& st : sets) {
+      rc = dev_check_finite(ctx, st.p, false, st.n, n_pairs, st.stride, 1);
+      if (rc != LOAMX_OK) return rc;
+    }
+    if (d_init) {
+      rc = dev_check_finite(ctx, d_init, false, nullptr, 1, (n_pairs * 7 + 2) / 3, 1);  // (7 doubles per pair; the kernel counts in points of 3)
+      if (rc != LOAMX_OK) return rc;
+    }
+  }
   return register_dev(ctx, in, C, d_results, false, nullptr, nullptr);
 }
 
@@ -1506,6 +1562,8 @@ static int register_scan_pairs(loamx_ctx* ctx, const void* d_xyz, bool f32, size
   if (rc != LOAMX_OK) return rc;
   if (n_pairs == 0) return LOAMX_OK;
   const size_t n_scans = 2 * n_pairs, ecap = edge_capacity(P), pcap = planar_capacity(P);
+  rc = dev_check_finite(ctx, d_xyz, f32, nullptr, n_scans, (size_t)P.H * P.W, 1);
+  if (rc != LOAMX_OK) return rc;
   ENSURE(ctx, WS_EDGE_IDX, n_scans * ecap * sizeof(uint32_t));
   ENSURE(ctx, WS_PLANAR_IDX, n_scans * pcap * sizeof(uint32_t));
   ENSURE(ctx, WS_N_EDGE, n_scans * sizeof(uint32_t));

@@ -134,6 +134,7 @@ constexpr uint32_t kRegFlagQueueOneStage = 64u;  // queue chain: always the FP64
 constexpr uint32_t kRegFlagForceRccl = 256u;     // a one-rank communicator really enqueues ncclAllGather / ncclBroadcast / ncclAllReduce (host side only)
 constexpr uint32_t kRegFlagNoCoopLeft = 512u;    // listed queue leftovers one lane per query (associate_knn_left_kernel, round 3), not one wavefront per query
 constexpr uint32_t kRegFlagNoRefMoments = 1024u;  // first ICF iteration as in round 3: five sweeps of the records, no moments
+constexpr uint32_t kRegFlagCheckFinite = 4096u;     // the "_dev" entry points look for non-finite input coordinates first (host side only)
 constexpr uint32_t kRegFlagNoExtractBoxes = 2048u;  // the index builds take their bounding boxes themselves even when the extraction left them
 constexpr uint32_t kRegFlagNoMixedAssoc = 128u;  // edge and plane first kernels as separate launches on two streams (launch_associate)
 
@@ -295,6 +296,11 @@ void launch_fit_sets(bool plane, const double* d_pts, size_t n_sets, int k, doub
 void launch_knn_queries(const GridSet& gs, const double* d_q, size_t n_q, int k, double max_dist, uint32_t* d_idx, uint32_t* d_count,
                         hipStream_t s);
 void launch_assoc_dump(const RegBatch& B, const RegConfig& C, const AssocDumpSet& edge, const AssocDumpSet& plane, hipStream_t s);
+
+/* ---- non-finite input check of the "_dev" entry points (context option CHECK_FINITE; synth_kernels.hip) --------- */
+// sets of `stride` points, `pitch` sets apart; d_n: points held by set i at d_n[i * pitch], or nullptr = all `stride`
+void launch_check_finite(const void* d_pts, bool f32, const uint32_t* d_n, size_t n_sets, size_t stride, uint32_t pitch, uint32_t* d_flag,
+                         hipStream_t s);
 
 /* ---- synthetic generator (synth_kernels.hip) --------------------------------------------------- */
 void launch_synth_pairs(uint64_t seed, uint64_t first_pair, size_t n_pairs, uint32_t H, uint32_t W, double sigma,
