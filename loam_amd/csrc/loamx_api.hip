@@ -1374,6 +1374,9 @@ int index_append(loamx_ctx* ctx, loamx_target_index* idx, const double* edge, si
     // a kind that receives nothing keeps its grid — also one grown by merges since its last full build (the size
     // at the last full build was compared here, and an edge-only insert re-sorted a million-point planar map)
     if (!merge[k] && (add[k] != 0 || !idx->grid_valid[k])) rebuild |= 1u << k;
+    // (from here on the grid no longer describes the set — n has grown — until the build or the merge below has
+    // succeeded; a failure in between must leave the flag down, so that the next insert rebuilds)
+    if (add[k] != 0) idx->grid_valid[k] = false;
     idx->n[k] += add[k];
   }
   // ---- merges: count the new points per cell (and learn whether they all lie inside the grid), then move + scatter
@@ -1428,6 +1431,7 @@ int index_append(loamx_ctx* ctx, loamx_target_index* idx, const double* edge, si
     if (rc != LOAMX_OK) return rc;
     std::swap(idx->sorted[k], idx->sorted2[k]);
     std::swap(idx->rel[k], idx->rel2[k]);
+    idx->grid_valid[k] = true;
     idx->merges++;
   }
   if (rebuild) return index_build(ctx, idx, rebuild);

@@ -917,6 +917,12 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_kn
 #define LOAMX_REST_THREADS 64
 #endif
 constexpr int kRestThreads = LOAMX_REST_THREADS;  // small workgroups: the queues are short and uneven
+// The listed leftovers of a queue: one WAVEFRONT per entry (associate_knn_coop_kernel) or one lane per entry
+// (associate_knn_left_kernel)? The cooperative search walks shells up to the one the radius closes; without a radius it falls
+// back to lane 0 alone, 63 lanes idle — such searches take the one-lane kernel's dense packing instead.
+__host__ __device__ inline bool queue_leftovers_coop(const RegConfig& C, bool plane) {
+  return !(C.flags & kRegFlagNoCoopLeft) && (plane ? C.r_plane : C.r_edge) > 0.0;
+}
 #ifndef LOAMX_REST_WAVES
 #define LOAMX_REST_WAVES 5  // measured (association scope): unconstrained (150 VGPRs, 3 waves/SIMD) 2.18 ms, 4 -> 2.12, 5 -> 2.11, 6 -> 2.14
 #endif
@@ -959,7 +965,7 @@ __global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_
 #pragma unroll
     for (int j = 0; j < KM; j++) pos[j] = 0;
     int kept = -1;
-    const bool coop = !one_stage && !(C.flags & kRegFlagNoCoopLeft);  // (wide entries: a dense block is the cooperative kernel's business)
+    const bool coop = !one_stage && queue_leftovers_coop(C, PLANE);  // (wide entries: a dense block is the cooperative kernel's business)
     if (one_stage || (!(entry & kQueueTied) && ((lean_set && !(entry & kQueueWide)) || ((entry & kQueueWide) && !coop)))) {
       const GridPoint sq = src_gs.sorted[pair * src_gs.stride + i];
       const Vec3 p = pose_act(S.est, v3(sq.x, sq.y, sq.z));
@@ -1214,6 +1220,8 @@ __device__ __forceinline__ int knn_coop_search(const GridDesc& g, const uint32_t
 
 // The listed leftovers, one WAVEFRONT per entry (see knn_coop_search); an entry the cooperative search does not apply to
 // (no radius limit) is searched by lane 0 alone, as associate_knn_left_kernel does it.
+// (one wavefront per workgroup: the entry loop steps by workgroups and s_rows is one lane's list — ADVICE r4)
+static_assert(kRestThreads == 64, "associate_knn_coop_kernel is written for one wavefront per workgroup");
 template <bool PLANE, int KM>
 __global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_coop_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
   size_t pair;
@@ -2331,7 +2339,7 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
     } else {                                                                                                      \
       launch_kernel((associate_knn_rest_kernel<PL, KMV, false>), dim3((unsigned)(pair_groups * 8 * rblk_)),  \
                          dim3(kRestThreads), 0, (st), B, C, rblk_);                                               \
-      if (C.flags & kRegFlagNoCoopLeft) {                                                                         \
+      if (!queue_leftovers_coop(C, (PL))) {                                                                       \
         launch_kernel((associate_knn_left_kernel<PL, KMV>), dim3((unsigned)(pair_groups * 8 * rblk_)),       \
                            dim3(kRestThreads), 0, (st), B, C, rblk_);                                             \
       } else {                                                                                                    \

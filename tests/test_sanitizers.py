@@ -17,8 +17,13 @@ def test_host_math_and_oracle_are_clean_under_asan_and_ubsan():
         return  # (this file is not part of SUITE; belt and braces against recursion)
     subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "hostcheck"), "san"])
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "san"])
-    asan = subprocess.check_output(["g++", "-print-file-name=libasan.so"], text=True).strip()
-    assert os.path.isabs(asan) and os.path.exists(asan), "libasan.so not found next to g++"
+    # the runtime of the SAME compiler the `san` targets use ($(CXX), make's default g++): a preloaded runtime of another
+    # compiler or version does not match the instrumented libraries. UBSan findings abort the child
+    # (-fno-sanitize-recover=undefined in SANFLAGS), so they fail it by exit code as well as by the grep below.
+    cxx = os.environ.get("CXX", "g++")
+    runtime = "libclang_rt.asan-x86_64.so" if "clang" in os.path.basename(cxx) else "libasan.so"
+    asan = subprocess.check_output([cxx, "-print-file-name=" + runtime], text=True).strip()
+    assert os.path.isabs(asan) and os.path.exists(asan), runtime + " not found next to " + cxx
     env = dict(os.environ, LD_PRELOAD=asan, LOAMX_IN_SANITIZER_CHILD="1",
                HOSTCHECK_LIB=os.path.join(HERE, "hostcheck", "libhostcheck_san.so"),
                ORACLE_LIB=os.path.join(ROOT, "oracle", "libloam_oracle_san.so"),
