@@ -120,7 +120,8 @@ const OptionName kOptionNames[] = {
     {"QUEUE_TWO_STAGE", false, kRegFlagQueueTwoStage}, {"QUEUE_ONE_STAGE", false, kRegFlagQueueOneStage},
     {"NO_MIXED_ASSOC", false, kRegFlagNoMixedAssoc}, {"FORCE_RCCL", false, kRegFlagForceRccl},
     {"NO_COOP_LEFT", false, kRegFlagNoCoopLeft}, {"NO_REF_MOMENTS", false, kRegFlagNoRefMoments},
-    {"NO_EXTRACT_BOXES", false, kRegFlagNoExtractBoxes}, {"CHECK_FINITE", false, kRegFlagCheckFinite}};
+    {"NO_EXTRACT_BOXES", false, kRegFlagNoExtractBoxes}, {"CHECK_FINITE", false, kRegFlagCheckFinite},
+    {"NO_SMALL_SETS", false, kRegFlagNoSmallSets}};
 
 int fail(loamx_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->last_error = msg;
@@ -645,6 +646,7 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C_in, loa
   B.max_counts = wsp<uint32_t>(ctx, WS_COUNTERS) + 16;  // bytes 64..88
   B.assoc_blocks_edge = B.assoc_blocks_plane = 0xFFFFFFFFu;
   B.knn_mode_edge = B.knn_mode_plane = 0u;
+  B.small_edge_sets = (C.flags & kRegFlagNoSmallSets) ? 0u : (!prebuilt ? 1u : (prebuilt->n[0] <= kBruteMax ? 2u : 0u));
   hipStream_t s = ctx->stream;
   // The per-pair state first: its kernel also finds the largest source sets, which come back to the host while
   // the index builds run (an event right behind the copy: the builds are already queued when the host waits).

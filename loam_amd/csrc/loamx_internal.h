@@ -134,6 +134,7 @@ constexpr uint32_t kRegFlagQueueOneStage = 64u;  // queue chain: always the FP64
 constexpr uint32_t kRegFlagForceRccl = 256u;     // a one-rank communicator really enqueues ncclAllGather / ncclBroadcast / ncclAllReduce (host side only)
 constexpr uint32_t kRegFlagNoCoopLeft = 512u;    // listed queue leftovers one lane per query (associate_knn_left_kernel, round 3), not one wavefront per query
 constexpr uint32_t kRegFlagNoRefMoments = 1024u;  // first ICF iteration as in round 3: five sweeps of the records, no moments
+constexpr uint32_t kRegFlagNoSmallSets = 8192u;     // edge-sized sets through grid_build_kernel like every other set
 constexpr uint32_t kRegFlagCheckFinite = 4096u;     // the "_dev" entry points look for non-finite input coordinates first (host side only)
 constexpr uint32_t kRegFlagNoExtractBoxes = 2048u;  // the index builds take their bounding boxes themselves even when the extraction left them
 constexpr uint32_t kRegFlagNoMixedAssoc = 128u;  // edge and plane first kernels as separate launches on two streams (launch_associate)
@@ -241,6 +242,8 @@ struct RegBatch {
   const unsigned long long* box_min;
   const unsigned long long* box_max;
   const uint32_t* box_bad;
+  uint32_t small_edge_sets;  // 1: pairs whose TARGET edge set holds at most kBruteMax points get both edge sets from small_sets_build_kernel;
+                             // 2: the target is a persistent index whose edge set is that small: every source edge set in its given order
 };
 
 // scratch the multi-workgroup build of a map-sized target set needs per pair (at B.sort_scratch + pair * stride points)

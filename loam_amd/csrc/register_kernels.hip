@@ -58,7 +58,10 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
                                                                    const uint32_t* __restrict__ n_pts, size_t stride,
                                                                    uint32_t in_pitch, double max_dist, GridSet gs, GridPoint* __restrict__ scratch,
                                                                    unsigned long long* __restrict__ bytes, const unsigned long long* __restrict__ box_min,
-                                                                   const unsigned long long* __restrict__ box_max, const uint32_t* __restrict__ box_bad) {
+                                                                   const unsigned long long* __restrict__ box_max, const uint32_t* __restrict__ box_bad,
+                                                                   const uint32_t* __restrict__ small_if) {
+  // (pairs whose target set of this kind is brute-force sized: small_sets_build_kernel builds both of their sets)
+  if (small_if && small_if[blockIdx.x * in_pitch] <= kBruteMax) return;
   __shared__ uint32_t s_cells[PACKED ? kGridLdsCells / 2 : kGridLdsCells];
   auto cell_get = [&](uint32_t c) -> uint32_t { return PACKED ? (s_cells[c >> 1] >> ((c & 1u) * 16u)) & 0xFFFFu : s_cells[c]; };
   auto cell_add = [&](uint32_t c) -> uint32_t {  // returns the value before the increment
@@ -287,6 +290,91 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const double*
            stamp[1] - stamp[0], stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4], stamp[6] - stamp[5], stamp[ns - 2] - stamp[ns - 3], stamp[ns - 1] - stamp[ns - 2]);
 #endif
 #undef STAMP
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Brute-force sized sets (round 5). A target set of at most kBruteMax points — the edge features of a scan — is searched
+ * by associate_knn_brute_kernel: every query scans all of it, its cell table is never read, and the order of the source
+ * queries does not matter for it either. grid_build_kernel gave each such set a 1 024-thread workgroup with 144 KB of LDS,
+ * i.e. a whole compute unit that a planar build could not share (two edge builds: ~120 us of the builds' 1.0 ms per step).
+ * This kernel builds BOTH sets of such a pair with 256 threads and a few hundred bytes of LDS, next to the planar builds:
+ * target = the same GridDesc as grid_build_kernel (grid_choose over the same box), the points in their given order with
+ * their float offsets; source = the points in their given order.
+ * ---------------------------------------------------------------------------------------------- */
+constexpr int kSmallThreads = 256;
+__global__ __launch_bounds__(kSmallThreads) void small_sets_build_kernel(const double* __restrict__ tgt_base, const uint32_t* __restrict__ n_tgt,
+                                                                         const double* __restrict__ src_base, const uint32_t* __restrict__ n_src,
+                                                                         size_t stride, uint32_t in_pitch, double max_dist, GridSet tgt_gs, GridSet src_gs,
+                                                                         unsigned long long* __restrict__ bytes, const unsigned long long* __restrict__ box_min,
+                                                                         const unsigned long long* __restrict__ box_max, const uint32_t* __restrict__ box_bad) {
+  __shared__ double s_red[6][kSmallThreads / 64];
+  __shared__ GridDesc s_g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t pair = blockIdx.x;
+  if (n_tgt == nullptr) {  // source sets only (the target lives in a persistent index whose set of this kind is brute-force sized)
+    const uint32_t ns_raw = n_src[pair * in_pitch];
+    const uint32_t ns = ns_raw < stride ? ns_raw : (uint32_t)stride;
+    const double* __restrict__ qp = src_base + pair * in_pitch * stride * 3;
+    GridPoint* __restrict__ ssp = src_gs.sorted + pair * src_gs.stride;
+    for (uint32_t i = tid; i < ns; i += kSmallThreads) ssp[i] = GridPoint{qp[3 * (size_t)i], qp[3 * (size_t)i + 1], qp[3 * (size_t)i + 2], i, 0u};
+    if (tid == 0 && bytes) atomicAdd(bytes, (unsigned long long)ns * 56ull);
+    return;
+  }
+  const uint32_t nt_raw = n_tgt[pair * in_pitch];
+  if (nt_raw > kBruteMax) return;  // uniform: grid_build_kernel takes this pair's sets
+  const uint32_t nt = nt_raw < stride ? nt_raw : (uint32_t)stride;
+  const double* __restrict__ tp = tgt_base + pair * in_pitch * stride * 3;
+  const bool have_box = box_min != nullptr && __hip_atomic_load(box_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;  // uniform
+  if (!have_box) {
+    double lx = kDblMax, ly = kDblMax, lz = kDblMax, hx = -kDblMax, hy = -kDblMax, hz = -kDblMax;
+    for (uint32_t i = tid; i < nt; i += kSmallThreads) {
+      const double x = tp[3 * (size_t)i], y = tp[3 * (size_t)i + 1], z = tp[3 * (size_t)i + 2];
+      lx = fmin(lx, x), ly = fmin(ly, y), lz = fmin(lz, z);
+      hx = fmax(hx, x), hy = fmax(hy, y), hz = fmax(hz, z);
+    }
+    lx = wave_min(lx), ly = wave_min(ly), lz = wave_min(lz);
+    hx = wave_max(hx), hy = wave_max(hy), hz = wave_max(hz);
+    if (lane == 0) {
+      s_red[0][wave] = lx, s_red[1][wave] = ly, s_red[2][wave] = lz;
+      s_red[3][wave] = hx, s_red[4][wave] = hy, s_red[5][wave] = hz;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double a[6];
+    if (have_box) {
+      for (int k = 0; k < 3; k++) {
+        a[k] = nt ? key_dbl(box_min[(pair * in_pitch) * 6 + k]) : kDblMax;
+        a[3 + k] = nt ? key_dbl(box_max[(pair * in_pitch) * 6 + k]) : -kDblMax;
+      }
+    } else {
+      for (int k = 0; k < 6; k++) {
+        a[k] = s_red[k][0];
+        for (int w = 1; w < kSmallThreads / 64; w++) a[k] = k < 3 ? fmin(a[k], s_red[k][w]) : fmax(a[k], s_red[k][w]);
+      }
+    }
+    GridDesc g;
+    grid_choose(g, v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), nt, max_dist, kGridCellsCap);
+    s_g = g;
+    tgt_gs.desc[pair] = g;
+  }
+  __syncthreads();
+  const GridDesc g = s_g;
+  GridPoint* __restrict__ sp = tgt_gs.sorted + pair * tgt_gs.stride;
+  float* __restrict__ rel = tgt_gs.rel ? tgt_gs.rel + pair * 3 * tgt_gs.stride : nullptr;
+  for (uint32_t p = tid; p < nt; p += kSmallThreads) {
+    const double x = tp[3 * (size_t)p], y = tp[3 * (size_t)p + 1], z = tp[3 * (size_t)p + 2];
+    sp[p] = GridPoint{x, y, z, p, 0u};
+    if (rel) rel[p] = (float)(x - g.ox), rel[tgt_gs.stride + p] = (float)(y - g.oy), rel[2 * tgt_gs.stride + p] = (float)(z - g.oz);
+  }
+  if (rel && (uint32_t)tid < kGridPad) rel[nt + tid] = kRelPad, rel[tgt_gs.stride + nt + tid] = kRelPad, rel[2 * tgt_gs.stride + nt + tid] = kRelPad;
+  // the source set: its points in their given order
+  const uint32_t ns_raw = n_src[pair * in_pitch];
+  const uint32_t ns = ns_raw < stride ? ns_raw : (uint32_t)stride;
+  const double* __restrict__ qp = src_base + pair * in_pitch * stride * 3;
+  GridPoint* __restrict__ ssp = src_gs.sorted + pair * src_gs.stride;
+  for (uint32_t i = tid; i < ns; i += kSmallThreads) ssp[i] = GridPoint{qp[3 * (size_t)i], qp[3 * (size_t)i + 1], qp[3 * (size_t)i + 2], i, 0u};
+  if (tid == 0 && bytes) atomicAdd(bytes, (unsigned long long)nt * (rel ? 68ull : 56ull) + (unsigned long long)ns * 56ull);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -595,8 +683,9 @@ __global__ __launch_bounds__(256) void index_insert_table_kernel(GridDesc* __res
 constexpr int kRankThreads = 256;
 __global__ __launch_bounds__(kRankThreads) void grid_rank_kernel(const uint32_t* __restrict__ n_pts, size_t stride,
                                                                  uint32_t in_pitch, GridSet gs,
-                                                                 const GridPoint* __restrict__ scratch) {
+                                                                 const GridPoint* __restrict__ scratch, const uint32_t* __restrict__ small_if) {
   const size_t pair = blockIdx.y;
+  if (small_if && small_if[pair * in_pitch] <= kBruteMax) return;  // (uniform: small_sets_build_kernel built this pair's set; nothing was scattered)
   const uint32_t n_raw = n_pts[pair * in_pitch];
   const uint32_t n = n_raw < stride ? n_raw : (uint32_t)stride;
   const uint32_t p = blockIdx.x * kRankThreads + threadIdx.x;
@@ -1813,11 +1902,25 @@ __global__ __launch_bounds__(64) void lm_pair_loop_kernel(RegBatch B, RegConfig 
 #pragma unroll
     for (int c = 0; c < kMomSize / 64; c++) v[c] = 0.0;
     double s0max = 0.0, v2max = 0.0;
-    for (uint32_t t = 0; t < used * 4; t++) {
+    // (four tiles' loads in flight at a time, added in tile order: the sum is the same, the wavefront waits for five round
+    // trips instead of twenty)
+    constexpr uint32_t kTileBatch = 4;
+    for (uint32_t t0 = 0; t0 < used * 4; t0 += kTileBatch) {
+      double w[kTileBatch][kMomSize / 64], m0[kTileBatch], m1[kTileBatch];
 #pragma unroll
-      for (int c = 0; c < kMomSize / 64; c++) v[c] += part[t * (size_t)(kMomSize + 2) + c * 64 + lane];
-      s0max = fmax(s0max, part[t * (size_t)(kMomSize + 2) + kMomSize]);  // (uniform loads)
-      v2max = fmax(v2max, part[t * (size_t)(kMomSize + 2) + kMomSize + 1]);
+      for (uint32_t b = 0; b < kTileBatch; b++) {
+        const bool in = t0 + b < used * 4;
+        const size_t off = (in ? t0 + b : t0) * (size_t)(kMomSize + 2);
+#pragma unroll
+        for (int c = 0; c < kMomSize / 64; c++) w[b][c] = in ? part[off + c * 64 + lane] : 0.0;
+        m0[b] = in ? part[off + kMomSize] : 0.0, m1[b] = in ? part[off + kMomSize + 1] : 0.0;  // (uniform loads; both maxima are >= 0)
+      }
+#pragma unroll
+      for (uint32_t b = 0; b < kTileBatch; b++) {
+#pragma unroll
+        for (int c = 0; c < kMomSize / 64; c++) v[c] += w[b][c];
+        s0max = fmax(s0max, m0[b]), v2max = fmax(v2max, m1[b]);
+      }
     }
 #pragma unroll
     for (int c = 0; c < kMomSize / 64; c++) mom[c * 64 + lane] = v[c], s_mom[c * 64 + lane] = v[c];
@@ -2206,7 +2309,8 @@ static void debug_ptr(const char* what, const void* p, size_t need) {
 template <bool ORDERED>
 static void launch_grid_build(size_t n_pairs, const double* pts, const uint32_t* n_pts, size_t stride, uint32_t in_pitch,
                               double max_dist, const GridSet& gs, GridPoint* scratch, uint32_t flags, hipStream_t s, unsigned long long* bytes,
-                              const unsigned long long* box_min = nullptr, const unsigned long long* box_max = nullptr, const uint32_t* box_bad = nullptr) {
+                              const unsigned long long* box_min = nullptr, const unsigned long long* box_max = nullptr, const uint32_t* box_bad = nullptr,
+                              const uint32_t* small_if = nullptr) {
   if (g_debug_sync) {
     fprintf(stderr, "[loamx]   grid build ORDERED=%d n_pairs %zu stride %zu in_pitch %u gs.stride %zu\n", (int)ORDERED, n_pairs, stride, in_pitch, gs.stride);
     debug_ptr("pts", pts, n_pairs * in_pitch * stride * 24);
@@ -2223,10 +2327,10 @@ static void launch_grid_build(size_t n_pairs, const double* pts, const uint32_t*
   }
   if (grid_small(stride, flags))
     launch_kernel((grid_build_kernel<ORDERED, true>), dim3((unsigned)n_pairs), dim3(kBuildThreads), 0, s, pts, n_pts, stride,
-                       in_pitch, max_dist, gs, scratch, bytes, box_min, box_max, box_bad);
+                       in_pitch, max_dist, gs, scratch, bytes, box_min, box_max, box_bad, small_if);
   else
     launch_kernel((grid_build_kernel<ORDERED, false>), dim3((unsigned)n_pairs), dim3(kBuildThreads), 0, s, pts, n_pts, stride,
-                       in_pitch, max_dist, gs, scratch, bytes, box_min, box_max, box_bad);
+                       in_pitch, max_dist, gs, scratch, bytes, box_min, box_max, box_bad, small_if);
 }
 
 void launch_grid_build_target(const RegBatch& B, const RegConfig& C, bool plane, hipStream_t s) {
@@ -2235,7 +2339,13 @@ void launch_grid_build_target(const RegBatch& B, const RegConfig& C, bool plane,
   const unsigned long long* bmin = B.box_min ? B.box_min + (plane ? 3 : 0) : nullptr;
   const unsigned long long* bmax = B.box_max ? B.box_max + (plane ? 3 : 0) : nullptr;
   if (plane) launch_grid_build<false>(B.n_pairs, B.tgt_planar, B.n_tgt_planar, B.planar_stride, B.in_pitch, C.r_plane, B.grid_plane, B.sort_scratch, C.flags, s, B.grid_bytes, bmin, bmax, B.box_bad);
-  else launch_grid_build<false>(B.n_pairs, B.tgt_edge, B.n_tgt_edge, B.edge_stride, B.in_pitch, C.r_edge, B.grid_edge, B.sort_scratch, C.flags, s, B.grid_bytes, bmin, bmax, B.box_bad);
+  else {
+    launch_grid_build<false>(B.n_pairs, B.tgt_edge, B.n_tgt_edge, B.edge_stride, B.in_pitch, C.r_edge, B.grid_edge, B.sort_scratch, C.flags, s, B.grid_bytes, bmin, bmax, B.box_bad,
+                             B.small_edge_sets == 1u ? B.n_tgt_edge : nullptr);
+    if (B.small_edge_sets == 1u)  // (both edge sets of the pairs whose target edge set is brute-force sized)
+      launch_kernel(small_sets_build_kernel, dim3((unsigned)B.n_pairs), dim3(kSmallThreads), 0, s, B.tgt_edge, B.n_tgt_edge, B.src_edge, B.n_src_edge, B.edge_stride,
+                    B.in_pitch, C.r_edge, B.grid_edge, B.src_grid_edge, B.grid_bytes, bmin, bmax, B.box_bad);
+  }
 }
 void launch_grid_build_targets(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   launch_grid_build_target(B, C, false, s);
@@ -2252,13 +2362,19 @@ void launch_grid_build_source(const RegBatch& B, const RegConfig& C, bool plane,
   const uint32_t* n_src = plane ? B.n_src_planar : B.n_src_edge;
   const GridSet& gs = plane ? B.src_grid_plane : B.src_grid_edge;
   // (boxes: the source scan of an interleaved pair is the scan behind its target scan)
+  if (!plane && B.small_edge_sets == 2u) {  // (persistent index with a brute-force sized edge set: the sources in their given order, as in a plain call)
+    launch_kernel(small_sets_build_kernel, dim3((unsigned)B.n_pairs), dim3(kSmallThreads), 0, s, static_cast<const double*>(nullptr), static_cast<const uint32_t*>(nullptr),
+                  B.src_edge, B.n_src_edge, B.edge_stride, B.in_pitch, C.r_edge, B.grid_edge, B.src_grid_edge, B.grid_bytes, static_cast<const unsigned long long*>(nullptr),
+                  static_cast<const unsigned long long*>(nullptr), static_cast<const uint32_t*>(nullptr));
+    return;
+  }
   const unsigned long long* bmin = (B.box_min && B.in_pitch == 2) ? B.box_min + 6 + (plane ? 3 : 0) : nullptr;
   const unsigned long long* bmax = (B.box_max && B.in_pitch == 2) ? B.box_max + 6 + (plane ? 3 : 0) : nullptr;
   launch_grid_build<true>(B.n_pairs, plane ? B.src_planar : B.src_edge, n_src, stride, B.in_pitch, plane ? C.r_plane : C.r_edge, gs,
-                          B.sort_scratch_src, C.flags, s, B.grid_bytes, bmin, bmax, B.box_bad);
+                          B.sort_scratch_src, C.flags, s, B.grid_bytes, bmin, bmax, B.box_bad, (!plane && B.small_edge_sets == 1u) ? B.n_tgt_edge : nullptr);
   if (stride && !grid_small(stride, C.flags))
     launch_kernel(grid_rank_kernel, dim3((unsigned)((stride + kRankThreads - 1) / kRankThreads), (unsigned)B.n_pairs), dim3(kRankThreads), 0, s,
-                  n_src, stride, B.in_pitch, gs, B.sort_scratch_src);
+                  n_src, stride, B.in_pitch, gs, B.sort_scratch_src, (!plane && B.small_edge_sets == 1u) ? B.n_tgt_edge : nullptr);
 }
 void launch_grid_build_sources(const RegBatch& B, const RegConfig& C, hipStream_t s) {
   launch_grid_build_source(B, C, false, s);

@@ -220,6 +220,27 @@ def test_index_builds_with_the_extraction_s_bounding_boxes_give_the_same_bits():
     d_res.free()
 
 
+def test_small_sets_build_agrees_with_the_big_build(oracle):
+    """Round 5: pairs whose target edge set is brute-force sized (at most 512 points) get both edge sets from
+    small_sets_build_kernel — the same grid, the points in their given order — instead of two 1 024-thread builds. The source
+    edges then reach the sums in another order than the Morton order of grid_build_kernel (NO_SMALL_SETS): same terminations
+    and iteration counts, poses within the summation-order noise."""
+    c = ctx()
+    P = 48
+    d_xyz, d_res = c.alloc(P * 2 * N * 24), c.alloc(P * 64)
+    c.synth_scan_pairs_dev(SEED, 5200, P, H, W, 0.01, d_xyz.ptr)
+    small = _run(c, d_xyz.ptr, P, d_res).view(capi.RESULT_DTYPE)
+    with option("NO_SMALL_SETS"):
+        big = _run(c, d_xyz.ptr, P, d_res).view(capi.RESULT_DTYPE)
+    d_xyz.free()
+    d_res.free()
+    assert np.array_equal(small["termination"], big["termination"]) and np.array_equal(small["iterations"], big["iterations"])
+    assert not np.array_equal(small["pose"], big["pose"])  # (the other build really ran)
+    for pr in range(P):
+        rot, trans = pose_diff(oracle, small[pr]["pose"], big[pr]["pose"])
+        assert rot < 1e-9 and trans < 1e-9, (pr, rot, trans)
+
+
 def test_128_beam_batch_source_and_target_builds_do_not_share_scratch(oracle):
     """Feature sets above 20 480 points (128-beam scans: ~34 k planar features) take the index builds that need scratch
     memory — the multi-workgroup build of the target sets and the ordered single-workgroup build + rank of the source
