@@ -105,7 +105,7 @@ def main():
         out = {}
         alias = {"curvature_valid_kernel": "curvature_valid_kernel", "sweep_kernel": "sweep_kernel", "moment_kernel": "moment_kernel",
                  "select_kernel<4>": "select_kernel", "select_mis_kernel<2, 4>": "select_kernel"}
-        alias.update({k: "select_kernel" for k in pmc if k.startswith("select_mis_kernel")})
+        alias.update({k: "select_kernel" for k in pmc if k.startswith("select_mis_kernel") or k.startswith("select_rows_kernel")})
         for k in sorted(pmc):
             f = pmc[k].get("FETCH_SIZE", {"dispatches": 0, "kib_total_reported": 0.0})
             w = pmc[k].get("WRITE_SIZE", {"dispatches": 0, "kib_total_reported": 0.0})
