@@ -48,7 +48,7 @@ VALU_PEAK_GINST = 256 * 4 * 2.4 / VALU_CYCLES_PER_INST
 SEED = 20240311
 H, W = 64, 1024
 SIGMA = 0.01
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")
 
 
 def parse_args():
