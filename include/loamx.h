@@ -145,8 +145,8 @@ int loamx_ctx_extract_counters(loamx_ctx* ctx, uint64_t* tie_replays, uint64_t* 
  * curvatures computed from them; a NaN range passes every comparison of loam/src/features.cpp:30-68; nanoflann and Ceres
  * receive them as they are). Here: every HOST entry point (loamx_compute_curvature / _valid_points, loamx_extract_features,
  * loamx_register_features / _indexed, loamx_associate, loamx_fit_lines / _planes, loamx_knn_search, loamx_target_index_create /
- * _insert, and their _f32 forms) refuses such input with LOAMX_ERR_BAD_PARAM before anything is launched (an index is left
- * as it was). The "_dev" entry points (loamx_extract_features_batch_dev, loamx_register_features_batch_dev,
+ * _insert, and their _f32 forms) refuses such input with LOAMX_ERR_BAD_PARAM: its uploaded copy is looked at by one small
+ * kernel before anything else is launched (a 4-byte read-back, one extra stream synchronisation; an index is left as it was). The "_dev" entry points (loamx_extract_features_batch_dev, loamx_register_features_batch_dev,
  * loamx_register_scan_pairs_dev, and their _f32 forms) do not look unless the context option CHECK_FINITE is set: then one
  * small kernel and a 4-byte read-back precede the call (it synchronises) and non-finite input is refused the same way.
  * Without it their result on such input is unspecified, as the reference's. */

@@ -233,17 +233,31 @@ struct TimedScope {
 // call before enqueueing anything outside a TimedScope: the next scope must record its own start
 inline void untimed(loamx_ctx* ctx) { ctx->tail_fresh = false; }
 
-// d_n == nullptr: `stride` points per set
-int dev_check_finite(loamx_ctx* ctx, const void* d_pts, bool f32, const uint32_t* d_n, size_t n_sets, size_t stride, uint32_t pitch) {
-  if (!(ctx->reg_flags & kRegFlagCheckFinite) || !d_pts || n_sets == 0 || stride == 0) return LOAMX_OK;
+// The check itself runs on the device in every case (a CPU loop over a 128 x 2048 scan costs more than its upload): zero the
+// flag word, one finite_kernel launch per array, a 4-byte read-back. Host entry points do it on their uploaded copies before
+// they launch anything else (one extra stream synchronisation, ~30 us); "_dev" entry points only under CHECK_FINITE.
+int finite_begin(loamx_ctx* ctx) {
   ENSURE(ctx, WS_FINITE_FLAG, 16);
   untimed(ctx);
   HIP_TRY(ctx, hipMemsetAsync(ctx->ws[WS_FINITE_FLAG].p, 0, 16, ctx->stream));
-  launch_check_finite(d_pts, f32, d_n, n_sets, stride, pitch, static_cast<uint32_t*>(ctx->ws[WS_FINITE_FLAG].p), ctx->stream);
+  return LOAMX_OK;
+}
+// d_n == nullptr: `stride` points per set
+void finite_add(loamx_ctx* ctx, const void* d_pts, bool f32, const uint32_t* d_n, size_t n_sets, size_t stride, uint32_t pitch) {
+  if (d_pts && n_sets && stride) launch_check_finite(d_pts, f32, d_n, n_sets, stride, pitch, static_cast<uint32_t*>(ctx->ws[WS_FINITE_FLAG].p), ctx->stream);
+}
+int finite_end(loamx_ctx* ctx) {
   uint32_t bad = 0;
   HIP_TRY(ctx, hipMemcpyAsync(&bad, ctx->ws[WS_FINITE_FLAG].p, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return bad ? fail(ctx, LOAMX_ERR_BAD_PARAM, kNonFiniteMsg) : LOAMX_OK;
+}
+int dev_check_finite(loamx_ctx* ctx, const void* d_pts, bool f32, const uint32_t* d_n, size_t n_sets, size_t stride, uint32_t pitch, bool force = false) {
+  if ((!force && !(ctx->reg_flags & kRegFlagCheckFinite)) || !d_pts || n_sets == 0 || stride == 0) return LOAMX_OK;
+  int rc = finite_begin(ctx);
+  if (rc != LOAMX_OK) return rc;
+  finite_add(ctx, d_pts, f32, d_n, n_sets, stride, pitch);
+  return finite_end(ctx);
 }
 
 
@@ -961,10 +975,11 @@ static int host_curv_mask(loamx_ctx* ctx, const void* xyz, bool f32, size_t n_po
   int rc = make_extract_params(ctx, lidar, fe, P);
   if (rc != LOAMX_OK) return rc;
   if (!xyz) return fail(ctx, LOAMX_ERR_BAD_PARAM, "null argument");
-  if (!host_all_finite(xyz, f32, n_points * 3)) return fail(ctx, LOAMX_ERR_BAD_PARAM, kNonFiniteMsg);
   const size_t scalar = f32 ? sizeof(float) : sizeof(double);
   ENSURE(ctx, WS_XYZ, n_points * 3 * scalar);
   HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_XYZ].p, xyz, n_points * 3 * scalar, hipMemcpyHostToDevice, ctx->stream));
+  rc = dev_check_finite(ctx, ctx->ws[WS_XYZ].p, f32, nullptr, 1, n_points, 1, true);
+  if (rc != LOAMX_OK) return rc;
   rc = extract_dev(ctx, ctx->ws[WS_XYZ].p, f32, 1, P, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true);
   if (rc != LOAMX_OK) return rc;
   if (curvature_out)
@@ -1016,13 +1031,14 @@ static int host_extract(loamx_ctx* ctx, const void* xyz, bool f32, size_t n_poin
   const size_t ecap = edge_capacity(P), pcap = planar_capacity(P);
   const size_t scalar = f32 ? sizeof(float) : sizeof(double);
   if (!xyz) return fail(ctx, LOAMX_ERR_BAD_PARAM, "null argument");
-  if (!host_all_finite(xyz, f32, n_points * 3)) return fail(ctx, LOAMX_ERR_BAD_PARAM, kNonFiniteMsg);
   ENSURE(ctx, WS_XYZ, n_points * 3 * scalar);
   ENSURE(ctx, WS_EDGE_IDX, ecap * sizeof(uint32_t));
   ENSURE(ctx, WS_PLANAR_IDX, pcap * sizeof(uint32_t));
   ENSURE(ctx, WS_N_EDGE, sizeof(uint32_t));
   ENSURE(ctx, WS_N_PLANAR, sizeof(uint32_t));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_XYZ].p, xyz, n_points * 3 * scalar, hipMemcpyHostToDevice, ctx->stream));
+  rc = dev_check_finite(ctx, ctx->ws[WS_XYZ].p, f32, nullptr, 1, n_points, 1, true);
+  if (rc != LOAMX_OK) return rc;
   rc = extract_dev(ctx, ctx->ws[WS_XYZ].p, f32, 1, P, wsp<uint32_t>(ctx, WS_EDGE_IDX), wsp<uint32_t>(ctx, WS_N_EDGE), nullptr,
                    wsp<uint32_t>(ctx, WS_PLANAR_IDX), wsp<uint32_t>(ctx, WS_N_PLANAR), nullptr, false);
   if (rc != LOAMX_OK) return rc;
@@ -1102,9 +1118,7 @@ static int register_features_impl(loamx_ctx* ctx, const loamx_target_index* inde
   }
   const size_t es = n_se > n_te ? n_se : n_te, ps = n_sp > n_tp ? n_sp : n_tp;
   if (es > 0x3FFFFFFFull || ps > 0x3FFFFFFFull) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "feature set too large");  // (queue entries: 30-bit query index + 2 flags)
-  if (!host_all_finite(src_edge, false, n_se * 3) || !host_all_finite(src_planar, false, n_sp * 3) || !host_all_finite(tgt_edge, false, n_te * 3) ||
-      !host_all_finite(tgt_planar, false, n_tp * 3) || !host_all_finite(init_pose, false, 7))
-    return fail(ctx, LOAMX_ERR_BAD_PARAM, kNonFiniteMsg);
+  if (!host_all_finite(init_pose, false, 7)) return fail(ctx, LOAMX_ERR_BAD_PARAM, kNonFiniteMsg);
   hipStream_t s = ctx->stream;
   const size_t esz = (es ? es : 1) * 3 * sizeof(double), psz = (ps ? ps : 1) * 3 * sizeof(double);
   ENSURE(ctx, WS_SRC_E, esz);
@@ -1119,6 +1133,14 @@ static int register_features_impl(loamx_ctx* ctx, const loamx_target_index* inde
   if (n_sp) HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_SRC_P].p, src_planar, n_sp * 24, hipMemcpyHostToDevice, s));
   if (n_tp) HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_TGT_P].p, tgt_planar, n_tp * 24, hipMemcpyHostToDevice, s));
   const uint32_t counts[4] = {(uint32_t)n_se, (uint32_t)n_sp, (uint32_t)n_te, (uint32_t)n_tp};
+  {  // non-finite coordinates are refused before anything else is launched (loamx.h: "Non-finite input")
+    rc = finite_begin(ctx);
+    if (rc != LOAMX_OK) return rc;
+    finite_add(ctx, ctx->ws[WS_SRC_E].p, false, nullptr, 1, n_se, 1), finite_add(ctx, ctx->ws[WS_TGT_E].p, false, nullptr, 1, n_te, 1);
+    finite_add(ctx, ctx->ws[WS_SRC_P].p, false, nullptr, 1, n_sp, 1), finite_add(ctx, ctx->ws[WS_TGT_P].p, false, nullptr, 1, n_tp, 1);
+    rc = finite_end(ctx);
+    if (rc != LOAMX_OK) return rc;
+  }
   HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_FCOUNTS].p, counts, sizeof(counts), hipMemcpyHostToDevice, s));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_INIT].p, init_pose, 7 * sizeof(double), hipMemcpyHostToDevice, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));  // `counts` is a stack array
@@ -1179,7 +1201,6 @@ static int fit_sets(loamx_ctx* ctx, bool plane, const double* points, size_t n_s
   if (k > (size_t)kFitMaxK) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "point sets of more than 32 points are not supported by the fit kernels");
   if (n_sets > 0x7FFFFFFFull / 64) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "too many point sets in one call");
   const size_t pw = plane ? 4 : 6;
-  if (!host_all_finite(points, false, n_sets * k * 3)) return fail(ctx, LOAMX_ERR_BAD_PARAM, kNonFiniteMsg);
   untimed(ctx);
   ENSURE(ctx, WS_FIT_IN, n_sets * k * 24);
   ENSURE(ctx, WS_FIT_OUT, n_sets * (pw + 1) * sizeof(double));
@@ -1187,6 +1208,10 @@ static int fit_sets(loamx_ctx* ctx, bool plane, const double* points, size_t n_s
   double* d_aux = d_prim + n_sets * pw;
   hipStream_t s = ctx->stream;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_FIT_IN].p, points, n_sets * k * 24, hipMemcpyHostToDevice, s));
+  {
+    int rc = dev_check_finite(ctx, ctx->ws[WS_FIT_IN].p, false, nullptr, 1, n_sets * k, 1, true);
+    if (rc != LOAMX_OK) return rc;
+  }
   launch_fit_sets(plane, wsp<double>(ctx, WS_FIT_IN), n_sets, (int)k, d_prim, d_aux, s);
   CHECK_LAUNCH(ctx, "fit_sets_kernel");
   HIP_TRY(ctx, hipMemcpyAsync(prim_out, d_prim, n_sets * pw * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1216,7 +1241,6 @@ int loamx_knn_search(loamx_ctx* ctx, const loamx_target_index* index, int which_
   }
   if (k > (size_t)kMaxK) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "k > 16 neighbours not supported by the search kernels");
   if (n_queries > 0x7FFFFFFFull / 64) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "too many queries in one call");
-  if (!host_all_finite(queries, false, n_queries * 3)) return fail(ctx, LOAMX_ERR_BAD_PARAM, kNonFiniteMsg);
   untimed(ctx);
   ENSURE(ctx, WS_FIT_IN, n_queries * 24);
   ENSURE(ctx, WS_FIT_OUT, n_queries * (k + 1) * sizeof(uint32_t));
@@ -1224,6 +1248,10 @@ int loamx_knn_search(loamx_ctx* ctx, const loamx_target_index* index, int which_
   uint32_t* d_cnt = d_idx + n_queries * k;
   hipStream_t s = ctx->stream;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[WS_FIT_IN].p, queries, n_queries * 24, hipMemcpyHostToDevice, s));
+  {
+    int rc = dev_check_finite(ctx, ctx->ws[WS_FIT_IN].p, false, nullptr, 1, n_queries, 1, true);
+    if (rc != LOAMX_OK) return rc;
+  }
   const int w = which_set;
   const GridSet gs{index->desc[w], index->cells[w], index->sorted[w], index->cap[w] + kGridPad, index->rel[w], index->cells_cap[w]};
   launch_knn_queries(gs, wsp<double>(ctx, WS_FIT_IN), n_queries, (int)k, max_dist, d_idx, d_cnt, s);
@@ -1360,18 +1388,31 @@ int index_append(loamx_ctx* ctx, loamx_target_index* idx, const double* edge, si
   for (int k = 0; k < 2; k++) {
     if (idx->n[k] + add[k] > 0x0FFFFFFFull) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "feature set too large");
     if (add[k] && !host[k]) return fail(ctx, LOAMX_ERR_BAD_PARAM, "null point array");
-    if (!host_all_finite(host[k], false, add[k] * 3)) return fail(ctx, LOAMX_ERR_BAD_PARAM, kNonFiniteMsg);  // (the index stays as it was)
+  }
+  hipStream_t s = ctx->stream;
+  // The new points go to a staging buffer first and are looked at there (loamx.h: "Non-finite input"): a refused insert must
+  // leave the index as it was, and making room (index_reserve) already re-allocates its arrays.
+  ENSURE(ctx, WS_FIT_IN, (add[0] + add[1] ? add[0] + add[1] : 1) * 24);
+  double* stage[2] = {wsp<double>(ctx, WS_FIT_IN), wsp<double>(ctx, WS_FIT_IN) + add[0] * 3};
+  {
+    for (int k = 0; k < 2; k++)
+      if (add[k]) HIP_TRY(ctx, hipMemcpyAsync(stage[k], host[k], add[k] * 24, hipMemcpyHostToDevice, s));
+    int rc = finite_begin(ctx);
+    if (rc != LOAMX_OK) return rc;
+    for (int k = 0; k < 2; k++) finite_add(ctx, stage[k], false, nullptr, 1, add[k], 1);
+    rc = finite_end(ctx);
+    if (rc != LOAMX_OK) return rc;
   }
   for (int k = 0; k < 2; k++) {  // all the room first: a failed allocation leaves the index as it was
     int rc = index_reserve(ctx, idx, k, add[k]);
     if (rc != LOAMX_OK) return rc;
   }
-  hipStream_t s = ctx->stream;
   const size_t n_old[2] = {idx->n[0], idx->n[1]};
   unsigned rebuild = 0u;
   bool merge[2] = {false, false};
+  for (int k = 0; k < 2; k++)  // the new points behind the sets
+    if (add[k]) HIP_TRY(ctx, hipMemcpyAsync(idx->pts[k] + idx->n[k] * 3, stage[k], add[k] * 24, hipMemcpyDeviceToDevice, s));
   for (int k = 0; k < 2; k++) {
-    if (add[k]) HIP_TRY(ctx, hipMemcpyAsync(idx->pts[k] + idx->n[k] * 3, host[k], add[k] * 24, hipMemcpyHostToDevice, s));
     merge[k] = add[k] != 0 && index_can_merge(idx, k, add[k]);
     // a kind that receives nothing keeps its grid — also one grown by merges since its last full build (the size
     // at the last full build was compared here, and an edge-only insert re-sorted a million-point planar map)
