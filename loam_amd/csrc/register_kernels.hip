@@ -1171,6 +1171,8 @@ __device__ __forceinline__ int knn_coop_search(const GridDesc& g, const uint32_t
   KnnKeys<KM> c;
   knn_init(c, k, g.n_points);
   bool done = false;
+  double kth = knn_key_empty();  // the k-th smallest key of the wavefront after the last shell that offered a candidate
+  bool fresh = false;            // (wave-uniform) candidates were offered since kth was drawn
   for (int32_t w = 1; w <= W && !done; w++) {
     // pieces of shell w: the rows at Chebyshev distance w over x in [cx - w, cx + w] (shell 1: all nine rows of the block,
     // centre first), then for w > 1 the two end cells cx -+ w of every row inside
@@ -1237,6 +1239,7 @@ __device__ __forceinline__ int knn_coop_search(const GridDesc& g, const uint32_t
         const uint32_t begin = (uint32_t)__builtin_amdgcn_readlane((int)rb, b), end = (uint32_t)__builtin_amdgcn_readlane((int)re, b);
         const double rs2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s2), b), __builtin_amdgcn_readlane(__double2loint(s2), b));
         if (rs2 > bound) continue;  // (the bound has moved since the piece was listed)
+        fresh = true;
         for (uint32_t p0 = begin; p0 < end; p0 += 64) {
           const uint32_t p = p0 + (uint32_t)lane;
           const bool real = p < end;
@@ -1254,8 +1257,12 @@ __device__ __forceinline__ int knn_coop_search(const GridDesc& g, const uint32_t
     // ---- is the search over after shell w? The k-th smallest key of the wavefront, drawn from the lanes' lists as at the
     // end (on a copy), against the faces of the visited block: knn_done's test
     {
+      // (an empty shell — an isolated query walks ceil(R / h) + 1 of them — leaves the k-th key where it was: the k
+      // wave-wide minima are only drawn again after a shell that offered candidates)
+      if (fresh) {
+      fresh = false;
       KnnKeys<KM> cc = c;
-      double kth = knn_key_empty();
+      kth = knn_key_empty();
       for (int t = 0; t < k; t++) {
         double head = knn_key_empty();
 #pragma unroll
@@ -1269,6 +1276,7 @@ __device__ __forceinline__ int knn_coop_search(const GridDesc& g, const uint32_t
             if (j >= KM - k) cc.key[j] = cc.key[j + 1];
           cc.key[KM] = knn_key_empty();
         }
+      }
       }
       KnnKeys<KM> probe;  // (only slot KM - 1 and the mask are read by knn_bound)
       probe.mask = c.mask;
