@@ -1010,6 +1010,9 @@ constexpr int kRestThreads = LOAMX_REST_THREADS;  // small workgroups: the queue
 __host__ __device__ inline bool queue_leftovers_coop(const RegConfig& C, bool plane) {
   return !(C.flags & kRegFlagNoCoopLeft) && (plane ? C.r_plane : C.r_edge) > 0.0;
 }
+#ifndef LOAMX_COOP_WAVES
+#define LOAMX_COOP_WAVES 4
+#endif
 #ifndef LOAMX_REST_WAVES
 #define LOAMX_REST_WAVES 5  // measured (association scope): unconstrained (150 VGPRs, 3 waves/SIMD) 2.18 ms, 4 -> 2.12, 5 -> 2.11, 6 -> 2.14
 #endif
@@ -1318,7 +1321,7 @@ __device__ __forceinline__ int knn_coop_search(const GridDesc& g, const uint32_t
 // (one wavefront per workgroup: the entry loop steps by workgroups and s_rows is one lane's list — ADVICE r4)
 static_assert(kRestThreads == 64, "associate_knn_coop_kernel is written for one wavefront per workgroup");
 template <bool PLANE, int KM>
-__global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_coop_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
+__global__ __launch_bounds__(kRestThreads, LOAMX_COOP_WAVES) void associate_knn_coop_kernel(RegBatch B, RegConfig C, uint32_t blocks_per_pair) {
   size_t pair;
   uint32_t chunk0;
   if (!xcd_pair_map(blockIdx.x, blocks_per_pair, B.n_pairs, pair, chunk0)) return;
