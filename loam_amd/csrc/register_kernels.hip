@@ -1641,8 +1641,13 @@ __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOM
 // the pair's edge records and the numbers of listed plane records of its moment tiles.
 constexpr uint32_t kEdgeCache = 320;   // records (9 doubles each: 23 KB); a scan yields ~290 edge features
 constexpr uint32_t kListCache = 64;    // moment tiles of a pair (4 per chunk of kSweepChunk slots)
+// Round 5: the LISTED plane records of a pair (the ones its moments leave out: 0 - 1 % of the slots) as one flat list in LDS for
+// the whole solve, like the edge records. They were read tile by tile in every evaluation — up to 20 rounds of two dependent
+// global round trips with a handful of lanes each: a third of the kernel (stamped: 22 k of an evaluation's ~60 k cycles).
+constexpr uint32_t kFlatCache = 192;   // records (7 doubles each: 10.5 KB); more than that: the tile-by-tile walk
 __device__ __forceinline__ double light_eval(const RegBatch& B, size_t pair, const double x[7], uint32_t n_se, uint32_t n_sp,
-                                             const double* mom, LightLds& L, const double (*s_edge)[kEdgeCache], const uint32_t* s_listed) {
+                                             const double* mom, LightLds& L, const double (*s_edge)[kEdgeCache], const uint32_t* s_listed,
+                                             const double (*s_frec)[kFlatCache], uint32_t n_flat) {
   const int lane = threadIdx.x;  // (64-thread workgroup)
   const size_t efield = B.n_pairs * B.edge_stride, pfield = B.n_pairs * B.planar_stride;
   const double* __restrict__ E = B.assoc.edge + pair * B.edge_stride;
@@ -1660,6 +1665,12 @@ __device__ __forceinline__ double light_eval(const RegBatch& B, size_t pair, con
       residual_accumulate(false, v3(f0, cached ? s_edge[1][v] : E[efield + v], cached ? s_edge[2][v] : E[2 * efield + v]), prim, x, acc);
     }
   }
+  if (n_flat != 0xFFFFFFFFu) {  // (uniform) the listed records from LDS, in list order
+    for (uint32_t e = lane; e < n_flat; e += 64) {
+      const double prim[6] = {s_frec[3][e], s_frec[4][e], s_frec[5][e], s_frec[6][e], 0.0, 0.0};
+      residual_accumulate(true, v3(s_frec[0][e], s_frec[1][e], s_frec[2][e]), prim, x, acc);
+    }
+  } else
   for (uint32_t lb = 0; lb < B.mom_blocks_per_pair * 4 && (lb / 4) * kSweepChunk < n_sp; lb++) {
     const uint32_t cnt = lb < kListCache ? s_listed[lb] : B.flagged_count[pair * B.mom_blocks_per_pair * 4 + lb];
     if (cnt == 0u) continue;  // (uniform)
@@ -1877,7 +1888,8 @@ __global__ __launch_bounds__(64) void lm_pair_loop_kernel(RegBatch B, RegConfig 
   __shared__ double s_mom[kMomSize + 2];
   __shared__ double s_acc[kAccSize];
   __shared__ double s_edge[9][kEdgeCache];
-  __shared__ uint32_t s_listed[kListCache];
+  __shared__ double s_frec[7][kFlatCache];
+  __shared__ uint32_t s_listed[kListCache], s_pref[kListCache];
   const int lane = threadIdx.x;
   const size_t pair = blockIdx.x;
   PairState& S = B.state[pair];
@@ -1939,13 +1951,42 @@ __global__ __launch_bounds__(64) void lm_pair_loop_kernel(RegBatch B, RegConfig 
     stream = (S.mom_ref_on ? plane_moments_valid_rel(s0max, v2max, S.lm.xeval, S.mom_ref) : plane_moments_valid_at(s0max, v2max, ident)) ? 0u : 1u;
   }
   if (lane == 0) S.stream_planes = stream;
+  // ---- the listed plane records, flat (tile order, list order inside a tile) — when the moments are in use and the lists fit
+  uint32_t n_flat = 0xFFFFFFFFu;
+  if (S.use_moments && B.mom_blocks_per_pair * 4 <= kListCache) {
+    const uint32_t tiles = B.mom_blocks_per_pair * 4;
+    const uint32_t mine = ((uint32_t)lane < tiles && ((uint32_t)lane / 4) * kSweepChunk < n_sp) ? s_listed[lane] : 0u;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (total <= kFlatCache) {  // uniform
+      s_pref[lane] = incl - mine;  // first flat entry of tile `lane`
+      wave_lds_fence();
+      const size_t pfield = B.n_pairs * B.planar_stride;
+      const double* __restrict__ Pl = B.assoc.plane + pair * B.planar_stride;
+      for (uint32_t e = lane; e < total; e += 64) {
+        uint32_t lb = 0;  // the tile of flat entry e: the last one whose first entry is <= e (tiles <= 64: a short scan of LDS words)
+        for (uint32_t t = 1; t < tiles; t++) lb = s_pref[t] <= e ? t : lb;
+        // (an empty tile shares its first entry with its successor: the LAST such tile is the one that holds e)
+        const uint32_t k = e - s_pref[lb];
+        const uint32_t q = B.flagged_list[(pair * B.mom_blocks_per_pair * 4 + lb) * (size_t)(kSweepChunk / 4) + k];
+#pragma unroll
+        for (int f = 0; f < 7; f++) s_frec[f][e] = Pl[f * pfield + q];
+      }
+      n_flat = total;
+    }
+  }
   uint32_t lm_active = 1u;
   double x[7];
 #pragma unroll
   for (int i = 0; i < 7; i++) x[i] = S.lm.xeval[i];
   wave_lds_fence();
   for (int k = 0; k < 5 && lm_active; k++) {  // iteration-0 evaluation + max_num_iterations = 4 candidates
-    const double v = stream ? stream_eval_wave(B, pair, x, n_se, n_sp) : light_eval(B, pair, x, n_se, n_sp, s_mom, L, s_edge, s_listed);
+    const double v = stream ? stream_eval_wave(B, pair, x, n_se, n_sp) : light_eval(B, pair, x, n_se, n_sp, s_mom, L, s_edge, s_listed, s_frec, n_flat);
     if (lane < kAccSize) s_acc[lane] = 0.0 + v;
     wave_lds_fence();
     if (lane == 0) {
