@@ -47,6 +47,7 @@ struct PendingEvent {
 struct loamx_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
+  bool max_counts_clean = false;     // write_results_kernel has reset RegBatch::max_counts for the next call
   hipStream_t aux_stream = nullptr;  // edge association chain, forked from / joined into `stream` with the two events
   hipEvent_t ev_fork = nullptr, ev_mid = nullptr, ev_join = nullptr;
   hipEvent_t ev_counts = nullptr;     // marks the read-back of the largest source set sizes (register_dev)
@@ -384,7 +385,6 @@ int extract_dev(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_scans, con
     if (fresh) HIP_TRY(ctx, hipMemsetAsync(ctx->ws[WS_EXTRACT_EVENTS].p, 0, 4 * sizeof(unsigned long long), ctx->stream));
   }
   untimed(ctx);
-  HIP_TRY(ctx, hipMemsetAsync(ctx->ws[WS_LINE_TOT].p, 0, (n_lines + 1) * sizeof(unsigned long long), ctx->stream));
   uint32_t* d_gave_up = reinterpret_cast<uint32_t*>(wsp<unsigned long long>(ctx, WS_LINE_TOT) + n_lines);
   unsigned long long* d_events = wsp<unsigned long long>(ctx, WS_EXTRACT_EVENTS);
   ExtractFused fz{wsp<unsigned long long>(ctx, WS_LINE_TOT), 0u, d_xyz, f32 ? 1u : 0u, d_edge_idx, d_n_edge, d_edge_xyz,
@@ -392,10 +392,10 @@ int extract_dev(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_scans, con
   if (boxes && d_edge_xyz && d_planar_xyz && launch_select_takes_boxes(P)) {
     ENSURE(ctx, WS_BOX, 2 * n_scans * 6 * sizeof(unsigned long long));
     fz.box_min = wsp<unsigned long long>(ctx, WS_BOX), fz.box_max = fz.box_min + n_scans * 6;
-    untimed(ctx);
-    HIP_TRY(ctx, hipMemsetAsync(fz.box_min, 0xFF, n_scans * 6 * sizeof(unsigned long long), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(fz.box_max, 0x00, n_scans * 6 * sizeof(unsigned long long), ctx->stream));
   }
+  untimed(ctx);
+  launch_extract_init(fz.line_tot, n_lines + 1, fz.box_min, fz.box_max, fz.box_min ? n_scans * 6 : 0, ctx->stream);
+  CHECK_LAUNCH(ctx, "extract_init_kernel");
   {
     // rows a5-a10 in one pass over the scan — opt-in (context option FUSED_EXTRACT; the two kernels below are the default,
     // see launch_extract_fused) and only where the parameters allow: 24 B/point read + (4 + 24) B per feature written;
@@ -665,11 +665,12 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C_in, loa
   // The per-pair state first: its kernel also finds the largest source sets, which come back to the host while
   // the index builds run (an event right behind the copy: the builds are already queued when the host waits).
   untimed(ctx);
-  {
+  if (!ctx->max_counts_clean) {  // (write_results_kernel leaves them ready for the next call: no copy kernel in front of state_init_kernel then)
     const uint32_t init[6] = {0u, 0u, 0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu};
     memcpy(&ctx->h_pinned[8], init, sizeof(init));
     HIP_TRY(ctx, hipMemcpyAsync(B.max_counts, &ctx->h_pinned[8], sizeof(init), hipMemcpyHostToDevice, s));
   }
+  ctx->max_counts_clean = false;
   launch_state_init(B, C, s);
   CHECK_LAUNCH(ctx, "state_init_kernel");
   if (!ctx->ev_counts) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_counts, hipEventDisableTiming));
@@ -689,8 +690,8 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C_in, loa
     // (Round 3: the first ICF iteration's edge chains right behind the edge builds on the auxiliary stream, i.e. next to
     // the planar index builds instead of next to the plane k-NN kernel: 11.60 / 11.72 vs 11.65 / 11.53 ms per step —
     // what the k-NN kernel gains the HBM-bound builds lose. Not kept.)
-    const bool side = !(C.flags & kRegFlagNoGridSide) && ctx->aux_stream && !prebuilt &&
-                      hipEventRecord(ctx->ev_fork, s) == hipSuccess && hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0) == hipSuccess;
+    // (the fork waits on the event already recorded behind the counts' copy: one marker packet fewer in front of the builds)
+    const bool side = !(C.flags & kRegFlagNoGridSide) && ctx->aux_stream && !prebuilt && hipStreamWaitEvent(ctx->aux_stream, ctx->ev_counts, 0) == hipSuccess;
     if (!prebuilt) launch_grid_build_targets(B, C, s);
     launch_grid_build_sources(B, C, side ? ctx->aux_stream : s);
     if (side && hipEventRecord(ctx->ev_join, ctx->aux_stream) == hipSuccess) (void)hipStreamWaitEvent(s, ctx->ev_join, 0);
@@ -753,15 +754,24 @@ int register_dev(loamx_ctx* ctx, const RegInputs& in, const RegConfig& C_in, loa
       // associations everywhere — its kernels find no active pair and return). A large batch does not wait after
       // the second iteration either: that hundreds of pairs all stop there is as good as excluded, and the
       // synchronisation idles the GPU for ~35 us (a single pair does wait: a third iteration would cost it 0.3 ms)
+      // The results go out BEFORE the host waits: when this was the last iteration (the usual case where the host looks at
+      // all) they are written while the read-back travels, instead of ~26 us of idle GPU later; otherwise they are written
+      // again at the end.
       untimed(ctx);
       HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, B.n_active, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      launch_write_results(B, d_results, s);
+      CHECK_LAUNCH(ctx, "write_results_kernel");
       HIP_TRY(ctx, hipStreamSynchronize(s));
-      if (ctx->h_pinned[0] == 0) break;
+      if (ctx->h_pinned[0] == 0) {
+        ctx->max_counts_clean = true;
+        return LOAMX_OK;
+      }
     }
   }
   untimed(ctx);
   launch_write_results(B, d_results, s);
   CHECK_LAUNCH(ctx, "write_results_kernel");
+  ctx->max_counts_clean = true;
   return LOAMX_OK;
 }
 

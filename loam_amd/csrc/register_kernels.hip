@@ -2136,6 +2136,10 @@ __global__ void outer_update_kernel(RegBatch B, RegConfig C) {
 __global__ void write_results_kernel(RegBatch B, loamx_reg_result* __restrict__ out) {
   const size_t pair = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pair >= B.n_pairs) return;
+  if (pair == 0 && B.max_counts) {  // ready for the next call's state_init_kernel (the host read them long ago)
+    for (int c = 0; c < 4; c++) B.max_counts[c] = 0u;
+    B.max_counts[4] = B.max_counts[5] = 0xFFFFFFFFu;
+  }
   const PairState& S = B.state[pair];
   for (int i = 0; i < 7; i++) out[pair].pose[i] = S.est[i];
   out[pair].termination = S.termination;
@@ -2536,6 +2540,9 @@ void launch_associate(const RegBatch& B, const RegConfig& C, hipStream_t s, hipS
     launch_kernel((associate_knn_mixed_kernel<5, 5>), grid, dim3(kAssocThreads), 0, s, B, C, be, bp, edge_blocks);
     g_launch_scope = outer;
     hipStream_t sb = aux2 ? aux2 : aux;
+    // (Round 5: the fork / join events as the kernels' own completion events — hipExtLaunchKernelGGL's stop event instead of
+    // hipEventRecord — shorten the gap in front of the fit from 6.4 to 5.3 us, but the host's wait at the end of the step
+    // then takes 23 us longer: not kept.)
     const bool fork2 = sb != nullptr && hipEventRecord(ev_mid, s) == hipSuccess && hipStreamWaitEvent(sb, ev_mid, 0) == hipSuccess;
     launch_kernel((associate_fit_mixed_kernel<5, 5>), grid, dim3(kAssocThreads), 0, s, B, C, be, bp, edge_blocks);
     LOAMX_ASSOC_B(true, 5, bp, (fork2 ? sb : s));
