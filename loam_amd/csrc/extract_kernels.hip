@@ -236,7 +236,12 @@ __device__ __forceinline__ void curvature_line_tiles(const T* __restrict__ g, co
 #ifndef LOAMX_CURV_WAVES
 #define LOAMX_CURV_WAVES 4
 #endif
-template <int NP, typename T>
+// SPLIT (round 5; between this kernel and select_rows_kernel only): the curvature leaves as two 32-bit arrays — hi words
+// (n points), then lo words (n points) in the same buffer — with the validity in the hi word's sign bit (a curvature is a sum
+// of squares: its own sign bit is never set; a line end's -1.0 already carries it) and no validity bytes at all. The
+// selection orders non-negative doubles by their hi words alone and fetches the lo words of a sector only when two hi words
+// it compares are equal: it reads 4 instead of 9 bytes per point.
+template <int NP, typename T, bool SPLIT = false>
 __global__ __launch_bounds__(kCurvThreads, LOAMX_CURV_WAVES) void curvature_valid2_kernel(const T* __restrict__ xyz, ExtractParams P,
                                                                double* __restrict__ curv_out,
                                                                uint8_t* __restrict__ mask_out) {
@@ -250,6 +255,15 @@ __global__ __launch_bounds__(kCurvThreads, LOAMX_CURV_WAVES) void curvature_vali
   curvature_line_tiles<NP, kCurvThreads, T>(g, P, (int)blockIdx.y * kCurvTilesPerGroup * kTile, kCurvTilesPerGroup, s_p, s_r, s_bits,
                               [&](int c0, const double cv[2], const bool ok[2]) {
                                 const size_t o = line * (size_t)W + c0;
+                                if constexpr (SPLIT) {  // (launched for even W only)
+                                  uint32_t* __restrict__ hi_out = reinterpret_cast<uint32_t*>(curv_out);
+                                  uint32_t* __restrict__ lo_out = hi_out + (size_t)gridDim.x * (size_t)W;
+                                  const uint32_t h0 = (uint32_t)__double2hiint(cv[0]) | (ok[0] ? 0u : 0x80000000u);
+                                  const uint32_t h1 = (uint32_t)__double2hiint(cv[1]) | (ok[1] ? 0u : 0x80000000u);
+                                  *reinterpret_cast<uint2*>(hi_out + o) = make_uint2(h0, h1);
+                                  *reinterpret_cast<uint2*>(lo_out + o) = make_uint2((uint32_t)__double2loint(cv[0]), (uint32_t)__double2loint(cv[1]));
+                                  return;
+                                }
                                 if (c0 + 1 < W && (W & 1) == 0) {  // both columns, aligned
                                   *reinterpret_cast<double2*>(curv_out + o) = make_double2(cv[0], cv[1]);
                                   *reinterpret_cast<uint16_t*>(mask_out + o) = (uint16_t)((ok[0] ? 1u : 0u) | (ok[1] ? 0x100u : 0u));
@@ -500,9 +514,21 @@ __global__ __launch_bounds__(64) void replay_kernel(const double* __restrict__ c
   for (size_t line = blockIdx.x; line < n_lines; line += gridDim.x) {
     if ((__hip_atomic_load(line_tot + line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kLineTied) == 0ull) continue;  // uniform
     wave_lds_sync();
-    for (int i = lane; i < W; i += 64) {
-      s_c[i] = curv[line * (size_t)W + i];
-      s_v[i] = mask[line * (size_t)W + i];
+    if (P.flags & kFlagSplitCurv) {  // hi | lo words, validity in the hi word's sign bit (curvature_valid2_kernel<.., SPLIT>)
+      const uint32_t* __restrict__ hi = reinterpret_cast<const uint32_t*>(curv);
+      const uint32_t* __restrict__ lo = hi + n_lines * (size_t)W;
+      for (int i = lane; i < W; i += 64) {
+        const uint32_t h = hi[line * (size_t)W + i];
+        // (std::sort's permutation depends on every value of the sector, valid or not: a line end is the -1.0 the curvature
+        // kernel wrote, every other point's own sign bit was clear)
+        s_c[i] = is_line_end((uint32_t)i, P.W, P.np) ? -1.0 : __hiloint2double((int)(h & 0x7FFFFFFFu), (int)lo[line * (size_t)W + i]);
+        s_v[i] = (h >> 31) ? 0 : 1;
+      }
+    } else {
+      for (int i = lane; i < W; i += 64) {
+        s_c[i] = curv[line * (size_t)W + i];
+        s_v[i] = mask[line * (size_t)W + i];
+      }
     }
     wave_lds_sync();
     ring_replay(s_c, s_v, s_ord, lane, W, P, (uint32_t)(line % P.H) * P.W, line, st);
@@ -1105,7 +1131,8 @@ static void launch_curvature_valid_t(const T* d_xyz, const dim3& grid, const Ext
                                      hipStream_t s) {
   if (P.np == 3 && !(P.flags & kFlagCurvV1)) {  // the reference's default neighbor_points (features.h:40)
     const dim3 grid2(grid.x, (P.W + kCurvTilesPerGroup * kTile - 1) / (kCurvTilesPerGroup * kTile));
-    launch_kernel((curvature_valid2_kernel<3, T>), grid2, dim3(kCurvThreads), 0, s, d_xyz, P, d_curv, d_mask);
+    if (P.flags & kFlagSplitCurv) launch_kernel((curvature_valid2_kernel<3, T, true>), grid2, dim3(kCurvThreads), 0, s, d_xyz, P, d_curv, d_mask);
+    else launch_kernel((curvature_valid2_kernel<3, T>), grid2, dim3(kCurvThreads), 0, s, d_xyz, P, d_curv, d_mask);
     return;
   }
   if (P.np == 3)
@@ -1160,7 +1187,9 @@ template <int R>
 static void launch_select_rows_r(const double* d_curv, const uint8_t* d_mask, size_t n_lines, const ExtractParams& P, const ExtractStage& st,
                                  const ExtractFused& fz, const RowSelGeom& G, hipStream_t s) {
   const dim3 grid((unsigned)((n_lines + 15) / 16));
-  if (R == 2 && G.ch == 11)
+  if (R == 2 && G.ch == 11 && (P.flags & kFlagSplitCurv))
+    launch_kernel((select_rows_kernel<R, R == 2 ? 11 : 0, false, R == 2>), grid, dim3(256), (size_t)G.bytes * 4, s, d_curv, d_mask, n_lines, P, st, fz, G);
+  else if (R == 2 && G.ch == 11)
     launch_kernel((select_rows_kernel<R, R == 2 ? 11 : 0>), grid, dim3(256), (size_t)G.bytes * 4, s, d_curv, d_mask, n_lines, P, st, fz, G);
   else
     launch_kernel((select_rows_kernel<R, 0>), grid, dim3(256), (size_t)G.bytes * 4, s, d_curv, d_mask, n_lines, P, st, fz, G);
@@ -1170,6 +1199,7 @@ static bool launch_select_rows(const double* d_curv, const uint8_t* d_mask, size
   RowSelGeom G;
   if (!row_select_geom(P, G) || (reinterpret_cast<uintptr_t>(d_mask) & 15u) != 0 || n_lines % 4 != 0) return false;
   if (fz.fuse && P.W > 65535) return false;
+  if ((P.flags & kFlagSplitCurv) && !(P.np == 3 && G.ch == 11)) return false;  // (launch_extract_split_ok said otherwise: not reached)
   switch ((int)P.np - 1) {
     case 1: launch_select_rows_r<1>(d_curv, d_mask, n_lines, P, st, fz, G, s); break;
     case 2: launch_select_rows_r<2>(d_curv, d_mask, n_lines, P, st, fz, G, s); break;
@@ -1197,6 +1227,17 @@ bool launch_extract_rows_fused(const void* d_xyz, bool f32, size_t n_scans, cons
     launch_kernel((curvature_tied_kernel<3, float>), dim3(grid), dim3(64), 0, s, static_cast<const float*>(d_xyz), n_lines, P, fz.line_tot, fz.error, d_curv, d_mask);
   else
     launch_kernel((curvature_tied_kernel<3, double>), dim3(grid), dim3(64), 0, s, static_cast<const double*>(d_xyz), n_lines, P, fz.line_tot, fz.error, d_curv, d_mask);
+  return true;
+}
+
+// May the curvature go from curvature_valid2_kernel to select_rows_kernel in the split form (hi words | lo words, validity in
+// the sign bit: see those kernels)? Exactly when launch_curvature_valid and launch_select will run those two kernels in the
+// instantiations that know the form, and the thresholds are comparable through their hi words (finite, not negative).
+bool launch_extract_split_ok(const ExtractParams& P, size_t n_scans) {
+  if (P.flags & (kFlagNoSplitCurv | kFlagNoMisSelect | kFlagNoRowSelect | kFlagCurvV1 | kFlagFusedExtract | kFlagFusedRows)) return false;
+  RowSelGeom G;
+  if (P.np != 3 || (P.W & 1u) || !row_select_geom(P, G) || G.ch != 11 || (n_scans * P.H) % 4 != 0) return false;
+  if (!(P.edge_thr >= 0.0 && P.edge_thr <= 1.7976931348623157e308 && P.planar_thr >= 0.0 && P.planar_thr <= 1.7976931348623157e308)) return false;
   return true;
 }
 

@@ -115,7 +115,7 @@ struct OptionName {
 const OptionName kOptionNames[] = {
     {"FORCE_TIE_REPLAY", true, kFlagForceReplay}, {"FORCE_SCAN_GIVEUP", true, kFlagForceGiveUp}, {"CURV_V1", true, kFlagCurvV1},
     {"NO_FUSED_COMPACT", true, kFlagNoFusedCompact}, {"NO_MIS_SELECT", true, kFlagNoMisSelect}, {"FUSED_EXTRACT", true, kFlagFusedExtract},
-    {"NO_ROW_SELECT", true, kFlagNoRowSelect}, {"FUSED_ROWS", true, kFlagFusedRows},
+    {"NO_ROW_SELECT", true, kFlagNoRowSelect}, {"FUSED_ROWS", true, kFlagFusedRows}, {"NO_SPLIT_CURV", true, kFlagNoSplitCurv},
     {"NO_MOMENTS", false, kRegFlagNoMoments}, {"NO_PACKED_GRID", false, kRegFlagNoPackedGrid}, {"NO_BIG_GRID", false, kRegFlagNoBigGrid},
     {"NO_GRID_SIDE", false, kRegFlagNoGridSide}, {"DEBUG_POISON", false, kRegFlagPoison},
     {"QUEUE_TWO_STAGE", false, kRegFlagQueueTwoStage}, {"QUEUE_ONE_STAGE", false, kRegFlagQueueOneStage},
@@ -420,17 +420,22 @@ int extract_dev(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_scans, con
       return check_launch(ctx, "select_rows_kernel (fused)");
     }
   }
+  // Round 5: between these two kernels the curvature travels as hi words | lo words with the validity in the sign bit where
+  // both know that form (kFlagSplitCurv; the selection then reads 4 instead of 9 bytes per point)
+  ExtractParams Pk = P;
+  if (launch_extract_split_ok(P, n_scans)) Pk.flags |= kFlagSplitCurv;
+  const bool split = (Pk.flags & kFlagSplitCurv) != 0u;
   {
-    TimedScope t(ctx, LOAMX_K_CURVATURE, (double)n_scans * (double)N * (f32 ? 21.0 : 33.0), true);
-    launch_curvature_valid(d_xyz, f32, n_scans, P, wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), ctx->stream);
+    TimedScope t(ctx, LOAMX_K_CURVATURE, (double)n_scans * (double)N * ((f32 ? 21.0 : 33.0) - (split ? 1.0 : 0.0)), true);
+    launch_curvature_valid(d_xyz, f32, n_scans, Pk, wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), ctx->stream);
   }
   CHECK_LAUNCH(ctx, "curvature_valid_kernel");
   bool fused = false, rows_ran = false;
   {
-    TimedScope t(ctx, LOAMX_K_SELECT, (double)n_scans * (double)N * 9.0, true);
-    fused = launch_select(wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), n_scans, P, st, &fz, ctx->stream, &rows_ran);
+    TimedScope t(ctx, LOAMX_K_SELECT, (double)n_scans * (double)N * (split ? 4.0 : 9.0), true);
+    fused = launch_select(wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), n_scans, Pk, st, &fz, ctx->stream, &rows_ran);
     // scan lines on which a curvature tie can decide something: again, in the reference's std::sort order (a no-op without)
-    launch_replay(wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), n_scans, P, st, fz, ctx->stream);
+    launch_replay(wsp<double>(ctx, WS_CURV), wsp<uint8_t>(ctx, WS_MASK), n_scans, Pk, st, fz, ctx->stream);
     // A scan line whose wavefront gave up waiting for the lines before it (bounded wait: unusual scheduling) left its
     // features in the stage arrays; this launch then gathers the batch from them and is a no-op otherwise (every
     // workgroup reads the flag and leaves): the call stays asynchronous and never fails for that reason.

@@ -104,6 +104,7 @@ bool launch_extract_fused(const void* d_xyz, bool f32, size_t n_scans, const Ext
 bool launch_extract_rows_fused(const void* d_xyz, bool f32, size_t n_scans, const ExtractParams& P, const ExtractStage& st,
                                const ExtractFused& fz, double* d_curv, uint8_t* d_mask, hipStream_t s);
 // the tie path: scan lines the selection kernel marked are redone in the reference's std::sort order (stage + counts)
+bool launch_extract_split_ok(const ExtractParams& P, size_t n_scans);
 void launch_extract_init(unsigned long long* line_tot, size_t n_tot, unsigned long long* box_min, unsigned long long* box_max, size_t n_box,
                          hipStream_t s);
 void launch_replay(const double* d_curv, const uint8_t* d_mask, size_t n_scans, const ExtractParams& P, const ExtractStage& st,

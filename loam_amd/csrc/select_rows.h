@@ -27,6 +27,7 @@
 #pragma once
 
 // Geometry of one launch, computed by the host (row_select_geom) and passed by value.
+constexpr int kKeyShift = 2;  // see row_select_geom
 struct RowSelGeom {
   uint32_t ch;         // points of the current sector per lane
   uint32_t ib;         // bits of a sector position inside the sort keys (16 * ch <= 1 << ib)
@@ -84,8 +85,12 @@ __host__ inline bool row_select_geom(const ExtractParams& P, RowSelGeom& G, bool
     u.d = v;
     return (int32_t)(u.b >> 32);
   };
+  // The curvature part of a key is (hi word - base) >> kKeyShift, clamped: 32 - ib bits that hold 20 - kKeyShift mantissa bits
+  // over 2^(12 - ib + kKeyShift) octaves (ib = 8, shift 2: 18 mantissa bits over 64 octaves). Round 5: with shift 0 — 16
+  // octaves — every planar pick below 2^-16 of its threshold was clamped to the same key, and a sector of a flat surface has
+  // several of those: the exact 64-bit pass ran in nearly every planar pass (counted: 195 000 of 196 608 wavefront-sectors).
   const int32_t kmax = (int32_t)((1u << (32 - G.ib)) - 1u);
-  G.kbase_p = (P.planar_thr > 0.0 ? hi_word(P.planar_thr) : 0) - kmax;
+  G.kbase_p = (P.planar_thr > 0.0 ? hi_word(P.planar_thr) : 0) - (int32_t)((uint32_t)kmax << kKeyShift);
   G.kbase_e = P.edge_thr > 0.0 ? hi_word(P.edge_thr) : 0;
   return true;
 }
@@ -138,6 +143,17 @@ __device__ __forceinline__ void push_gt(uint32_t& m, double a, double b) {
 }
 __device__ __forceinline__ void push_lt(uint32_t& m, double a, double b) {
   asm("v_cmp_lt_f64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(a), "v"(b) : "vcc");
+}
+
+// the same on the hi words of non-negative doubles (the split form: select_rows_kernel<.., SPLIT>)
+__device__ __forceinline__ void push_gt_i32(uint32_t& m, int32_t a, int32_t b) {
+  asm("v_cmp_gt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(a), "v"(b) : "vcc");
+}
+__device__ __forceinline__ void push_lt_i32(uint32_t& m, int32_t a, int32_t b) {
+  asm("v_cmp_lt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(a), "v"(b) : "vcc");
+}
+__device__ __forceinline__ void push_ge0_i32(uint32_t& m, int32_t a) {
+  asm("v_cmp_le_i32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(a) : "vcc");
 }
 
 // ---- the sort: 64 keys of a row on 16 lanes x 4 registers, rank q = 4 * lane + register, ascending ---------------------
@@ -285,10 +301,13 @@ struct RowSelCtx {  // per-lane constants of a wavefront's four lines
 // hiw: (compile-time CH) the hi words of the lane's own CH curvatures, in registers: the keys of all own points are then
 // built up front by straight code instead of one dependent LDS read per pick. pk_list: the row's pick list of this
 // (sector, kind): sector positions of the kept picks in output order.
-template <int R, bool EDGE, int CHT>
+// ensure(): (wave-uniform call) makes the curvature buffer hold doubles before the exact pass reads it (the split form
+// stages hi words only; a no-op otherwise).
+template <int R, bool EDGE, int CHT, typename Ensure>
 __device__ __forceinline__ uint32_t row_pass(const RowSelCtx& X, uint32_t& V, uint32_t T, uint32_t sm, const uint32_t gt[R],
                                              const uint32_t eqm[R], bool have_eq, bool& tie, uint32_t cap, int start,
-                                             uint32_t line_base, uint32_t* __restrict__ stage, void* pk_list, const int32_t* hiw) {
+                                             uint32_t line_base, uint32_t* __restrict__ stage, void* pk_list, const int32_t* hiw,
+                                             Ensure&& ensure) {
   const int l = X.l, CH = X.CH;
   uint32_t U = V & T & sm;
   if (__ballot(U != 0) == 0) return 0;
@@ -323,7 +342,7 @@ __device__ __forceinline__ uint32_t row_pass(const RowSelCtx& X, uint32_t& V, ui
   const int32_t kbase = EDGE ? X.kbase_e : X.kbase_p;
   // 32-bit key of the own point j from the hi word of its curvature
   auto make_key = [&](int32_t hi, int j) -> uint32_t {
-    int32_t kx = hi - kbase;
+    int32_t kx = (hi - kbase) >> kKeyShift;
     kx = kx < 0 ? 0 : (kx > X.kmax ? X.kmax : kx);
     const uint32_t k = ((uint32_t)kx << X.ib) | (uint32_t)(l * CH + j);
     return EDGE ? ~k : k;
@@ -388,6 +407,7 @@ __device__ __forceinline__ uint32_t row_pass(const RowSelCtx& X, uint32_t& V, ui
     }
   }
   if (undecided) {
+    ensure();
     // ---- the exact pass: curvature and position folded into one double (low IB mantissa bits replaced by the position;
     // edge keys negated, padding = +inf), as select_mis_kernel sorts. Picks whose truncated curvatures still collide, or a
     // pick that is not finite: the order among them is std::sort's — the line is replayed (tie).
@@ -451,9 +471,15 @@ __device__ __forceinline__ uint32_t row_pass(const RowSelCtx& X, uint32_t& V, ui
 
 // CHT: points per lane as a compile-time constant (11 for 64 x 1024 / 6 sectors: the loops over a lane's points unroll),
 // 0 = G.ch.
-template <int R, int CHT, bool FUSED = false>
+// SPLIT: the curvature arrives as hi words | lo words with the validity in the hi word's sign bit and no validity bytes
+// (curvature_valid2_kernel<.., SPLIT>). A sector is staged as 32-bit hi words and every comparison is a comparison of hi
+// words — exact for non-negative doubles whose hi words differ; where two hi words that are compared (neighbours within R, or
+// a point and a threshold) are EQUAL, or two picks' keys collide, the sector's lo words are fetched and the doubles compared
+// as before (wave-uniform, ~1 sector in 500 on noisy scans). vb then holds the SUPPRESSED points, as in the fused form.
+template <int R, int CHT, bool FUSED = false, bool SPLIT = false>
 __global__ __launch_bounds__(FUSED ? 128 : 256, FUSED ? 3 : 4) void select_rows_kernel(const double* __restrict__ curv, const uint8_t* __restrict__ mask, size_t n_lines,
                                                           ExtractParams P, ExtractStage st, ExtractFused fz, RowSelGeom G) {
+  static_assert(!SPLIT || (CHT != 0 && !FUSED), "the split form is written for the compile-time lane chunk");
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row = lane >> 4, l = lane & 15;
   const size_t line0 = ((size_t)blockIdx.x * (FUSED ? 2 : 4) + wave) * 4;  // four consecutive lines of one scan (H % 4 == 0)
@@ -495,7 +521,22 @@ __global__ __launch_bounds__(FUSED ? 128 : 256, FUSED ? 3 : 4) void select_rows_
     return (lane + 64 * i < BLu && col >= np && col + np < W) ? curv[(line0 + rr) * (size_t)W + col] : kNaN;
   };
   constexpr int NL = (CHT && !FUSED) ? (16 * CHT + 3 * R + 63) / 64 : 1;
-  double pre[4][NL];
+  double pre[SPLIT ? 1 : 4][NL];
+  int32_t prei[SPLIT ? 4 : 1][NL];
+  // (split form) the staged hi words: [row][IP] in the curvature buffer's first bytes. IP = 240: a lane reads word l * 11 + t
+  // of its row, and 11 * 35 = 1 (mod 64), so the 16 lanes of a row sit on 16 banks that are consecutive after multiplication
+  // by 35; a row offset of 240 = 48 (mod 64) is 16 in that numbering: the four rows take the 64 banks once each. (At the
+  // doubles' pitch of 183 the rows were 55 = 5 * 11 banks apart — 11 of a row's 16 banks shared with the next row: measured
+  // 1.41 instead of 1.32 ms.)
+  constexpr int IP = 240;
+  static_assert(!SPLIT || (CHT == 11 && 4 * IP * 4 <= 4 * (16 * 11 + 3 * R) * 8), "bank arithmetic above; the four rows of hi words fit under the doubles");
+  int32_t* ibuf = reinterpret_cast<int32_t*>(cbuf);
+  const int32_t* __restrict__ chi = reinterpret_cast<const int32_t*>(curv);
+  const uint32_t* __restrict__ clo = reinterpret_cast<const uint32_t*>(curv) + n_lines * (size_t)P.W;
+  auto fetch_hi = [&](uint32_t s, int rr, int i) -> int32_t {  // (positions outside the line: never valid)
+    const int col = (int)(s * P.pps) + lane + 64 * i - R;
+    return (lane + 64 * i < BLu && col >= np && col + np < W) ? chi[(line0 + rr) * (size_t)W + col] : (int32_t)0x80000000;
+  };
   // ---- fused form (rows a5 + a6 inside this kernel: curvature and validity never reach HBM). A sector of ONE line at a
   // time: its points, with the halo of the curvature sum and of the validity windows, are staged in LDS by all 64 lanes
   // (xa: NX points as they lie in the scan), then: range of every point (sr), the four invalidation codes as wavefront
@@ -520,6 +561,12 @@ __global__ __launch_bounds__(FUSED ? 128 : 256, FUSED ? 3 : 4) void select_rows_
 #pragma unroll
     for (int i = 0; i < NIA; i++) nxa[i] = fetch_xa(0, 0, i);
     for (int k = lane; k < 4 * (int)G.vw; k += 64) vb[k] = 0;  // fused form: vb holds the SUPPRESSED points of the four lines
+  } else if constexpr (SPLIT) {
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+      for (int i = 0; i < NL; i++) prei[rr][i] = fetch_hi(0, rr, i);
+    for (int k = lane; k < 4 * (int)G.vw; k += 64) vb[k] = 0;  // the SUPPRESSED points of the four lines
   } else {
     if constexpr (CHT != 0) {
 #pragma unroll
@@ -644,6 +691,18 @@ __global__ __launch_bounds__(FUSED ? 128 : 256, FUSED ? 3 : 4) void select_rows_
           }
         }
       }
+    } else if constexpr (SPLIT) {
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+        for (int i = 0; i < NL; i++)
+          if (lane + 64 * i < BLu) ibuf[rr * IP + lane + 64 * i] = prei[rr][i];
+      if (s + 1 < P.S) {
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+          for (int i = 0; i < NL; i++) prei[rr][i] = fetch_hi(s + 1, rr, i);
+      }
     } else if constexpr (CHT != 0) {
 #pragma unroll
       for (int rr = 0; rr < 4; rr++)
@@ -666,9 +725,67 @@ __global__ __launch_bounds__(FUSED ? 128 : 256, FUSED ? 3 : 4) void select_rows_
     uint32_t gt[R], eqm[R], ET = 0, PT = 0;
     int32_t hiw[CHT ? CHT : 1];  // (compile-time CH) hi words of my own curvatures: the sort keys come from them
     bool anyeq = false;
+    bool is_dbl = !SPLIT;  // (uniform) the curvature buffer holds doubles
+    uint32_t VS = 0;       // (split form) validity of my CH points: the sign bits of their hi words
+    // (split form) the sector's lo words, and with them the doubles into the curvature buffer — every lane its staged positions
+    auto ensure = [&]() {
+      if constexpr (SPLIT) {
+        if (is_dbl) return;  // uniform
+        is_dbl = true;
+        // row by row from the last one down: the doubles of row rr lie over the hi words of rows 2 rr and 2 rr + 1, which
+        // are converted by then (row 0 over itself: read, barrier, write); a loop, not unrolled — this path is cold and
+        // its registers must not cost the common one anything
+#pragma unroll 1
+        for (int rr = 3; rr >= 0; rr--) {
+          int32_t h[NL];
+          uint32_t lo_[NL];
+#pragma unroll
+          for (int i = 0; i < NL; i++) {
+            h[i] = lane + 64 * i < BLu ? ibuf[rr * IP + lane + 64 * i] : (int32_t)0x80000000;
+            const int col = start + lane + 64 * i - R;  // (a non-negative hi word lies inside the line)
+            lo_[i] = h[i] >= 0 ? clo[(line0 + rr) * (size_t)W + col] : 0u;
+          }
+          wave_lds_sync();
+#pragma unroll
+          for (int i = 0; i < NL; i++)
+            if (lane + 64 * i < BLu) cbuf[(size_t)rr * G.pitch + lane + 64 * i] = h[i] >= 0 ? __hiloint2double(h[i], (int)lo_[i]) : kNaN;
+          wave_lds_sync();
+        }
+      }
+    };
 #pragma unroll
     for (int d = 0; d < R; d++) gt[d] = 0, eqm[d] = 0;
-    {
+    if constexpr (SPLIT) {
+      const int32_t* cpi = ibuf + row * IP + l * CH;
+      const int32_t te = __double2hiint(thr_e), tp = __double2hiint(thr_p);
+      int32_t w[R + 1];
+#pragma unroll
+      for (int d = 1; d <= R; d++) w[d] = cpi[CH + 2 * R - 1 + d];
+#pragma unroll
+      for (int t = CH + 2 * R - 1; t >= 0; t--) {
+        w[0] = cpi[t];
+        const bool v0 = w[0] >= 0;
+#pragma unroll
+        for (int d = 1; d <= R; d++) {
+          push_gt_i32(gt[d - 1], w[0], w[d]);
+          anyeq = anyeq || (v0 && w[0] == w[d]);
+        }
+        if (t >= R && t < R + CH) {
+          push_gt_i32(ET, w[0], te), push_lt_i32(PT, w[0], tp), push_ge0_i32(VS, w[0]);
+          anyeq = anyeq || (v0 && (w[0] == te || w[0] == tp));
+          hiw[t - R] = w[0];
+        }
+#pragma unroll
+        for (int d = R; d >= 1; d--) w[d] = w[d - 1];
+      }
+      if (__ballot(anyeq) != 0) {  // (uniform) equal hi words somewhere: this sector is compared as doubles
+        ensure();
+#pragma unroll
+        for (int d = 0; d < R; d++) gt[d] = 0;
+        ET = 0, PT = 0, anyeq = false;
+      }
+    }
+    if (is_dbl) {  // (uniform)
       double w[R + 1];
 #pragma unroll
       for (int d = 1; d <= R; d++) w[d] = X.cp[CH + 2 * R - 1 + d];
@@ -682,7 +799,7 @@ __global__ __launch_bounds__(FUSED ? 128 : 256, FUSED ? 3 : 4) void select_rows_
         }
         if (t >= R && t < R + CH) {
           push_gt(ET, w[0], thr_e), push_lt(PT, w[0], thr_p);
-          if constexpr (CHT != 0) hiw[t - R] = __double2hiint(w[0]);
+          if constexpr (CHT != 0 && !SPLIT) hiw[t - R] = __double2hiint(w[0]);
         }
 #pragma unroll
         for (int d = R; d >= 1; d--) w[d] = w[d - 1];
@@ -706,16 +823,18 @@ __global__ __launch_bounds__(FUSED ? 128 : 256, FUSED ? 3 : 4) void select_rows_
       const uint32_t* vs = vsec + row * 8 + (bo >> 5);
       V0 = __builtin_amdgcn_alignbit(vs[1], vs[0], bo & 31u) & X.cm & ~V0;
     }
+    if constexpr (SPLIT) V0 = VS & X.cm & ~V0;
     uint32_t V = V0;
     int nb = len - l * CH;
     nb = nb < 0 ? 0 : (nb > CH ? CH : nb);
     const uint32_t sm = (1u << nb) - 1u;
     const size_t group = line * P.S + s;
     unsigned char* pk_s = pk_row + ((size_t)s * (G.cap_e + G.cap_p) << (G.pk8 ? 0 : 1));
-    const uint32_t ne = row_pass<R, true, CHT>(X, V, ET, sm, gt, eqm, have_eq, tie, G.cap_e, start, line_base, st.edge_stage + group * P.cap_edge, pk_s, hiw);
+    const uint32_t ne = row_pass<R, true, CHT>(X, V, ET, sm, gt, eqm, have_eq, tie, G.cap_e, start, line_base, st.edge_stage + group * P.cap_edge, pk_s, hiw,
+                                               ensure);
     ROWS_STAMP(3)
     const uint32_t npl = row_pass<R, false, CHT>(X, V, PT, sm, gt, eqm, have_eq, tie, G.cap_p, start, line_base, st.planar_stage + group * P.cap_planar,
-                                                 pk_s + ((size_t)G.cap_e << (G.pk8 ? 0 : 1)), hiw);
+                                                 pk_s + ((size_t)G.cap_e << (G.pk8 ? 0 : 1)), hiw, ensure);
     ROWS_STAMP(4)
     if (l == 0) {
       st.edge_cnt[group] = ne, st.planar_cnt[group] = npl;
@@ -727,7 +846,7 @@ __global__ __launch_bounds__(FUSED ? 128 : 256, FUSED ? 3 : 4) void select_rows_
     if (clr) {
       const unsigned long long mm = (unsigned long long)clr << sh;
       uint32_t* vw_ = vb + row * G.vw + wv;
-      if constexpr (FUSED) {
+      if constexpr (FUSED || SPLIT) {
         if ((uint32_t)mm) __hip_atomic_fetch_or(vw_, (uint32_t)mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if ((uint32_t)(mm >> 32)) __hip_atomic_fetch_or(vw_ + 1, (uint32_t)(mm >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else {

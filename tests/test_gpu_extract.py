@@ -356,10 +356,11 @@ def test_fused_extraction_with_the_rare_paths_forced(oracle):
         b_.free()
 
 
-@pytest.mark.parametrize("form", ["rows", "NO_ROW_SELECT", "FUSED_ROWS"])
+@pytest.mark.parametrize("form", ["rows", "NO_SPLIT_CURV", "NO_ROW_SELECT", "FUSED_ROWS"])
 @pytest.mark.parametrize("forced", [None, "FORCE_TIE_REPLAY", "FORCE_SCAN_GIVEUP", "NO_FUSED_COMPACT"])
 def test_selection_forms_against_the_oracle(oracle, form, forced):
-    """Round 5: the selection with four scan lines per wavefront (select_rows_kernel, the default), one line per wavefront
+    """Round 5: the selection with four scan lines per wavefront (select_rows_kernel, the default: curvature handed over as
+    hi words | lo words with the validity in the sign bit; NO_SPLIT_CURV: as doubles + validity bytes), one line per wavefront
     (NO_ROW_SELECT: select_mis_kernel) and the opt-in fused form that computes curvature and validity itself (FUSED_ROWS; its
     tied lines are recomputed by curvature_tied_kernel for the std::sort replay): double and float input, one noise-free scan
     (ties in most lines), the rare paths forced — index sequences and point copies are the oracle's."""
