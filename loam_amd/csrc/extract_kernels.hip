@@ -793,8 +793,8 @@ __device__ __forceinline__ bool select_line(int lane, size_t line, int W, int CH
   if (lane == 0)
     __hip_atomic_store(fz.line_tot + line, kLinePublished | ((unsigned long long)E_l << 32) | (unsigned long long)P_l,
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  uint32_t* __restrict__ oe = fz.edge_idx + scan * fz.edge_stride;
-  uint32_t* __restrict__ op = fz.planar_idx + scan * fz.planar_stride;
+  uint32_t* __restrict__ oe = fz.edge_idx ? fz.edge_idx + scan * fz.edge_stride : nullptr;  // (optional, as the point copies)
+  uint32_t* __restrict__ op = fz.planar_idx ? fz.planar_idx + scan * fz.planar_stride : nullptr;
   double* __restrict__ xe = fz.edge_xyz ? fz.edge_xyz + scan * fz.edge_stride * 3 : nullptr;
   double* __restrict__ xp = fz.planar_xyz ? fz.planar_xyz + scan * fz.planar_stride * 3 : nullptr;
   const size_t scan_off = scan * (size_t)P.H * P.W * 3;
@@ -867,7 +867,7 @@ __device__ __forceinline__ bool select_line(int lane, size_t line, int W, int CH
       if (on[q]) {
         const bool edge = (q & 1u) == 0u;
         const uint32_t o = (edge ? base_e : base_p) + off[q];
-        (edge ? oe : op)[o] = idx[q];
+        if (oe && op) (edge ? oe : op)[o] = idx[q];
         double* __restrict__ x = edge ? xe : xp;
         if (x) {
 #pragma unroll
@@ -1092,7 +1092,7 @@ __device__ __forceinline__ void compact_one(const T* __restrict__ scan_xyz, uint
       }
 #pragma unroll
       for (uint32_t b = 0; b < kCompactBatch; b++)
-        if (ok[b]) out_idx[o[b]] = idx[b];
+        if (ok[b] && out_idx) out_idx[o[b]] = idx[b];
     }
     carry += total;
     __syncthreads();
@@ -1117,10 +1117,10 @@ __global__ __launch_bounds__(256) void compact_kernel(const T* __restrict__ xyz,
   const uint32_t groups = P.H * P.S;
   const T* scan_xyz = xyz + scan * (size_t)P.H * P.W * 3;
   compact_one(scan_xyz, groups, P.cap_edge, st.edge_stage + scan * (size_t)groups * P.cap_edge,
-              st.edge_cnt + scan * (size_t)groups, edge_idx + scan * edge_stride,
+              st.edge_cnt + scan * (size_t)groups, edge_idx ? edge_idx + scan * edge_stride : nullptr,
               edge_xyz ? edge_xyz + scan * edge_stride * 3 : nullptr, n_edge + scan, split, s_scan, s_off, s_cnt);
   compact_one(scan_xyz, groups, P.cap_planar, st.planar_stage + scan * (size_t)groups * P.cap_planar,
-              st.planar_cnt + scan * (size_t)groups, planar_idx + scan * planar_stride,
+              st.planar_cnt + scan * (size_t)groups, planar_idx ? planar_idx + scan * planar_stride : nullptr,
               planar_xyz ? planar_xyz + scan * planar_stride * 3 : nullptr, n_planar + scan, split, s_scan, s_off, s_cnt);
 }
 

@@ -908,8 +908,10 @@ __global__ __launch_bounds__(FUSED ? 128 : 256, FUSED ? 3 : 4) void select_rows_
     // a sector's picks touch every 128-byte line of it anyway (every 3.7th point is picked, in curvature order), so the
     // gather fetched the whole scan plus re-fetches and kept the texture addresser busy with 64 lines per instruction.
     // The picked points leave through LDS as well, so that the stores are runs of consecutive doubles.
-    uint32_t* __restrict__ oe = fz.edge_idx + scan * fz.edge_stride;
-    uint32_t* __restrict__ op = fz.planar_idx + scan * fz.planar_stride;
+    // (the index arrays are optional: loamx_register_scan_pairs_dev wants the points only)
+    uint32_t* __restrict__ oe = fz.edge_idx ? fz.edge_idx + scan * fz.edge_stride : nullptr;
+    uint32_t* __restrict__ op = fz.planar_idx ? fz.planar_idx + scan * fz.planar_stride : nullptr;
+    const bool want_idx = oe != nullptr && op != nullptr;  // uniform
     double* __restrict__ xe = fz.edge_xyz ? fz.edge_xyz + scan * fz.edge_stride * 3 : nullptr;
     double* __restrict__ xp = fz.planar_xyz ? fz.planar_xyz + scan * fz.planar_stride * 3 : nullptr;
     const size_t scan_pt0 = scan * (size_t)P.H * P.W;  // first point of the scan
@@ -980,7 +982,7 @@ __global__ __launch_bounds__(FUSED ? 128 : 256, FUSED ? 3 : 4) void select_rows_
             const uint32_t pos = i0 == 0 ? pos0 : (on ? pick_pos(i) : 0u);
             const double* src = xbuf + 3 * pos;
             const double x = src[0], y = src[1], z = src[2];
-            if (on) (edge ? oe : op)[(edge ? run_e[rr] : run_p[rr]) + jj] = lb + pos;
+            if (on && want_idx) (edge ? oe : op)[(edge ? run_e[rr] : run_p[rr]) + jj] = lb + pos;
             if (want_box && on) {
               if (edge) {
                 bmin[0][0] = fmin(bmin[0][0], x), bmin[0][1] = fmin(bmin[0][1], y), bmin[0][2] = fmin(bmin[0][2], z);

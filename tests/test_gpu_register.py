@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import reference_kats as K
-from gpu_common import ctx, pose_diff, to_capi_reg
+from gpu_common import ctx, option, pose_diff, to_capi_reg
 from loam_amd import capi
 
 pytestmark = pytest.mark.gpu
@@ -251,6 +251,28 @@ def test_batch_pipeline_is_reproducible_and_batch_size_invariant():
     assert np.array_equal(part, runs[0][first * 64:])
     d_res.free()
     d_xyz.free()
+
+
+@pytest.mark.parametrize("opt", ["FORCE_TIE_REPLAY", "FORCE_SCAN_GIVEUP", "NO_FUSED_COMPACT", "NO_ROW_SELECT", "NO_MIS_SELECT", "NO_SPLIT_CURV", "FUSED_ROWS"])
+def test_scan_pairs_do_not_depend_on_the_extraction_path(opt):
+    """loamx_register_scan_pairs_dev asks the extraction for the features' points only (no index arrays: round 5), through
+    whichever selection / compaction path runs: every forced or optional path of the extraction gives the bits of the default."""
+    H, W, n_pairs, seed = 64, 1024, 6, 777
+    N = H * W
+    c = ctx()
+    lidar = capi.LidarParams(H, W, 1.0, 120.0)
+    fe, reg = capi.FeatureExtractionParams(), capi.RegistrationParams()
+    d_xyz, d_res = c.alloc(n_pairs * 2 * N * 24), c.alloc(n_pairs * 64)
+    c.synth_scan_pairs_dev(seed, 0, n_pairs, H, W, 0.01, d_xyz.ptr)
+    c.register_scan_pairs_dev(d_xyz.ptr, n_pairs, lidar, fe, reg, d_res.ptr)
+    c.synchronize()
+    want = d_res.download(np.uint8, n_pairs * 64).copy()
+    with option(opt):
+        c.register_scan_pairs_dev(d_xyz.ptr, n_pairs, lidar, fe, reg, d_res.ptr)
+        c.synchronize()
+    assert np.array_equal(d_res.download(np.uint8, n_pairs * 64), want), opt
+    d_xyz.free()
+    d_res.free()
 
 
 def test_scan_pairs_128x2048_use_the_big_set_paths(oracle):
