@@ -1200,11 +1200,19 @@ static bool launch_select_rows(const double* d_curv, const uint8_t* d_mask, size
   if (!row_select_geom(P, G) || (reinterpret_cast<uintptr_t>(d_mask) & 15u) != 0 || n_lines % 4 != 0) return false;
   if (fz.fuse && P.W > 65535) return false;
   if ((P.flags & kFlagSplitCurv) && !(P.np == 3 && G.ch == 11)) return false;  // (launch_extract_split_ok said otherwise: not reached)
-  switch ((int)P.np - 1) {
-    case 1: launch_select_rows_r<1>(d_curv, d_mask, n_lines, P, st, fz, G, s); break;
-    case 2: launch_select_rows_r<2>(d_curv, d_mask, n_lines, P, st, fz, G, s); break;
-    case 3: launch_select_rows_r<3>(d_curv, d_mask, n_lines, P, st, fz, G, s); break;
-    default: launch_select_rows_r<4>(d_curv, d_mask, n_lines, P, st, fz, G, s); break;
+  // With the fused compaction: first without the stage arrays, then — a launch that leaves at once unless a line gave up or
+  // was tied — the plain selection that writes them for replay_kernel / compact_kernel (ExtractFused::no_stage / only_if)
+  const bool two = fz.fuse && fz.error != nullptr && fz.line_tot != nullptr && !(P.flags & kFlagStageAlways);
+  for (int pass = 0; pass < (two ? 2 : 1); pass++) {
+    ExtractFused f = fz;
+    if (two && pass == 0) f.no_stage = 1u;
+    if (two && pass == 1) f.fuse = 0u, f.only_if = fz.error, f.box_min = f.box_max = nullptr;
+    switch ((int)P.np - 1) {
+      case 1: launch_select_rows_r<1>(d_curv, d_mask, n_lines, P, st, f, G, s); break;
+      case 2: launch_select_rows_r<2>(d_curv, d_mask, n_lines, P, st, f, G, s); break;
+      case 3: launch_select_rows_r<3>(d_curv, d_mask, n_lines, P, st, f, G, s); break;
+      default: launch_select_rows_r<4>(d_curv, d_mask, n_lines, P, st, f, G, s); break;
+    }
   }
   return true;
 }

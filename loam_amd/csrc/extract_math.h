@@ -41,6 +41,7 @@ enum : uint32_t {
   kFlagFusedExtract = 32u,   // one-pass extract_fused_kernel where the parameters allow
   kFlagNoRowSelect = 64u,    // one scan line per wavefront (select_mis_kernel) instead of four (select_rows_kernel)
   kFlagFusedRows = 128u,     // opt-in: the fused form of select_rows_kernel (curvature + validity inside it) instead of the two kernels
+  kFlagStageAlways = 512u,   // the fused selection writes the stage arrays too (one launch; otherwise a second, conditional one does)
   kFlagNoSplitCurv = 256u,   // curvature as doubles + validity bytes between the two kernels even where the split form applies
   kFlagSplitCurv = 1u << 30  // (set by extract_dev, not an option) this call's kernels use the split form: see curvature_valid2_kernel
 };

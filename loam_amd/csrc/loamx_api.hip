@@ -115,7 +115,7 @@ struct OptionName {
 const OptionName kOptionNames[] = {
     {"FORCE_TIE_REPLAY", true, kFlagForceReplay}, {"FORCE_SCAN_GIVEUP", true, kFlagForceGiveUp}, {"CURV_V1", true, kFlagCurvV1},
     {"NO_FUSED_COMPACT", true, kFlagNoFusedCompact}, {"NO_MIS_SELECT", true, kFlagNoMisSelect}, {"FUSED_EXTRACT", true, kFlagFusedExtract},
-    {"NO_ROW_SELECT", true, kFlagNoRowSelect}, {"FUSED_ROWS", true, kFlagFusedRows}, {"NO_SPLIT_CURV", true, kFlagNoSplitCurv},
+    {"NO_ROW_SELECT", true, kFlagNoRowSelect}, {"FUSED_ROWS", true, kFlagFusedRows}, {"NO_SPLIT_CURV", true, kFlagNoSplitCurv}, {"STAGE_ALWAYS", true, kFlagStageAlways},
     {"NO_MOMENTS", false, kRegFlagNoMoments}, {"NO_PACKED_GRID", false, kRegFlagNoPackedGrid}, {"NO_BIG_GRID", false, kRegFlagNoBigGrid},
     {"NO_GRID_SIDE", false, kRegFlagNoGridSide}, {"DEBUG_POISON", false, kRegFlagPoison},
     {"QUEUE_TWO_STAGE", false, kRegFlagQueueTwoStage}, {"QUEUE_ONE_STAGE", false, kRegFlagQueueOneStage},

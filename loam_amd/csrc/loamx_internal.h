@@ -77,6 +77,12 @@ struct ExtractFused {
   // Complete iff the flag word *error stays zero (no line gave up or was tied: those scans went through compact_kernel).
   unsigned long long* box_min;
   unsigned long long* box_max;
+  // select_rows_kernel only (round 5). no_stage: the stage arrays and per-sector counts — the fallback compaction's input — are
+  // not written; only_if: the launch leaves at once unless this word is non-zero. launch_select runs the fused selection
+  // without the stage arrays (4 B per feature saved) and, behind it, the plain one under only_if = error: when a line gave up
+  // or was tied, that second launch produces what replay_kernel / compact_kernel read; otherwise it costs its launch.
+  uint32_t no_stage;
+  const uint32_t* only_if;
 };
 // doubles as unsigned keys with the same order (for atomicMin / atomicMax)
 __device__ __forceinline__ unsigned long long dbl_key(double v) {

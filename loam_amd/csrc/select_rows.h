@@ -292,6 +292,7 @@ struct RowSelCtx {  // per-lane constants of a wavefront's four lines
   uint32_t* sl;         // LDS: the row's 64 key slots (4 bytes each)
   uint32_t* tk;         // LDS: the row's cap threshold key (8 bytes)
   uint32_t ib, pk8;     // bits of a sector position; pick lists hold bytes (1) or 16-bit words (0)
+  bool no_stage;        // the stage arrays are not written (ExtractFused::no_stage)
   int32_t kbase_e, kbase_p, kmax;
 };
 
@@ -349,7 +350,7 @@ __device__ __forceinline__ uint32_t row_pass(const RowSelCtx& X, uint32_t& V, ui
   };
   auto key32 = [&](int j) -> uint32_t { return make_key(reinterpret_cast<const int32_t*>(X.cp)[2 * (j + R) + 1], j); };
   auto put_pick = [&](uint32_t q, uint32_t pos) {  // kept pick of output rank q at sector position pos
-    stage[q] = line_base + (uint32_t)start + pos;
+    if (!X.no_stage) stage[q] = line_base + (uint32_t)start + pos;
     if (X.pk8) static_cast<uint8_t*>(pk_list)[q] = (uint8_t)pos;
     else static_cast<uint16_t*>(pk_list)[q] = (uint16_t)pos;
   };
@@ -480,6 +481,7 @@ template <int R, int CHT, bool FUSED = false, bool SPLIT = false>
 __global__ __launch_bounds__(FUSED ? 128 : 256, FUSED ? 3 : 4) void select_rows_kernel(const double* __restrict__ curv, const uint8_t* __restrict__ mask, size_t n_lines,
                                                           ExtractParams P, ExtractStage st, ExtractFused fz, RowSelGeom G) {
   static_assert(!SPLIT || (CHT != 0 && !FUSED), "the split form is written for the compile-time lane chunk");
+  if (fz.only_if && __hip_atomic_load(fz.only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;  // uniform (ExtractFused::only_if)
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row = lane >> 4, l = lane & 15;
   const size_t line0 = ((size_t)blockIdx.x * (FUSED ? 2 : 4) + wave) * 4;  // four consecutive lines of one scan (H % 4 == 0)
@@ -497,6 +499,7 @@ __global__ __launch_bounds__(FUSED ? 128 : 256, FUSED ? 3 : 4) void select_rows_
   X.sl = reinterpret_cast<uint32_t*>(blk + G.off_sl) + row * 64;
   X.tk = reinterpret_cast<uint32_t*>(blk + G.off_tk) + row * 2;
   unsigned char* pk_row = blk + G.off_pk + ((size_t)row * G.pk_stride << (G.pk8 ? 0 : 1));
+  X.no_stage = fz.no_stage != 0u;
   X.ib = G.ib, X.pk8 = G.pk8, X.kbase_e = G.kbase_e, X.kbase_p = G.kbase_p, X.kmax = (int32_t)((1u << (32 - G.ib)) - 1u);
   uint16_t* cnt = reinterpret_cast<uint16_t*>(blk + G.off_cnt) + row * 32;  // picks kept per (sector, kind) of my line
   const size_t line = line0 + row;
@@ -837,7 +840,7 @@ __global__ __launch_bounds__(FUSED ? 128 : 256, FUSED ? 3 : 4) void select_rows_
                                                  pk_s + ((size_t)G.cap_e << (G.pk8 ? 0 : 1)), hiw, ensure);
     ROWS_STAMP(4)
     if (l == 0) {
-      st.edge_cnt[group] = ne, st.planar_cnt[group] = npl;
+      if (!X.no_stage) st.edge_cnt[group] = ne, st.planar_cnt[group] = npl;
       cnt[2 * s] = (uint16_t)ne, cnt[2 * s + 1] = (uint16_t)npl;  // (for the copy phase)
     }
     tot_e += ne, tot_p += npl;
