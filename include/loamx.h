@@ -134,7 +134,7 @@ int loamx_ctx_extract_counters(loamx_ctx* ctx, uint64_t* tie_replays, uint64_t* 
  * switch only ever affects the context it was set on. None changes a result beyond the summation order of
  * NO_MOMENTS (and CHECK_FINITE, which only adds a refusal). Names — the complete list; DESIGN.md section 5 describes each:
  *   extraction:    FORCE_TIE_REPLAY, FORCE_SCAN_GIVEUP, CURV_V1, NO_FUSED_COMPACT, NO_MIS_SELECT, NO_ROW_SELECT, FUSED_EXTRACT,
- *                  FUSED_ROWS
+ *                  FUSED_ROWS, NO_SPLIT_CURV, STAGE_ALWAYS
  *   registration:  NO_MOMENTS, NO_REF_MOMENTS, NO_PACKED_GRID, NO_BIG_GRID, NO_GRID_SIDE, NO_EXTRACT_BOXES, NO_SMALL_SETS, DEBUG_POISON,
  *                  QUEUE_TWO_STAGE, QUEUE_ONE_STAGE, NO_COOP_LEFT, NO_MIXED_ASSOC, MAP_CELLS_LOG2 (a number: 0 = default)
  *   multi-GPU:     FORCE_RCCL (a one-rank communicator really enqueues the RCCL collectives)

@@ -1187,6 +1187,15 @@ template <int R>
 static void launch_select_rows_r(const double* d_curv, const uint8_t* d_mask, size_t n_lines, const ExtractParams& P, const ExtractStage& st,
                                  const ExtractFused& fz, const RowSelGeom& G, hipStream_t s) {
   const dim3 grid((unsigned)((n_lines + 15) / 16));
+  if (fz.only_if) {  // the conditional second launch (launch_select_rows)
+    if (R == 2 && G.ch == 11 && (P.flags & kFlagSplitCurv))
+      launch_kernel((select_rows_stage_kernel<R, R == 2 ? 11 : 0, R == 2>), grid, dim3(256), (size_t)G.bytes * 4, s, d_curv, d_mask, n_lines, P, st, fz, G);
+    else if (R == 2 && G.ch == 11)
+      launch_kernel((select_rows_stage_kernel<R, R == 2 ? 11 : 0, false>), grid, dim3(256), (size_t)G.bytes * 4, s, d_curv, d_mask, n_lines, P, st, fz, G);
+    else
+      launch_kernel((select_rows_stage_kernel<R, 0, false>), grid, dim3(256), (size_t)G.bytes * 4, s, d_curv, d_mask, n_lines, P, st, fz, G);
+    return;
+  }
   if (R == 2 && G.ch == 11 && (P.flags & kFlagSplitCurv))
     launch_kernel((select_rows_kernel<R, R == 2 ? 11 : 0, false, R == 2>), grid, dim3(256), (size_t)G.bytes * 4, s, d_curv, d_mask, n_lines, P, st, fz, G);
   else if (R == 2 && G.ch == 11)

@@ -478,8 +478,8 @@ __device__ __forceinline__ uint32_t row_pass(const RowSelCtx& X, uint32_t& V, ui
 // a point and a threshold) are EQUAL, or two picks' keys collide, the sector's lo words are fetched and the doubles compared
 // as before (wave-uniform, ~1 sector in 500 on noisy scans). vb then holds the SUPPRESSED points, as in the fused form.
 template <int R, int CHT, bool FUSED = false, bool SPLIT = false>
-__global__ __launch_bounds__(FUSED ? 128 : 256, FUSED ? 3 : 4) void select_rows_kernel(const double* __restrict__ curv, const uint8_t* __restrict__ mask, size_t n_lines,
-                                                          ExtractParams P, ExtractStage st, ExtractFused fz, RowSelGeom G) {
+__device__ __forceinline__ void select_rows_body(const double* __restrict__ curv, const uint8_t* __restrict__ mask, size_t n_lines,
+                                                 const ExtractParams& P, const ExtractStage& st, const ExtractFused& fz, const RowSelGeom& G) {
   static_assert(!SPLIT || (CHT != 0 && !FUSED), "the split form is written for the compile-time lane chunk");
   if (fz.only_if && __hip_atomic_load(fz.only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;  // uniform (ExtractFused::only_if)
   extern __shared__ __align__(16) unsigned char smem[];
@@ -1040,6 +1040,19 @@ __global__ __launch_bounds__(FUSED ? 128 : 256, FUSED ? 3 : 4) void select_rows_
       if (fz.events) atomicAdd(&fz.events[2], (unsigned long long)(run_e[3] + run_p[3]));  // (roofline bytes of the fused kernel)
     }
   }
+}
+
+template <int R, int CHT, bool FUSED = false, bool SPLIT = false>
+__global__ __launch_bounds__(FUSED ? 128 : 256, FUSED ? 3 : 4) void select_rows_kernel(const double* __restrict__ curv, const uint8_t* __restrict__ mask, size_t n_lines,
+                                                          ExtractParams P, ExtractStage st, ExtractFused fz, RowSelGeom G) {
+  select_rows_body<R, CHT, FUSED, SPLIT>(curv, mask, n_lines, P, st, fz, G);
+}
+// The same kernel under another name: the conditional second launch behind a fused selection (ExtractFused::only_if), which
+// leaves at once unless a line gave up or was tied — a name of its own so that profiles do not average it with the first.
+template <int R, int CHT, bool SPLIT>
+__global__ __launch_bounds__(256, 4) void select_rows_stage_kernel(const double* __restrict__ curv, const uint8_t* __restrict__ mask, size_t n_lines,
+                                                                   ExtractParams P, ExtractStage st, ExtractFused fz, RowSelGeom G) {
+  select_rows_body<R, CHT, false, SPLIT>(curv, mask, n_lines, P, st, fz, G);
 }
 
 #undef LOAMX_CX
