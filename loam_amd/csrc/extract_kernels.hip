@@ -103,7 +103,13 @@ __global__ __launch_bounds__(kCurvThreads) void curvature_valid_kernel(const T* 
 // coordinate arrays, every thread owns TWO adjacent columns and reads the 2 NP + 2 values its two sums share as
 // 16-byte pairs (NP = 3: 5 ds_read_b128 per coordinate for two points instead of 2 x 7 ds_read_b64), and writes
 // both results with one 16-byte + one 2-byte store. Arithmetic and its order are those of curvature_at.
-constexpr int kCurvTilesPerGroup = 2;  // tiles one workgroup walks (the next tile's loads fly during this tile's arithmetic)
+// Tiles one workgroup walks. Round 5: ONE. With two (rounds 3 - 4: the next tile's loads fly in registers during this tile's
+// arithmetic) the kernel held 116 - 128 registers = 4 wavefronts per SIMD; without the prefetch it holds 64 = 8, and the other
+// workgroups of the CU do the overlapping: 0.92 -> 0.73 - 0.76 ms (4.6 -> 5.7 TB/s).
+#ifndef LOAMX_CURV_TILES
+#define LOAMX_CURV_TILES 1
+#endif
+constexpr int kCurvTilesPerGroup = LOAMX_CURV_TILES;
 
 __device__ __forceinline__ void wave_lds_sync() {
   // LDS operations of one wavefront complete in issue order; this only stops the compiler from
@@ -131,7 +137,11 @@ struct Curv2 {
 // one wavefront on its own with wavefront-level ordering only, `tid` then being the lane) and
 // hands every thread its two results: sink(c0, cv[2], ok[2]) for the columns c0, c0 + 1 (c0 < W; c0 + 1 may be == W).
 // s_p / s_r / s_bits: Curv2<NP>::kLoc doubles x 3, kLoc doubles, kWords words x 4 of LDS.
-template <int NP, int THREADS, typename T, typename Sink>
+// AOS (round 5, curvature_valid2_kernel): the tile is kept in LDS as it lies in the scan — [point][xyz], the same 3 * kLoc doubles —
+// instead of as three coordinate arrays: element k of the staged span goes to word k (no k / 3, k % 3 per element: 42 of the
+// kernel's ~340 vector instructions per thread), and a thread reads the nine points its two sums need as one run of 216 bytes
+// (14 ds_read_b128 at a lane stride of 48 bytes: the 16 lanes of a quarter-wavefront cover the 64 banks once) instead of 15.
+template <int NP, int THREADS, typename T, typename Sink, bool AOS = false>
 __device__ __forceinline__ void curvature_line_tiles(const T* __restrict__ g, const ExtractParams& P, int t_first, int n_tiles,
                                                      double (*s_p)[Curv2<NP, THREADS>::kLoc], double* s_r,
                                                      unsigned long long (*s_bits)[Curv2<NP, THREADS>::kWords], Sink sink) {
@@ -165,14 +175,19 @@ __device__ __forceinline__ void curvature_line_tiles(const T* __restrict__ g, co
     const int base = t0 - hp;  // column of local index 0
     const int lo = t0 - halo > 0 ? t0 - halo : 0;
     const int hi = t0 + kTile + halo < W ? t0 + kTile + halo : W;
+    double* const aos = &s_p[0][0];  // (AOS) the same LDS as [point][xyz]
     {  // element k goes to coordinate k % 3 of point k / 3
       const int nd = (hi - lo) * 3;
 #pragma unroll
       for (int q = 0; q < kLoads; q++) {
         const int k = tid + q * kCurvThreads;
         if (k < nd) {
-          const uint32_t pt = __umulhi((uint32_t)k, 0x55555556u);  // k / 3
-          s_p[(uint32_t)k - 3u * pt][lo - base + (int)pt] = (double)regs[q];
+          if constexpr (AOS) {
+            aos[3 * (lo - base) + k] = (double)regs[q];
+          } else {
+            const uint32_t pt = __umulhi((uint32_t)k, 0x55555556u);  // k / 3
+            s_p[(uint32_t)k - 3u * pt][lo - base + (int)pt] = (double)regs[q];
+          }
         }
       }
     }
@@ -180,7 +195,8 @@ __device__ __forceinline__ void curvature_line_tiles(const T* __restrict__ g, co
     if (tt + 1 < n_tiles && t0 + kTile < W) fetch(t0 + kTile);  // in flight until the next trip
     for (int c = lo + tid; c < hi; c += kCurvThreads) {
       const int li = c - base;
-      s_r[li] = point_range(s_p[0][li], s_p[1][li], s_p[2][li]);
+      if constexpr (AOS) s_r[li] = point_range(aos[3 * li], aos[3 * li + 1], aos[3 * li + 2]);
+      else s_r[li] = point_range(s_p[0][li], s_p[1][li], s_p[2][li]);
     }
     barrier();
     {
@@ -200,6 +216,25 @@ __device__ __forceinline__ void curvature_line_tiles(const T* __restrict__ g, co
     const int c0 = t0 + 2 * tid, li0 = hp + 2 * tid;
     if (c0 < W) {
       double d[2][3];
+      if constexpr (AOS) {
+        static_assert(!AOS || (A % 2 == 0 && A >= NP), "the run of points li0 - A .. li0 + 1 + NP starts 16-byte aligned (li0 is even) and holds every neighbour");
+        constexpr int kRun = (3 * (A + NP + 2) + 1) / 2;  // 16-byte pieces covering points li0 - A .. li0 + 1 + NP
+        double r[2 * kRun];
+#pragma unroll
+        for (int q = 0; q < kRun; q++) {
+          const double2 v = *reinterpret_cast<const double2*>(&aos[3 * (li0 - A) + 2 * q]);
+          r[2 * q] = v.x, r[2 * q + 1] = v.y;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int col = 0; col < 2; col++) {  // features-inl.h:73-82, the order of curvature_at
+            double acc = -(2.0 * np) * r[3 * (A + col) + a];
+#pragma unroll
+            for (int n = 1; n <= NP; n++) acc = acc + r[3 * (A + col - n) + a] + r[3 * (A + col + n) + a];
+            d[col][a] = acc;
+          }
+      } else {
 #pragma unroll
       for (int a = 0; a < 3; a++) {
         double w[2 * kPairs];
@@ -215,6 +250,7 @@ __device__ __forceinline__ void curvature_line_tiles(const T* __restrict__ g, co
           for (int n = 1; n <= NP; n++) acc = acc + w[A + col - n] + w[A + col + n];
           d[col][a] = acc;
         }
+      }
       }
       double cv[2];
       bool ok[2];
@@ -252,8 +288,7 @@ __global__ __launch_bounds__(kCurvThreads, LOAMX_CURV_WAVES) void curvature_vali
   const size_t line = blockIdx.x;  // scan * H + line
   const int W = (int)P.W;
   const T* __restrict__ g = xyz + line * (size_t)W * 3;
-  curvature_line_tiles<NP, kCurvThreads, T>(g, P, (int)blockIdx.y * kCurvTilesPerGroup * kTile, kCurvTilesPerGroup, s_p, s_r, s_bits,
-                              [&](int c0, const double cv[2], const bool ok[2]) {
+  auto sink = [&](int c0, const double cv[2], const bool ok[2]) {
                                 const size_t o = line * (size_t)W + c0;
                                 if constexpr (SPLIT) {  // (launched for even W only)
                                   uint32_t* __restrict__ hi_out = reinterpret_cast<uint32_t*>(curv_out);
@@ -271,7 +306,12 @@ __global__ __launch_bounds__(kCurvThreads, LOAMX_CURV_WAVES) void curvature_vali
                                   curv_out[o] = cv[0], mask_out[o] = ok[0] ? 1 : 0;
                                   if (c0 + 1 < W) curv_out[o + 1] = cv[1], mask_out[o + 1] = ok[1] ? 1 : 0;
                                 }
-                              });
+                              };
+#ifndef LOAMX_CURV_AOS
+#define LOAMX_CURV_AOS 1
+#endif
+  curvature_line_tiles<NP, kCurvThreads, T, decltype(sink), LOAMX_CURV_AOS != 0>(g, P, (int)blockIdx.y * kCurvTilesPerGroup * kTile, kCurvTilesPerGroup, s_p, s_r,
+                                                                                  s_bits, sink);
 }
 
 
