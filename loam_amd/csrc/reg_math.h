@@ -1264,10 +1264,16 @@ LOAMX_HD bool knn_lean_half_trip(KnnKeys32<KM>& c, LeanBatch& cur, LeanBatch& nx
   return nxt.n != 0u || ri < nrow;
 }
 
-template <int KM>
+// requery: the query point once more, for the verification behind the walk. The round-1 kernel passes a functor that reloads
+// and moves the source point again, so that the point's three doubles and its cell are not live through the candidate loop
+// (9 registers: what the kernel needs to fit a sixth wavefront per SIMD); KnnSameQuery hands the argument back.
+struct KnnSameQuery {
+  LOAMX_HD Vec3 operator()(const Vec3& q) const { return q; }
+};
+template <int KM, typename Requery = KnnSameQuery>
 LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cell_start, const GridPoint* __restrict__ sp,
                              const float* __restrict__ rel, uint32_t plane, Vec3 q, int k, double max_dist, double pass_max,
-                             uint32_t pos[KM], uint32_t* row_scratch, int row_stride) {
+                             uint32_t pos[KM], uint32_t* row_scratch, int row_stride, Requery requery = Requery()) {
 #pragma unroll
   for (int j = 0; j < KM; j++) pos[j] = 0;
   if (g.n_points == 0 || k <= 0) return 0;
@@ -1410,7 +1416,11 @@ LOAMX_HD int knn_lean_round1(const GridDesc& g, const uint32_t* __restrict__ cel
 #if defined(LOAMX_LEAN_UNPIPELINED)
   if (p < e || ri < nrow) return -2;  // the trip budget is used up with rows still to look at: the queue's business
 #endif
-  return knn_lean_finish<KM>(g, sp, q, k, max_dist, pass_max, a, cx, cy, cz, c, started, row_scratch, row_stride, 0, pos);
+  {
+    const Vec3 q2 = requery(q);
+    const int32_t cx2 = grid_cell_coord(q2.x, g.ox, g.inv_h), cy2 = grid_cell_coord(q2.y, g.oy, g.inv_h), cz2 = grid_cell_coord(q2.z, g.oz, g.inv_h);
+    return knn_lean_finish<KM>(g, sp, q2, k, max_dist, pass_max, a, cx2, cy2, cz2, c, started, row_scratch, row_stride, 0, pos);
+  }
 }
 
 
@@ -1543,14 +1553,14 @@ LOAMX_HD int knn_lean_round2(const GridDesc& g, const uint32_t* __restrict__ cel
 
 // WIDE = false: 8-bit running numbers (the fast kernel; a query with more than 63 batches is queued);
 // WIDE = true: 10 or 12 bits (the queue kernel tries this before the FP64 search: dense local maps).
-template <int KM, bool WIDE = false>
+template <int KM, bool WIDE = false, typename Requery = KnnSameQuery>
 LOAMX_HD int knn_search_f32_round1(const GridDesc& g, const uint32_t* __restrict__ cell_start,
                                    const GridPoint* __restrict__ sp, const float* __restrict__ rel, uint32_t plane, Vec3 q,
                                    int k, double max_dist, double pass_max, uint32_t pos[KM], uint32_t* row_scratch,
-                                   int row_stride) {
+                                   int row_stride, Requery requery = Requery()) {
 #if !defined(LOAMX_NO_LEAN_KNN)
   if (!WIDE && g.n_points <= kLeanMaxPoints)  // (wave-uniform: a property of the target set)
-    return knn_lean_round1<KM>(g, cell_start, sp, rel, plane, q, k, max_dist, pass_max, pos, row_scratch, row_stride);
+    return knn_lean_round1<KM>(g, cell_start, sp, rel, plane, q, k, max_dist, pass_max, pos, row_scratch, row_stride, requery);
 #endif
 #pragma unroll
   for (int j = 0; j < KM; j++) pos[j] = 0;

@@ -733,6 +733,12 @@ constexpr int kAssocThreads = 256;
 #ifndef LOAMX_ASSOC_WAVES
 #define LOAMX_ASSOC_WAVES 4  // measured: 2 -> 12.3 ms, 3 -> 9.3, 4 -> 8.1 (320 B scratch), 5+ spills badly
 #endif
+#ifndef LOAMX_KNN_REQUERY
+#define LOAMX_KNN_REQUERY 1
+#endif
+#ifndef LOAMX_ASSOC_WAVES5
+#define LOAMX_ASSOC_WAVES5 (LOAMX_KNN_REQUERY ? 6 : 4)  // the round-1 kernels of k <= 5 (knn_round1_body: 80 registers with the requery)
+#endif
 
 // Workgroup -> (pair, chunk) mapping: workgroups are dealt round-robin over the 8 XCDs, so all
 // chunks of one pair are given ids with the same id % 8 and share one XCD's L2 (the pair's target
@@ -953,9 +959,25 @@ __device__ __forceinline__ void knn_round1_body(const RegBatch& B, const RegConf
   const GridPoint* __restrict__ sp = gs.sorted + pair * gs.stride;
   uint32_t pos[KM];  // (s_rows: per-thread row lists of knn_lean_round1, [word][thread], conflict free)
   const float* __restrict__ rel = gs.rel + pair * 3 * gs.stride;
+#if LOAMX_KNN_REQUERY
+  // (round 5) the verification behind the walk takes the query point from a second load + transform instead of from nine
+  // registers held through the candidate loop: 89 -> 80 registers, a sixth wavefront per SIMD without scratch (the recomputation
+  // alone, at five: 1.155 -> 1.195 ms; with the sixth wavefront: 1.139 ms)
+  const GridPoint* __restrict__ src_pts = src_gs.sorted + pair * src_gs.stride;
+  auto requery = [&](const Vec3&) -> Vec3 {
+    uint32_t ii = i;
+    asm volatile("" : "+v"(ii));  // (opaque: a second load, not the first one's registers kept)
+    const GridPoint s2 = src_pts[ii];
+    return pose_act(S.est, v3(s2.x, s2.y, s2.z));
+  };
+  const int kept = knn_search_f32_round1<KM, false, decltype(requery)>(g, cs, sp, rel, (uint32_t)gs.stride, p, PLANE ? C.k_plane : C.k_edge,
+                                             PLANE ? C.r_plane : C.r_edge, PLANE ? C.pass_plane : C.pass_edge, pos,
+                                             s_rows + threadIdx.x, kAssocThreads, requery);
+#else
   const int kept = knn_search_f32_round1<KM>(g, cs, sp, rel, (uint32_t)gs.stride, p, PLANE ? C.k_plane : C.k_edge,
                                              PLANE ? C.r_plane : C.r_edge, PLANE ? C.pass_plane : C.pass_edge, pos,
                                              s_rows + threadIdx.x, kAssocThreads);
+#endif
   const size_t field = B.n_pairs * stride, slot = pair * stride + i;
   uint32_t* __restrict__ nn = PLANE ? B.assoc.nn_plane : B.assoc.nn_edge;  // [1 + KM][n_pairs * stride]
   nn[slot] = kept < 0 ? 0xFFFFFFFFu : (uint32_t)kept;
@@ -969,7 +991,7 @@ __device__ __forceinline__ void knn_round1_body(const RegBatch& B, const RegConf
   for (int j = 0; j < KM; j++) nn[(1 + j) * field + slot] = pos[j];  // neighbour j is slot (KM - k) + j
 }
 template <bool PLANE, int KM>
-__global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_knn_kernel(RegBatch B, RegConfig C,
+__global__ __launch_bounds__(kAssocThreads, KM <= 5 ? LOAMX_ASSOC_WAVES5 : LOAMX_ASSOC_WAVES) void associate_knn_kernel(RegBatch B, RegConfig C,
                                                                                          uint32_t blocks_per_pair) {
   __shared__ uint32_t s_rows[kLeanRowWords * kAssocThreads];
   knn_round1_body<PLANE, KM>(B, C, blocks_per_pair, blockIdx.x, s_rows);
@@ -979,7 +1001,7 @@ __global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_kn
 // edge chain cost the plane kernel about half of its own duration (1.07 -> 1.22 ms); as extra workgroups of the same
 // dispatch it costs its instructions. One LDS buffer serves both kinds (the row lists are the larger).
 template <int KME, int KMP>
-__global__ __launch_bounds__(kAssocThreads, LOAMX_ASSOC_WAVES) void associate_knn_mixed_kernel(RegBatch B, RegConfig C, uint32_t blocks_edge,
+__global__ __launch_bounds__(kAssocThreads, (KME <= 5 && KMP <= 5) ? LOAMX_ASSOC_WAVES5 : LOAMX_ASSOC_WAVES) void associate_knn_mixed_kernel(RegBatch B, RegConfig C, uint32_t blocks_edge,
                                                                                                uint32_t blocks_plane, uint32_t edge_blocks) {
   constexpr size_t kRowBytes = sizeof(uint32_t) * kLeanRowWords * kAssocThreads, kTileBytes = kBruteLdsBytes;
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[kRowBytes > kTileBytes ? kRowBytes : kTileBytes];
