@@ -48,7 +48,7 @@ VALU_PEAK_GINST = 256 * 4 * 2.4 / VALU_CYCLES_PER_INST
 SEED = 20240311
 H, W = 64, 1024
 SIGMA = 0.01
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc.json")
 
 
 def parse_args():
@@ -242,6 +242,19 @@ def main():
         stats = ctx.kernel_stats()
         ctx.enable_kernel_timing(False)
 
+    # the selection's algorithmic bytes include the picks' coordinates (24 B read + 24 B written per feature: the copies the
+    # reference's extractFeatures returns), which the library cannot price when it enqueues the launch — the feature counts
+    # live on the device. Counted here, once, outside every timed region.
+    picks_per_launch = None
+    if stats and rank == 0:
+        ecap, pcap, ns = ctx.edge_capacity(lidar, fe), ctx.planar_capacity(lidar, fe), 2 * P
+        bufs = [ctx.alloc(ns * ecap * 4), ctx.alloc(ns * 4), ctx.alloc(ns * ecap * 24), ctx.alloc(ns * pcap * 4), ctx.alloc(ns * 4), ctx.alloc(ns * pcap * 24)]
+        ctx.extract_features_batch_dev(xyz.data_ptr(), ns, lidar, fe, *[b.ptr for b in bufs], f32=f32)
+        ctx.synchronize()
+        picks_per_launch = int(bufs[1].download(np.uint32, ns).astype(np.int64).sum() + bufs[4].download(np.uint32, ns).astype(np.int64).sum())
+        for b in bufs:
+            b.free()
+
     res_all = all_results.cpu().numpy().view(capi.RESULT_DTYPE)
     res = res_all[first_pair:first_pair + P]
     ranks = None
@@ -295,6 +308,10 @@ def main():
             avg_ms = s["total_ms"] / s["launches"]
             kern[name] = dict(launches=s["launches"], total_ms=round(s["total_ms"], 4), avg_ms=round(avg_ms, 5),
                               algorithmic_bytes_per_launch=s["algorithmic_bytes"] / s["launches"])
+        if "select_kernel" in kern and picks_per_launch is not None:
+            kern["select_kernel"]["algorithmic_bytes_per_launch"] += 48.0 * picks_per_launch
+            kern["select_kernel"]["algorithmic_bytes_note"] = (f"curvature words read + 2 x 24 B per feature copied ({picks_per_launch} features per launch, "
+                                                               "counted on the device outside the timed region)")
         for name, k in kern.items():
             b = k["algorithmic_bytes_per_launch"]
             k["achieved_GBs"] = round(b / (k["avg_ms"] * 1e-3) / 1e9, 2) if b > 0 and k["avg_ms"] > 0 else None
@@ -303,17 +320,18 @@ def main():
             top = {n: k for n, k in kern.items() if n != "knn_plane_kernel"}  # (a sub-scope of associate_kernel)
             dominant = max(top, key=lambda n: top[n]["total_ms"])
             dk = kern[dominant]
-            roofline = dict(kernel=dominant, bound="hbm", achieved=dk["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
+            # `scope` = the HIP-event scope the numbers below are measured over (one launch of every kernel of the association:
+            # k-NN + fit, edge + plane, queue chain); `kernel` = the rocprofv3 kernel that dominates that scope and the step
+            roofline = dict(kernel=dominant, scope=dominant, bound="hbm", achieved=dk["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=dk["hbm_frac"], traffic=None,
                             avg_launch_ms=dk["avg_ms"], algorithmic_bytes_per_launch=dk["algorithmic_bytes_per_launch"],
                             share_of_kernel_time=round(dk["total_ms"] / sum(k["total_ms"] for k in top.values()), 4),
                             measured_over_steps=stat_steps)
-            # `kernel` above is an event SCOPE (one launch of every kernel of the association: k-NN + fit, edge + plane, queue
-            # chain). The rocprofv3 kernel that dominates it — and the whole step — is named here, with its live duration
-            # (HIP events around that launch alone: sub-scope knn_plane_kernel) and, from the committed trace of the same
-            # sources, rocprofv3's own average and share of kernel time
+            # The dominant kernel's live duration (HIP events around that launch alone: sub-scope knn_plane_kernel) and, from the
+            # committed trace of the same sources, rocprofv3's own average and share of kernel time
             if dominant == "associate_kernel" and "knn_plane_kernel" in kern:
-                roofline["dominant_rocprof_kernel"] = {
+                roofline["kernel"] = "associate_knn_mixed_kernel<5, 5>"
+                roofline["kernel_detail"] = {
                     "name": "associate_knn_mixed_kernel<5, 5>", "avg_us": round(kern["knn_plane_kernel"]["avg_ms"] * 1e3, 1),
                     "share": round(kern["knn_plane_kernel"]["total_ms"] / sum(k["total_ms"] for k in top.values()), 4),
                     "measured": "HIP events on the launch stream, this run"}
@@ -329,9 +347,9 @@ def main():
                     roofline["traffic_note"] = f"{os.path.relpath(PMC_FILE, ROOT)} was profiled on other kernel sources ({pmc.get('source_sha256')} vs {h_now}): traffic not reported"
                 elif pmc.get("bench_config", {}).get("pairs_per_gpu") == P:
                     tr = pmc.get("kernel_trace", {})
-                    if tr and "dominant_rocprof_kernel" in roofline:
+                    if tr and "kernel_detail" in roofline:
                         big = max(tr, key=lambda n: tr[n]["share"])
-                        roofline["dominant_rocprof_kernel"].update({"rocprofv3_name": big, "rocprofv3_avg_us": tr[big]["avg_us"],
+                        roofline["kernel_detail"].update({"rocprofv3_name": big, "rocprofv3_avg_us": tr[big]["avg_us"],
                                                                     "rocprofv3_share": tr[big]["share"],
                                                                     "rocprofv3_source": os.path.relpath(PMC_FILE, ROOT)})
                     # an event scope holds one dispatch of every kernel of that family (e.g. associate = kNN + fit,

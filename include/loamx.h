@@ -131,8 +131,12 @@ int loamx_ctx_synchronize(loamx_ctx* ctx);
 int loamx_ctx_extract_counters(loamx_ctx* ctx, uint64_t* tie_replays, uint64_t* scan_fallbacks);
 /* Debug / measurement switches of ONE context (no reference counterpart). loamx_ctx_create reads the environment
  * variables LOAMX_<NAME> once as the defaults (set = 1); no entry point looks at the environment afterwards, and a
- * switch only ever affects the context it was set on. None changes a result beyond the summation order of
- * NO_MOMENTS (and CHECK_FINITE, which only adds a refusal). Names — the complete list; DESIGN.md section 5 describes each:
+ * switch only ever affects the context it was set on. None changes a result beyond the order in which a pair's residual
+ * terms are summed: NO_MOMENTS / NO_REF_MOMENTS (records streamed instead of taken through the moment matrix) and NO_SMALL_SETS
+ * (the source edge features are then fed in Morton order instead of the given order: low bits of the pose, asserted by
+ * tests/test_gpu_multi.py) — and CHECK_FINITE, which only adds a refusal. For the same reason the default results of two
+ * RELEASES may differ in the low bits (far below the 1e-5 parity bar): round 5 began to feed the source edge features of a
+ * pair whose target edge set has at most 512 points in their given order. Names — the complete list; DESIGN.md section 5:
  *   extraction:    FORCE_TIE_REPLAY, FORCE_SCAN_GIVEUP, CURV_V1, NO_FUSED_COMPACT, NO_MIS_SELECT, NO_ROW_SELECT, FUSED_EXTRACT,
  *                  FUSED_ROWS, NO_SPLIT_CURV, STAGE_ALWAYS
  *   registration:  NO_MOMENTS, NO_REF_MOMENTS, NO_PACKED_GRID, NO_BIG_GRID, NO_GRID_SIDE, NO_EXTRACT_BOXES, NO_SMALL_SETS, DEBUG_POISON,

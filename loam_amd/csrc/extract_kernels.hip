@@ -1295,6 +1295,8 @@ bool launch_extract_split_ok(const ExtractParams& P, size_t n_scans) {
   RowSelGeom G;
   if (P.np != 3 || (P.W & 1u) || !row_select_geom(P, G) || G.ch != 11 || (n_scans * P.H) % 4 != 0) return false;
   if (!(P.edge_thr >= 0.0 && P.edge_thr <= 1.7976931348623157e308 && P.planar_thr >= 0.0 && P.planar_thr <= 1.7976931348623157e308)) return false;
+  // (-0.0 passes ">= 0.0", but its hi word is 0x80000000: compared as signed integers a +0.0 curvature would beat it)
+  if (__builtin_signbit(P.edge_thr) || __builtin_signbit(P.planar_thr)) return false;
   return true;
 }
 

@@ -444,6 +444,9 @@ int extract_dev(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_scans, con
                      d_planar_xyz, planar_capacity(P), ctx->stream, d_gave_up, d_events + 1);
   }
   CHECK_LAUNCH(ctx, "select_kernel");
+  // (the split curvature form is understood by select_rows_kernel alone: had launch_select refused it on a condition
+  // launch_extract_split_ok does not share, the other selection kernels would have read hi / lo words as doubles)
+  if (split && !rows_ran) return fail(ctx, LOAMX_ERR_UNSUPPORTED, "internal: split curvature form without the row selection");
   if (fused && rows_ran && boxes && fz.box_min) boxes->min = fz.box_min, boxes->max = fz.box_max, boxes->bad = d_gave_up;
   if (fused) return LOAMX_OK;
   {
@@ -1129,6 +1132,10 @@ static int register_features_impl(loamx_ctx* ctx, const loamx_target_index* inde
   if (index) {
     if (index->radius[0] != C.r_edge || index->radius[1] != C.r_plane)
       return fail(ctx, LOAMX_ERR_BAD_PARAM, "registration params do not match the ones the target index was built with");
+    // (an insert that failed between growing a set and rebuilding its grid leaves n ahead of the grid)
+    for (int k = 0; k < 2; k++)
+      if (index->n[k] != 0 && !index->grid_valid[k])
+        return fail(ctx, LOAMX_ERR_BAD_PARAM, "the target index is inconsistent (an insert into it failed): insert again or build a new one");
     n_te = 0, n_tp = 0;  // the target lives in the index
   }
   const size_t es = n_se > n_te ? n_se : n_te, ps = n_sp > n_tp ? n_sp : n_tp;
@@ -1248,6 +1255,8 @@ int loamx_knn_search(loamx_ctx* ctx, const loamx_target_index* index, int which_
   std::lock_guard<std::mutex> lock(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (which_set != 0 && which_set != 1) return fail(ctx, LOAMX_ERR_BAD_PARAM, "which_set: 0 = edge points, 1 = planar points");
+  if (index->n[which_set] != 0 && !index->grid_valid[which_set])
+    return fail(ctx, LOAMX_ERR_BAD_PARAM, "the target index is inconsistent (an insert into it failed): insert again or build a new one");
   if (n_queries == 0) return LOAMX_OK;
   if (!queries || !indices_out || !counts_out) return fail(ctx, LOAMX_ERR_BAD_PARAM, "null argument");
   if (k == 0) {
@@ -1603,8 +1612,11 @@ int loamx_register_features_batch_dev(loamx_ctx* ctx, size_t n_pairs, const doub
       rc = dev_check_finite(ctx, st.p, false, st.n, n_pairs, st.stride, 1);
       if (rc != LOAMX_OK) return rc;
     }
-    if (d_init) {
-      rc = dev_check_finite(ctx, d_init, false, nullptr, 1, (n_pairs * 7 + 2) / 3, 1);  // (7 doubles per pair; the kernel counts in points of 3)
+    if (d_init && n_pairs) {  // (7 doubles per pair, counted as scalars: the buffer need not end on a whole point)
+      rc = finite_begin(ctx);
+      if (rc != LOAMX_OK) return rc;
+      launch_check_finite_scalars(d_init, n_pairs * 7, static_cast<uint32_t*>(ctx->ws[WS_FINITE_FLAG].p), ctx->stream);
+      rc = finite_end(ctx);
       if (rc != LOAMX_OK) return rc;
     }
   }

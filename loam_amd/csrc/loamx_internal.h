@@ -313,6 +313,7 @@ void launch_assoc_dump(const RegBatch& B, const RegConfig& C, const AssocDumpSet
 // sets of `stride` points, `pitch` sets apart; d_n: points held by set i at d_n[i * pitch], or nullptr = all `stride`
 void launch_check_finite(const void* d_pts, bool f32, const uint32_t* d_n, size_t n_sets, size_t stride, uint32_t pitch, uint32_t* d_flag,
                          hipStream_t s);
+void launch_check_finite_scalars(const double* d_v, size_t n_scalars, uint32_t* d_flag, hipStream_t s);
 
 /* ---- synthetic generator (synth_kernels.hip) --------------------------------------------------- */
 void launch_synth_pairs(uint64_t seed, uint64_t first_pair, size_t n_pairs, uint32_t H, uint32_t W, double sigma,

@@ -1036,10 +1036,12 @@ __host__ __device__ inline bool queue_leftovers_coop(const RegConfig& C, bool pl
 #define LOAMX_COOP_WAVES 4
 #endif
 #ifndef LOAMX_REST_WAVES
-#define LOAMX_REST_WAVES 5  // measured (association scope): unconstrained (150 VGPRs, 3 waves/SIMD) 2.18 ms, 4 -> 2.12, 5 -> 2.11, 6 -> 2.14
+// (round 2 measured 4 -> 2.12 ms, 5 -> 2.11, 6 -> 2.14 of association scope on the one-stage form; since the two-stage chain every
+// instance settles at 3 wavefronts per SIMD (k <= 8) or 2 (k = 16) whatever is asked: the attribute now says what the compiler does)
+#define LOAMX_REST_WAVES(KM) ((KM) <= 8 ? 3 : 2)
 #endif
 template <bool PLANE, int KM, bool ONE_STAGE>
-__global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_rest_kernel(RegBatch B, RegConfig C,
+__global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES(KM)) void associate_knn_rest_kernel(RegBatch B, RegConfig C,
                                                                                               uint32_t blocks_per_pair) {
   constexpr bool one_stage = ONE_STAGE;  // (two instantiations: each at its own register budget)
   size_t pair;
@@ -1101,7 +1103,7 @@ __global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_
 // The listed queue entries (see above): the FP64 keyed collector — each candidate ONE double, the bits of d2 with the
 // low mantissa bits replaced by the position — over all rounds. What its keys cannot decide keeps its negative count.
 template <bool PLANE, int KM>
-__global__ __launch_bounds__(kRestThreads, LOAMX_REST_WAVES) void associate_knn_left_kernel(RegBatch B, RegConfig C,
+__global__ __launch_bounds__(kRestThreads, 5) void associate_knn_left_kernel(RegBatch B, RegConfig C,
                                                                                               uint32_t blocks_per_pair) {
   size_t pair;
   uint32_t chunk0;

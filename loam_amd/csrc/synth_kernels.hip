@@ -20,14 +20,16 @@ __global__ __launch_bounds__(256) void synth_kernel(uint64_t seed, uint64_t firs
 }
 // CHECK_FINITE (loamx.h: "Non-finite input"): does any of the first n[set * pitch] points of a set (stride points apart;
 // n == nullptr: every one of the `stride` points) hold a coordinate that is not finite? One flag word, set, never cleared.
+// `scalars` != 0: one flat array of that many numbers instead (an array that is not made of points: the initial poses).
 template <typename T>
 __global__ __launch_bounds__(256) void finite_kernel(const T* __restrict__ pts, const uint32_t* __restrict__ n, size_t stride, uint32_t pitch,
-                                                     uint32_t* __restrict__ flag) {
+                                                     uint32_t* __restrict__ flag, size_t scalars) {
   const size_t set = blockIdx.y;
   const size_t cnt = n ? (n[set * pitch] < stride ? n[set * pitch] : stride) : stride;
+  const size_t end = scalars ? scalars : cnt * 3;
   const T* __restrict__ p = pts + set * pitch * stride * 3;
   bool bad = false;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt * 3; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < end; i += (size_t)gridDim.x * blockDim.x) {
     const double v = (double)p[i];
     bad = bad || !(fabs(v) <= 1.7976931348623157e308);
   }
@@ -43,11 +45,17 @@ void launch_check_finite(const void* d_pts, bool f32, const uint32_t* d_n, size_
     const size_t ns = n_sets - s0 < 32768 ? n_sets - s0 : 32768;
     if (f32)
       hipLaunchKernelGGL(finite_kernel<float>, dim3(bx, (unsigned)ns), dim3(256), 0, s, static_cast<const float*>(d_pts) + s0 * pitch * stride * 3,
-                         d_n ? d_n + s0 * pitch : nullptr, stride, pitch, d_flag);
+                         d_n ? d_n + s0 * pitch : nullptr, stride, pitch, d_flag, (size_t)0);
     else
       hipLaunchKernelGGL(finite_kernel<double>, dim3(bx, (unsigned)ns), dim3(256), 0, s, static_cast<const double*>(d_pts) + s0 * pitch * stride * 3,
-                         d_n ? d_n + s0 * pitch : nullptr, stride, pitch, d_flag);
+                         d_n ? d_n + s0 * pitch : nullptr, stride, pitch, d_flag, (size_t)0);
   }
+}
+// exactly n_scalars doubles (nothing is rounded up to whole points: the caller's buffer ends there)
+void launch_check_finite_scalars(const double* d_v, size_t n_scalars, uint32_t* d_flag, hipStream_t s) {
+  if (n_scalars == 0) return;
+  const unsigned bx = (unsigned)((n_scalars + 255) / 256 < 64 ? (n_scalars + 255) / 256 : 64);
+  hipLaunchKernelGGL(finite_kernel<double>, dim3(bx, 1u), dim3(256), 0, s, d_v, static_cast<const uint32_t*>(nullptr), (size_t)0, 0u, d_flag, n_scalars);
 }
 
 void launch_synth_pairs(uint64_t seed, uint64_t first_pair, size_t n_pairs, uint32_t H, uint32_t W, double sigma,

@@ -132,3 +132,37 @@ def test_dev_entry_points_refuse_non_finite_input_when_asked_to_look(bad):
         d_res2.free()
     for b_ in (d_xyz, d_res, d_bad, d_ei, d_pi, d_ne, d_np, d_ex, d_px):
         b_.free()
+
+
+def test_initial_poses_are_checked_as_exactly_seven_numbers_per_pair():
+    """CHECK_FINITE once rounded n_pairs * 7 up to whole points and read up to two doubles past the caller's
+    buffer. One pair, the pose followed directly by two NaNs that are not part of it: accepted; a NaN inside it: refused."""
+    c = ctx()
+    Hs = 64
+    lidar, fe, reg = capi.LidarParams(Hs, W, 1.0, 120.0), capi.FeatureExtractionParams(), capi.RegistrationParams()
+    N = Hs * W
+    d_xyz = c.alloc(2 * N * 24)
+    c.synth_scan_pairs_dev(5, 41, 1, Hs, W, 0.01, d_xyz.ptr)
+    ecap, pcap = c.edge_capacity(lidar, fe), c.planar_capacity(lidar, fe)
+    d_ei, d_pi, d_ne, d_np = c.alloc(2 * ecap * 4), c.alloc(2 * pcap * 4), c.alloc(2 * 4), c.alloc(2 * 4)
+    d_ex, d_px = c.alloc(2 * ecap * 24), c.alloc(2 * pcap * 24)
+    c.extract_features_batch_dev(d_xyz.ptr, 2, lidar, fe, d_ei.ptr, d_ne.ptr, d_ex.ptr, d_pi.ptr, d_np.ptr, d_px.ptr)
+    c.synchronize()
+    d_res = c.alloc(64)
+    pose = np.array([0, 0, 0, 1, 0, 0, 0, np.nan, np.nan])
+    d_init = c.alloc(pose.nbytes).upload(pose)
+
+    def run():  # source = scan 1, target = scan 0 (sets one scan apart)
+        c.register_features_batch_dev(1, d_ex.ptr + ecap * 24, d_ne.ptr + 4, d_px.ptr + pcap * 24, d_np.ptr + 4, d_ex.ptr, d_ne.ptr, d_px.ptr, d_np.ptr,
+                                      ecap, pcap, d_init.ptr, reg, d_res.ptr)
+        c.synchronize()
+        return d_res.download(np.uint8, 64).copy()
+
+    plain = run()
+    with option("CHECK_FINITE"):
+        assert np.array_equal(run(), plain)
+        pose[6] = np.inf
+        d_init.upload(pose)
+        _refused(run)
+    for b_ in (d_xyz, d_ei, d_pi, d_ne, d_np, d_ex, d_px, d_res, d_init):
+        b_.free()
