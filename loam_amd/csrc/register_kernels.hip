@@ -1694,15 +1694,23 @@ __device__ __forceinline__ double light_eval(const RegBatch& B, size_t pair, con
       const double prim[6] = {s_frec[3][e], s_frec[4][e], s_frec[5][e], s_frec[6][e], 0.0, 0.0};
       residual_accumulate(true, v3(s_frec[0][e], s_frec[1][e], s_frec[2][e]), prim, x, acc);
     }
-  } else
-  for (uint32_t lb = 0; lb < B.mom_blocks_per_pair * 4 && (lb / 4) * kSweepChunk < n_sp; lb++) {
-    const uint32_t cnt = lb < kListCache ? s_listed[lb] : B.flagged_count[pair * B.mom_blocks_per_pair * 4 + lb];
-    if (cnt == 0u) continue;  // (uniform)
-    const uint32_t* __restrict__ fl = B.flagged_list + (pair * B.mom_blocks_per_pair * 4 + lb) * (size_t)(kSweepChunk / 4);
-    for (uint32_t k = lane; k < cnt; k += 64) {
-      const uint32_t q = fl[k];
-      const double prim[6] = {Pl[3 * pfield + q], Pl[4 * pfield + q], Pl[5 * pfield + q], Pl[6 * pfield + q], 0.0, 0.0};
-      residual_accumulate(true, v3(Pl[q], Pl[pfield + q], Pl[2 * pfield + q]), prim, x, acc);
+  } else {
+    // Tile by tile, but every record on the lane — and in the per-lane order — the flat list gives it: entry e of the pair's
+    // concatenated lists belongs to lane e % 64. (Round 6: each tile used to start at lane 0 again. Which of the two walks a pair
+    // takes depends on the slot capacity of the call — more than kListCache tiles when a scan is registered against a map
+    // through the plain entry point, fewer through a persistent index — so the two gave sums that differed in the last bit for
+    // some inputs: tools/debug_c5.py, seeds 6 and 7 of config 5; the seed of tests/test_gpu_multi.py happened to agree.)
+    uint32_t off = 0;  // uniform
+    for (uint32_t lb = 0; lb < B.mom_blocks_per_pair * 4 && (lb / 4) * kSweepChunk < n_sp; lb++) {
+      const uint32_t cnt = lb < kListCache ? s_listed[lb] : B.flagged_count[pair * B.mom_blocks_per_pair * 4 + lb];
+      if (cnt == 0u) continue;  // (uniform)
+      const uint32_t* __restrict__ fl = B.flagged_list + (pair * B.mom_blocks_per_pair * 4 + lb) * (size_t)(kSweepChunk / 4);
+      for (uint32_t k = ((uint32_t)lane + 64u - (off & 63u)) & 63u; k < cnt; k += 64) {
+        const uint32_t q = fl[k];
+        const double prim[6] = {Pl[3 * pfield + q], Pl[4 * pfield + q], Pl[5 * pfield + q], Pl[6 * pfield + q], 0.0, 0.0};
+        residual_accumulate(true, v3(Pl[q], Pl[pfield + q], Pl[2 * pfield + q]), prim, x, acc);
+      }
+      off += cnt;
     }
   }
   // every lane ends up with the wavefront's sums (xor butterfly: the same value in every lane, fixed order)
