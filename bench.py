@@ -22,6 +22,9 @@ Prints ONE JSON line on rank 0 (contract in the task description) with extra obj
                  roofline of the (instruction-bound) k-NN kernel from the committed PMC pass
   cpu_baseline — the CPU oracle (oracle/, a port of the reference path) timed on this host's cores
                  on a bounded sample of the same pairs (rank 0, N=1 only): all threads + one thread
+  extra        — streamed: the same pairs from PINNED HOST memory to host results (loamx_register_scan_pairs: chunked uploads on
+                 a copy stream under the kernels), double and float scans: pairs/s and the PCIe rate reached, + the latency of
+                 one pair from host buffers. Never `value`: the headline is device-resident
   ranks        — (N > 1) what RCCL reported: communicator size, the gathered rank ids and devices
 """
 import argparse
@@ -67,6 +70,9 @@ def parse_args():
                     help="scalar type of the resident scans: f64 (the headline workload) or f32 (SURVEY 8f4: sensor data as "
                          "floats, widened on load; arithmetic stays FP64)")
     ap.add_argument("--seed", type=int, default=SEED, help="seed of the synthetic scan pairs (default: the benchmark's)")
+    ap.add_argument("--no-streamed", action="store_true",
+                    help="skip the host-memory figure (extra.streamed: loamx_register_scan_pairs from pinned host scans, N = 1 only)")
+    ap.add_argument("--streamed-pairs", type=int, default=512, help="pairs per call of the streamed figure (pinned host copy: 3.1 MB per pair)")
     return ap.parse_args()
 
 
@@ -128,6 +134,47 @@ def cpu_baseline(scans, pairs, threads):
         with ThreadPoolExecutor(max_workers=threads) as ex:
             out = list(ex.map(one, pairs))
     return out, time.perf_counter() - t0
+
+
+def streamed_figure(ctx, capi, xyz, n, lidar, fe, reg, f32_resident, dev_results):
+    """Host scans in, host results out through loamx_register_scan_pairs: the first n pairs of the batch, pinned, as doubles
+    and as floats. PCIe-bound by construction (3.1 MB per pair against ~10 us of kernels)."""
+    import numpy as np
+    import torch
+    N = H * W
+    out = {"entry_point": "loamx_register_scan_pairs / _f32 (chunks of 128 pairs, double-buffered hipMemcpyAsync on a copy stream under the kernels)",
+           "pairs_per_call": n, "host_memory": "pinned (torch pin_memory)"}
+    src = xyz[: n * 2 * N * 3]
+    for name, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        if name == "f64" and f32_resident:
+            continue  # (the resident batch was rounded to float: no double scans to stream)
+        host = torch.empty(n * 2 * N * 3, dtype=dt, pin_memory=True)
+        host.copy_(src.to(dt).cpu())
+        arr = host.numpy()
+        res = np.zeros(n, dtype=capi.RESULT_DTYPE)
+        ctx.register_scan_pairs(arr, n, lidar, fe, reg, out=res)  # warm-up: staging buffers, workspace
+        steps = 3
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.register_scan_pairs(arr, n, lidar, fe, reg, out=res)
+        dt_s = (time.perf_counter() - t0) / steps
+        entry = {"pairs_per_s": round(n / dt_s, 1), "ms_per_call": round(dt_s * 1e3, 3),
+                 "pcie_GBs": round(arr.nbytes / dt_s / 1e9, 2), "bytes_per_pair": arr.nbytes // n}
+        if name == "f64" and not f32_resident:
+            entry["bit_identical_to_device_resident_results"] = bool(np.array_equal(res.view(np.uint8), dev_results[:n].view(np.uint8)))
+        out[name] = entry
+        if name == ("f32" if f32_resident else "f64"):  # one pair from host buffers: latency of the reference's own unit of use
+            one = np.zeros(1, dtype=capi.RESULT_DTYPE)
+            first = arr[: 2 * N * 3]
+            for _ in range(5):
+                ctx.register_scan_pairs(first, 1, lidar, fe, reg, out=one)
+            K = 50
+            t0 = time.perf_counter()
+            for _ in range(K):
+                ctx.register_scan_pairs(first, 1, lidar, fe, reg, out=one)
+            out["one_pair_gpu_host_buffers_ms"] = round((time.perf_counter() - t0) / K * 1e3, 3)
+        del host
+    return out
 
 
 def main():
@@ -421,6 +468,12 @@ def main():
             out["parity"] = {"pairs_checked": n_sample, "se3_max_rot_err_rad": max_rot, "se3_max_trans_err_m": max_trans,
                              "tolerance": 1e-5, "termination_and_iterations_equal": bool(term_equal),
                              "feature_index_sequences_equal": idx_equal}
+        # ---- the streamed figure (outside the headline: SURVEY 8d prices inputs resident in HBM) -------------
+        if n_gpus == 1 and not args.no_streamed:
+            try:
+                out["extra"] = {"streamed": streamed_figure(ctx, capi, xyz, min(P, max(1, args.streamed_pairs)), lidar, fe, reg, f32, res)}
+            except Exception as e:  # (e.g. no room for the pinned copy on this host)
+                out["extra"] = {"streamed": {"error": f"{type(e).__name__}: {e}"}}
         print(json.dumps(out), flush=True)
 
     if comm is not None:

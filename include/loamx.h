@@ -141,6 +141,7 @@ int loamx_ctx_extract_counters(loamx_ctx* ctx, uint64_t* tie_replays, uint64_t* 
  *                  FUSED_ROWS, NO_SPLIT_CURV, STAGE_ALWAYS
  *   registration:  NO_MOMENTS, NO_REF_MOMENTS, NO_PACKED_GRID, NO_BIG_GRID, NO_GRID_SIDE, NO_EXTRACT_BOXES, NO_SMALL_SETS, DEBUG_POISON,
  *                  QUEUE_TWO_STAGE, QUEUE_ONE_STAGE, NO_COOP_LEFT, NO_MIXED_ASSOC, MAP_CELLS_LOG2 (a number: 0 = default)
+ *   host streaming: STREAM_CHUNK_PAIRS (a number: pairs per uploaded chunk of loamx_register_scan_pairs; 0 = default, 128)
  *   multi-GPU:     FORCE_RCCL (a one-rank communicator really enqueues the RCCL collectives)
  *   input checks:  CHECK_FINITE (see "Non-finite input" below)
  * Unknown name: LOAMX_ERR_BAD_PARAM.
@@ -148,7 +149,7 @@ int loamx_ctx_extract_counters(loamx_ctx* ctx, uint64_t* tie_replays, uint64_t* 
  * Non-finite input. The reference is undefined on NaN / Inf coordinates (loam/include/loam/features-inl.h:38 sorts on
  * curvatures computed from them; a NaN range passes every comparison of loam/src/features.cpp:30-68; nanoflann and Ceres
  * receive them as they are). Here: every HOST entry point (loamx_compute_curvature / _valid_points, loamx_extract_features,
- * loamx_register_features / _indexed, loamx_associate, loamx_fit_lines / _planes, loamx_knn_search, loamx_target_index_create /
+ * loamx_register_features / _indexed, loamx_register_scan_pairs, loamx_associate, loamx_fit_lines / _planes, loamx_knn_search, loamx_target_index_create /
  * _insert, and their _f32 forms) refuses such input with LOAMX_ERR_BAD_PARAM: its uploaded copy is looked at by one small
  * kernel before anything else is launched (a 4-byte read-back, one extra stream synchronisation; an index is left as it was). The "_dev" entry points (loamx_extract_features_batch_dev, loamx_register_features_batch_dev,
  * loamx_register_scan_pairs_dev, and their _f32 forms) do not look unless the context option CHECK_FINITE is set: then one
@@ -300,6 +301,18 @@ int loamx_register_features_batch_dev(loamx_ctx* ctx, size_t n_pairs, const doub
 int loamx_register_scan_pairs_dev(loamx_ctx* ctx, const double* d_xyz, size_t n_pairs,
                                   const loamx_lidar_params* lidar, const loamx_fe_params* fe,
                                   const loamx_reg_params* reg, loamx_reg_result* d_results);
+
+/* The same unit from HOST memory to host memory — the reference's own unit of use (README.md:44-60: a scan pair in host
+ * memory in, a pose out). The batch is cut into chunks of `STREAM_CHUNK_PAIRS` pairs (context option, a number; 0 = the
+ * default, 128); chunk k + 1 travels to the device on a copy stream (hipMemcpyAsync into the second of two staging buffers)
+ * while chunk k is registered through loamx_register_scan_pairs_dev's own path; the 64-byte results come back in one copy at
+ * the end. Results are bit-identical to the "_dev" entry point's. For the upload to overlap the kernels `xyz` must be pinned
+ * (hipHostMalloc / hipHostRegister); pageable memory works, one chunk at a time. Throughput is PCIe's: 3.1 MB of FP64 scans
+ * per pair (1.6 MB as floats) against ~10 us of kernels. Non-finite input is refused (LOAMX_ERR_BAD_PARAM) chunk by chunk. */
+int loamx_register_scan_pairs(loamx_ctx* ctx, const double* xyz, size_t n_pairs, const loamx_lidar_params* lidar,
+                              const loamx_fe_params* fe, const loamx_reg_params* reg, loamx_reg_result* results);
+int loamx_register_scan_pairs_f32(loamx_ctx* ctx, const float* xyz, size_t n_pairs, const loamx_lidar_params* lidar,
+                                  const loamx_fe_params* fe, const loamx_reg_params* reg, loamx_reg_result* results);
 
 /* the same over float scans */
 int loamx_register_scan_pairs_dev_f32(loamx_ctx* ctx, const float* d_xyz, size_t n_pairs,

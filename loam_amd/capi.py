@@ -83,7 +83,8 @@ EXPORTS = [
     "loamx_compute_curvature", "loamx_compute_valid_points", "loamx_extract_features", "loamx_register_features",
     "loamx_target_index_create", "loamx_target_index_destroy", "loamx_register_features_indexed",
     "loamx_edge_capacity", "loamx_planar_capacity", "loamx_extract_features_batch_dev",
-    "loamx_register_features_batch_dev", "loamx_register_scan_pairs_dev", "loamx_ctx_enable_kernel_timing",
+    "loamx_register_features_batch_dev", "loamx_register_scan_pairs_dev", "loamx_register_scan_pairs",
+    "loamx_register_scan_pairs_f32", "loamx_ctx_enable_kernel_timing",
     "loamx_ctx_reset_kernel_stats", "loamx_ctx_get_kernel_stats", "loamx_kernel_name", "loamx_synth_pair_pose",
     "loamx_synth_scan_host", "loamx_synth_scan_pairs_dev", "loamx_dev_alloc", "loamx_dev_free",
     "loamx_copy_to_device", "loamx_copy_to_host",
@@ -159,6 +160,8 @@ def load(build_if_missing=True):
                                                   C.POINTER(FeatureExtractionParams), C.POINTER(RegistrationParams),
                                                   vp]
     lib.loamx_register_scan_pairs_dev_f32.argtypes = lib.loamx_register_scan_pairs_dev.argtypes
+    lib.loamx_register_scan_pairs.argtypes = lib.loamx_register_scan_pairs_dev.argtypes  # (host pointers)
+    lib.loamx_register_scan_pairs_f32.argtypes = lib.loamx_register_scan_pairs_dev.argtypes
     lib.loamx_ctx_enable_kernel_timing.argtypes = [vp, C.c_int]
     lib.loamx_ctx_reset_kernel_stats.argtypes = [vp]
     lib.loamx_ctx_get_kernel_stats.argtypes = [vp, C.POINTER(KernelStat)]
@@ -538,6 +541,22 @@ class Context:
     def register_scan_pairs_dev(self, d_xyz, n_pairs, lidar, fe, reg, d_results, f32=False):
         fn = self.lib.loamx_register_scan_pairs_dev_f32 if f32 else self.lib.loamx_register_scan_pairs_dev
         self._check(fn(self.h, d_xyz, n_pairs, C.byref(lidar), C.byref(fe), C.byref(reg), d_results))
+
+    def register_scan_pairs(self, xyz, n_pairs, lidar, fe=None, reg=None, out=None):
+        """Host memory in, host memory out (loamx_register_scan_pairs): xyz = a C-contiguous float64 / float32 array (or an
+        integer address + dtype via `xyz=(ptr, np.float32)`) of n_pairs x 2 scans, target scan first; returns the result
+        records (RESULT_DTYPE). Pinned memory (e.g. a torch pin_memory tensor's numpy view) lets the uploads overlap."""
+        fe, reg = fe or FeatureExtractionParams(), reg or RegistrationParams()
+        if isinstance(xyz, tuple):
+            ptr, dt = xyz
+            f32 = np.dtype(dt) == np.float32
+        else:
+            assert xyz.flags["C_CONTIGUOUS"] and xyz.dtype in (np.float64, np.float32)
+            ptr, f32 = xyz.ctypes.data, xyz.dtype == np.float32
+        res = out if out is not None else np.zeros(n_pairs, dtype=RESULT_DTYPE)
+        fn = self.lib.loamx_register_scan_pairs_f32 if f32 else self.lib.loamx_register_scan_pairs
+        self._check(fn(self.h, ptr, n_pairs, C.byref(lidar), C.byref(fe), C.byref(reg), res.ctypes.data))
+        return res
 
     def synth_scan_pairs_dev(self, seed, first_pair, n_pairs, scan_lines, points_per_line, sigma, d_xyz):
         self._check(self.lib.loamx_synth_scan_pairs_dev(self.h, seed, first_pair, n_pairs, scan_lines,

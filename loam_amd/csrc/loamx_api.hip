@@ -26,7 +26,7 @@ enum WsId {
   WS_EDGE_IDX, WS_PLANAR_IDX, WS_N_EDGE, WS_N_PLANAR, WS_EDGE_XYZ, WS_PLANAR_XYZ,
   WS_GRID_DESC_E, WS_GRID_DESC_P, WS_CELLS_E, WS_CELLS_P, WS_SORTED_E, WS_SORTED_P, WS_REL_E, WS_REL_P,
   WS_SGRID_DESC_E, WS_SGRID_DESC_P, WS_SCELLS_E, WS_SCELLS_P, WS_SSORTED_E, WS_SSORTED_P, WS_SORT_SCRATCH, WS_SORT_SCRATCH_SRC, WS_ASSOC_E, WS_ASSOC_P, WS_NN_E, WS_NN_P, WS_RNN_E, WS_RNN_P, WS_NEAREST_E, WS_NEAREST_P, WS_REST_E, WS_REST_P, WS_EXACT_E, WS_EXACT_P, WS_NASSOC, WS_STATE, WS_PARTIALS, WS_MOM_PARTIALS, WS_MOMENTS, WS_FLAGGED_LIST, WS_FLAGGED_COUNT, WS_LINE_TOT, WS_EXTRACT_EVENTS, WS_BOX, WS_FINITE_FLAG,
-  WS_COUNTERS, WS_ITERINFO, WS_DUMP_E, WS_DUMP_P, WS_FIT_IN, WS_FIT_OUT, WS_SRC_E, WS_SRC_P, WS_TGT_E, WS_TGT_P, WS_FCOUNTS, WS_RESULTS, WS_INIT,
+  WS_COUNTERS, WS_ITERINFO, WS_STREAM_IN0, WS_STREAM_IN1, WS_STREAM_RES, WS_DUMP_E, WS_DUMP_P, WS_FIT_IN, WS_FIT_OUT, WS_SRC_E, WS_SRC_P, WS_TGT_E, WS_TGT_P, WS_FCOUNTS, WS_RESULTS, WS_INIT,
   WS_COUNT
 };
 
@@ -67,6 +67,9 @@ struct loamx_ctx {
   uint32_t extract_flags = 0;  // kFlag* of extract_math.h
   uint32_t reg_flags = 0;      // kRegFlag* of loamx_internal.h
   int map_cells_log2 = 0;      // cell table of a map-sized persistent index (0: kGridMapCellsCap)
+  int stream_chunk_pairs = 0;  // pairs per uploaded chunk of loamx_register_scan_pairs (0: kStreamChunkPairs)
+  hipStream_t copy_stream = nullptr;  // uploads of loamx_register_scan_pairs (created on first use)
+  hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
 
   unsigned long long sweep_slots_base[2] = {0, 0};
   unsigned long long features_base = 0;  // events[2] at the last loamx_ctx_reset_kernel_stats
@@ -846,6 +849,7 @@ int loamx_ctx_create(int device, loamx_ctx** out) {
   for (const OptionName& o : kOptionNames)
     if (getenv((std::string("LOAMX_") + o.name).c_str())) (o.extract ? ctx->extract_flags : ctx->reg_flags) |= o.bit;
   if (const char* mc = getenv("LOAMX_MAP_CELLS_LOG2")) ctx->map_cells_log2 = atoi(mc);
+  if (const char* sc = getenv("LOAMX_STREAM_CHUNK_PAIRS")) ctx->stream_chunk_pairs = atoi(sc) > 0 ? atoi(sc) : 0;
   // optional: without the auxiliary stream the edge and plane association chains simply run in sequence
   // The auxiliary streams carry the small, latency-bound kernels next to the big ones of the main stream. Round 1 gave
   // them the highest priority (their workgroups dispatched as soon as they are ready: association 2.61 -> 2.57 ms then);
@@ -894,6 +898,14 @@ void loamx_ctx_destroy(loamx_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->aux2_stream);
     (void)hipStreamDestroy(ctx->aux2_stream);
   }
+  if (ctx->copy_stream) {
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamDestroy(ctx->copy_stream);
+  }
+  for (int b = 0; b < 2; b++) {
+    if (ctx->ev_up[b]) (void)hipEventDestroy(ctx->ev_up[b]);
+    if (ctx->ev_free[b]) (void)hipEventDestroy(ctx->ev_free[b]);
+  }
   if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
   if (ctx->ev_counts) (void)hipEventDestroy(ctx->ev_counts);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -926,6 +938,11 @@ int loamx_ctx_set_option(loamx_ctx* ctx, const char* name, int value) {
     ctx->map_cells_log2 = value;
     return LOAMX_OK;
   }
+  if (!strcmp(name, "STREAM_CHUNK_PAIRS")) {
+    if (value < 0) return fail(ctx, LOAMX_ERR_BAD_PARAM, "STREAM_CHUNK_PAIRS: a number of pairs (0 = default)");
+    ctx->stream_chunk_pairs = value;
+    return LOAMX_OK;
+  }
   for (const OptionName& o : kOptionNames)
     if (!strcmp(name, o.name)) {
       uint32_t& w = o.extract ? ctx->extract_flags : ctx->reg_flags;
@@ -940,6 +957,10 @@ int loamx_ctx_get_option(loamx_ctx* ctx, const char* name, int* value) {
   std::lock_guard<std::mutex> lock(ctx->mu);
   if (!strcmp(name, "MAP_CELLS_LOG2")) {
     *value = ctx->map_cells_log2;
+    return LOAMX_OK;
+  }
+  if (!strcmp(name, "STREAM_CHUNK_PAIRS")) {
+    *value = ctx->stream_chunk_pairs;
     return LOAMX_OK;
   }
   for (const OptionName& o : kOptionNames)
@@ -1623,11 +1644,9 @@ int loamx_register_features_batch_dev(loamx_ctx* ctx, size_t n_pairs, const doub
   return register_dev(ctx, in, C, d_results, false, nullptr, nullptr);
 }
 
-static int register_scan_pairs(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_pairs, const loamx_lidar_params* lidar,
-                               const loamx_fe_params* fe, const loamx_reg_params* reg, loamx_reg_result* d_results) {
-  if (!ctx) return LOAMX_ERR_BAD_PARAM;
-  std::lock_guard<std::mutex> lock(ctx->mu);
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+// (the caller holds ctx->mu and has selected the device; `look` = refuse non-finite input whatever CHECK_FINITE says)
+static int register_scan_pairs_locked(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_pairs, const loamx_lidar_params* lidar,
+                                      const loamx_fe_params* fe, const loamx_reg_params* reg, loamx_reg_result* d_results, bool look = false) {
   ExtractParams P;
   int rc = make_extract_params(ctx, lidar, fe, P);
   if (rc != LOAMX_OK) return rc;
@@ -1636,7 +1655,7 @@ static int register_scan_pairs(loamx_ctx* ctx, const void* d_xyz, bool f32, size
   if (rc != LOAMX_OK) return rc;
   if (n_pairs == 0) return LOAMX_OK;
   const size_t n_scans = 2 * n_pairs, ecap = edge_capacity(P), pcap = planar_capacity(P);
-  rc = dev_check_finite(ctx, d_xyz, f32, nullptr, n_scans, (size_t)P.H * P.W, 1);
+  rc = dev_check_finite(ctx, d_xyz, f32, nullptr, n_scans, (size_t)P.H * P.W, 1, look);
   if (rc != LOAMX_OK) return rc;
   ENSURE(ctx, WS_N_EDGE, n_scans * sizeof(uint32_t));
   ENSURE(ctx, WS_N_PLANAR, n_scans * sizeof(uint32_t));
@@ -1657,6 +1676,90 @@ static int register_scan_pairs(loamx_ctx* ctx, const void* d_xyz, bool f32, size
   in.n_tgt_planar = wsp<uint32_t>(ctx, WS_N_PLANAR), in.n_src_planar = in.n_tgt_planar + 1;
   in.init = nullptr;
   return register_dev(ctx, in, C, d_results, false, nullptr, nullptr);
+}
+static int register_scan_pairs(loamx_ctx* ctx, const void* d_xyz, bool f32, size_t n_pairs, const loamx_lidar_params* lidar,
+                               const loamx_fe_params* fe, const loamx_reg_params* reg, loamx_reg_result* d_results) {
+  if (!ctx) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return register_scan_pairs_locked(ctx, d_xyz, f32, n_pairs, lidar, fe, reg, d_results);
+}
+
+// Host memory in, host memory out (loamx.h: loamx_register_scan_pairs): chunk k + 1 is uploaded on the copy stream into the
+// other staging buffer while chunk k goes through register_scan_pairs_locked — the host blocks inside that call (its two
+// read-backs), so the next upload is enqueued BEFORE it; a buffer is refilled once the chunk that read it has finished.
+constexpr size_t kStreamChunkPairs = 128;
+static int register_scan_pairs_host(loamx_ctx* ctx, const void* xyz, bool f32, size_t n_pairs, const loamx_lidar_params* lidar,
+                                    const loamx_fe_params* fe, const loamx_reg_params* reg, loamx_reg_result* results) {
+  if (!ctx) return LOAMX_ERR_BAD_PARAM;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  {  // (parameter errors before anything moves)
+    ExtractParams P;
+    int rc = make_extract_params(ctx, lidar, fe, P);
+    if (rc != LOAMX_OK) return rc;
+    RegConfig C;
+    rc = make_reg_config(ctx, reg, C);
+    if (rc != LOAMX_OK) return rc;
+  }
+  if (n_pairs == 0) return LOAMX_OK;
+  if (!xyz || !results) return fail(ctx, LOAMX_ERR_BAD_PARAM, "null argument");
+  const size_t pair_bytes = 2 * (size_t)lidar->scan_lines * lidar->points_per_line * 3 * (f32 ? sizeof(float) : sizeof(double));
+  size_t chunk = ctx->stream_chunk_pairs > 0 ? (size_t)ctx->stream_chunk_pairs : kStreamChunkPairs;
+  chunk = chunk < n_pairs ? chunk : n_pairs;
+  const size_t n_chunks = (n_pairs + chunk - 1) / chunk;
+  untimed(ctx);
+  ENSURE(ctx, WS_STREAM_IN0, chunk * pair_bytes);
+  if (n_chunks > 1) ENSURE(ctx, WS_STREAM_IN1, chunk * pair_bytes);
+  ENSURE(ctx, WS_STREAM_RES, n_pairs * sizeof(loamx_reg_result));
+  if (!ctx->copy_stream) {
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; b++) {
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_up[b], hipEventDisableTiming));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_free[b], hipEventDisableTiming));
+    }
+  }
+  unsigned char* in[2] = {wsp<unsigned char>(ctx, WS_STREAM_IN0), n_chunks > 1 ? wsp<unsigned char>(ctx, WS_STREAM_IN1) : nullptr};
+  loamx_reg_result* d_res = wsp<loamx_reg_result>(ctx, WS_STREAM_RES);
+  const unsigned char* host = static_cast<const unsigned char*>(xyz);
+  auto pairs_of = [&](size_t k) { return k + 1 < n_chunks ? chunk : n_pairs - k * chunk; };
+  auto upload = [&](size_t k) -> hipError_t {
+    const int b = (int)(k & 1);
+    hipError_t e = hipSuccess;
+    if (k >= 2) e = hipStreamWaitEvent(ctx->copy_stream, ctx->ev_free[b], 0);  // (the chunk that read this buffer is done)
+    if (e == hipSuccess) e = hipMemcpyAsync(in[b], host + k * chunk * pair_bytes, pairs_of(k) * pair_bytes, hipMemcpyHostToDevice, ctx->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev_up[b], ctx->copy_stream);
+    return e;
+  };
+  // (whatever earlier calls left on the context's stream may still read the staging buffers' neighbours: nothing to wait for,
+  // the buffers are this entry point's own — but a previous call of THIS entry point has synchronised before it returned)
+  HIP_TRY(ctx, upload(0));
+  int rc = LOAMX_OK;
+  for (size_t k = 0; k < n_chunks && rc == LOAMX_OK; k++) {
+    const int b = (int)(k & 1);
+    if (k + 1 < n_chunks) HIP_TRY(ctx, upload(k + 1));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_up[b], 0));
+    rc = register_scan_pairs_locked(ctx, in[b], f32, pairs_of(k), lidar, fe, reg, d_res + k * chunk, true);
+    untimed(ctx);
+    if (rc == LOAMX_OK) HIP_TRY(ctx, hipEventRecord(ctx->ev_free[b], ctx->stream));
+  }
+  if (rc != LOAMX_OK) {  // (uploads in flight must not outlive the caller's buffer)
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    return rc;
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(results, d_res, n_pairs * sizeof(loamx_reg_result), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return LOAMX_OK;
+}
+
+int loamx_register_scan_pairs(loamx_ctx* ctx, const double* xyz, size_t n_pairs, const loamx_lidar_params* lidar,
+                              const loamx_fe_params* fe, const loamx_reg_params* reg, loamx_reg_result* results) {
+  return register_scan_pairs_host(ctx, xyz, false, n_pairs, lidar, fe, reg, results);
+}
+int loamx_register_scan_pairs_f32(loamx_ctx* ctx, const float* xyz, size_t n_pairs, const loamx_lidar_params* lidar,
+                                  const loamx_fe_params* fe, const loamx_reg_params* reg, loamx_reg_result* results) {
+  return register_scan_pairs_host(ctx, xyz, true, n_pairs, lidar, fe, reg, results);
 }
 
 int loamx_register_scan_pairs_dev(loamx_ctx* ctx, const double* d_xyz, size_t n_pairs, const loamx_lidar_params* lidar,

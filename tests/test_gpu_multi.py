@@ -314,3 +314,39 @@ def test_config5_scan_against_a_million_point_map(oracle):
     rot, trans = pose_diff(oracle, po, np.asarray(pose))
     assert rot < 1e-5 and trans < 1e-5, (rot, trans)
     print("config 5: %d map points, %d ICF iterations, SE(3) difference %.1e rad %.1e m" % (len(map_p), iters, rot, trans))
+
+
+def test_scan_pairs_from_host_memory_equal_the_device_resident_call():
+    """Round 6: loamx_register_scan_pairs — host scans in, host results out, chunks uploaded under the
+    registration of the chunk before. Same bits as loamx_register_scan_pairs_dev whatever the chunking (uneven last chunk, one
+    chunk, a chunk per pair), for double and float scans; non-finite input is refused; an empty batch is a no-op."""
+    c = ctx()
+    P = 20
+    lidar = capi.LidarParams(H, W, 1.0, 120.0)
+    d_xyz, d_res = c.alloc(P * 2 * N * 24), c.alloc(P * 64)
+    c.synth_scan_pairs_dev(SEED, 300, P, H, W, 0.01, d_xyz.ptr)
+    want = _run(c, d_xyz.ptr, P, d_res).view(capi.RESULT_DTYPE)
+    host = d_xyz.download(np.float64, P * 2 * N * 3).copy()
+    for chunk in (7, 0, 1):
+        with option("STREAM_CHUNK_PAIRS", chunk):
+            got = c.register_scan_pairs(host, P, lidar)
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), chunk
+    # float scans: the same as the device-resident float call on the same rounded scans
+    host32 = host.astype(np.float32)
+    d_x32 = c.alloc(host32.nbytes).upload(host32)
+    c.register_scan_pairs_dev(d_x32.ptr, P, lidar, capi.FeatureExtractionParams(), capi.RegistrationParams(), d_res.ptr, f32=True)
+    c.synchronize()
+    want32 = d_res.download(np.uint8, P * 64).copy()
+    with option("STREAM_CHUNK_PAIRS", 6):
+        got32 = c.register_scan_pairs(host32, P, lidar)
+    assert np.array_equal(got32.view(np.uint8), want32)
+    assert len(c.register_scan_pairs(host, 0, lidar)) == 0
+    dirty = host.copy()
+    dirty[(2 * 13 + 1) * N * 3 + 5] = np.nan  # the source scan of pair 13: third chunk of seven
+    with option("STREAM_CHUNK_PAIRS", 5), pytest.raises(capi.LoamxError) as e:
+        c.register_scan_pairs(dirty, P, lidar)
+    assert e.value.status == capi.ERR_BAD_PARAM and "non-finite" in str(e.value)
+    again = c.register_scan_pairs(host, P, lidar)  # the context is as good as before
+    assert np.array_equal(again.view(np.uint8), want.view(np.uint8))
+    for b_ in (d_xyz, d_res, d_x32):
+        b_.free()
