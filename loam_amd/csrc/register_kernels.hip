@@ -1924,12 +1924,24 @@ __global__ __launch_bounds__(64) void lm_pair_loop_kernel(RegBatch B, RegConfig 
   __shared__ uint32_t s_listed[kListCache], s_pref[kListCache];
   const int lane = threadIdx.x;
   const size_t pair = blockIdx.x;
-  PairState& S = B.state[pair];
-  if (!S.active) return;  // uniform
-  if (!S.lm.active) {     // (uniform; lm_begin_kernel starts every active pair's solve, so this does not happen)
-    if (lane == 0) outer_update_pair(B, C, pair, S);
+  PairState& S_global = B.state[pair];
+  if (!S_global.active) return;  // uniform
+  if (!S_global.lm.active) {     // (uniform; lm_begin_kernel starts every active pair's solve, so this does not happen)
+    if (lane == 0) outer_update_pair(B, C, pair, S_global);
     return;
   }
+  // Round 6: the pair's state lives in LDS for the length of the solve. Every bookkeeping step read and wrote the 700-byte
+  // PairState in global memory through lane 0 alone, and the other lanes fetched the next candidate from there: dependent
+  // round trips on the one wavefront's critical path, five times per launch.
+  __shared__ PairState s_S;
+  static_assert(sizeof(PairState) % 8 == 0, "copied as 64-bit words");
+  {
+    const unsigned long long* __restrict__ src = reinterpret_cast<const unsigned long long*>(&S_global);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&s_S);
+    for (int w = lane; w < (int)(sizeof(PairState) / 8); w += 64) dst[w] = src[w];
+  }
+  wave_lds_fence();
+  PairState& S = s_S;
   const uint32_t n_se_raw = B.n_src_edge[pair * B.in_pitch], n_sp_raw = B.n_src_planar[pair * B.in_pitch];
   const uint32_t n_se = n_se_raw < B.edge_stride ? n_se_raw : (uint32_t)B.edge_stride;
   const uint32_t n_sp = n_sp_raw < B.planar_stride ? n_sp_raw : (uint32_t)B.planar_stride;
@@ -2040,6 +2052,12 @@ __global__ __launch_bounds__(64) void lm_pair_loop_kernel(RegBatch B, RegConfig 
   }
   // ---- the outer step of the ICF iteration (what outer_update_kernel does after the first iteration's solve)
   if (lane == 0) outer_update_pair(B, C, pair, S);
+  wave_lds_fence();
+  {
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&s_S);
+    unsigned long long* __restrict__ dst = reinterpret_cast<unsigned long long*>(&S_global);
+    for (int w = lane; w < (int)(sizeof(PairState) / 8); w += 64) dst[w] = src[w];
+  }
 }
 
 /* ------------------------------------------------------------------------------------------------
