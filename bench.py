@@ -289,19 +289,6 @@ def main():
         stats = ctx.kernel_stats()
         ctx.enable_kernel_timing(False)
 
-    # the selection's algorithmic bytes include the picks' coordinates (24 B read + 24 B written per feature: the copies the
-    # reference's extractFeatures returns), which the library cannot price when it enqueues the launch — the feature counts
-    # live on the device. Counted here, once, outside every timed region.
-    picks_per_launch = None
-    if stats and rank == 0:
-        ecap, pcap, ns = ctx.edge_capacity(lidar, fe), ctx.planar_capacity(lidar, fe), 2 * P
-        bufs = [ctx.alloc(ns * ecap * 4), ctx.alloc(ns * 4), ctx.alloc(ns * ecap * 24), ctx.alloc(ns * pcap * 4), ctx.alloc(ns * 4), ctx.alloc(ns * pcap * 24)]
-        ctx.extract_features_batch_dev(xyz.data_ptr(), ns, lidar, fe, *[b.ptr for b in bufs], f32=f32)
-        ctx.synchronize()
-        picks_per_launch = int(bufs[1].download(np.uint32, ns).astype(np.int64).sum() + bufs[4].download(np.uint32, ns).astype(np.int64).sum())
-        for b in bufs:
-            b.free()
-
     res_all = all_results.cpu().numpy().view(capi.RESULT_DTYPE)
     res = res_all[first_pair:first_pair + P]
     ranks = None
@@ -355,10 +342,8 @@ def main():
             avg_ms = s["total_ms"] / s["launches"]
             kern[name] = dict(launches=s["launches"], total_ms=round(s["total_ms"], 4), avg_ms=round(avg_ms, 5),
                               algorithmic_bytes_per_launch=s["algorithmic_bytes"] / s["launches"])
-        if "select_kernel" in kern and picks_per_launch is not None:
-            kern["select_kernel"]["algorithmic_bytes_per_launch"] += 48.0 * picks_per_launch
-            kern["select_kernel"]["algorithmic_bytes_note"] = (f"curvature words read + 2 x 24 B per feature copied ({picks_per_launch} features per launch, "
-                                                               "counted on the device outside the timed region)")
+        if "select_kernel" in kern:  # (loamx_ctx_get_kernel_stats prices the copies: the kernel counts its features)
+            kern["select_kernel"]["algorithmic_bytes_note"] = "curvature words read + 2 x 24 B per feature copied (features counted by the kernel)"
         for name, k in kern.items():
             b = k["algorithmic_bytes_per_launch"]
             k["achieved_GBs"] = round(b / (k["avg_ms"] * 1e-3) / 1e9, 2) if b > 0 and k["avg_ms"] > 0 else None

@@ -1825,6 +1825,11 @@ int loamx_ctx_get_kernel_stats(loamx_ctx* ctx, loamx_kernel_stat* stats) {
     unsigned long long ev[4] = {0, 0, 0, 0};
     HIP_TRY(ctx, hipMemcpy(ev, ctx->ws[WS_EXTRACT_EVENTS].p, sizeof(ev), hipMemcpyDeviceToHost));
     stats[LOAMX_K_EXTRACT_FUSED].algorithmic_bytes += 28.0 * (double)(ev[2] - ctx->features_base);
+    // the selection with its fused compaction copies every feature: 24 B read + 24 B written per feature on top of the
+    // curvature words it was priced with at launch (without them the scope read as 0.07 of HBM while the
+    // kernel moves 4.9 TB/s); the features are counted by the kernel itself (events[2])
+    if (stats[LOAMX_K_SELECT].launches != 0 && stats[LOAMX_K_EXTRACT_FUSED].launches == 0)
+      stats[LOAMX_K_SELECT].algorithmic_bytes += 48.0 * (double)(ev[2] - ctx->features_base);
   }
   return LOAMX_OK;
 }

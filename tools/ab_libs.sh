@@ -5,7 +5,7 @@ tags=$1; shift; keep=$1; shift
 for i in 1 2; do
   for v in $tags; do
     cp loam_amd/lib/libloamx_$v.so loam_amd/lib/libloamx.so
-    timeout -k 10 300 python3 bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1 | python3 -c "
+    timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-streamed "$@" 2>/dev/null | tail -1 | python3 -c "
 import json,sys,re; j=json.loads(sys.stdin.read()); k=j.get('kernels',{})
 print('$v', j['value'], j['ms_per_step'], ' '.join('%s=%.4f'%(n[:9],v['avg_ms']) for n,v in k.items() if v['launches'] and re.search('$keep' or '.', n)))"
   done

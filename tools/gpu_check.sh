@@ -5,7 +5,7 @@ tag=${1:-chk}; shift
 D=gpurun_out/$tag; mkdir -p "$D"
 # -s: a runtime abort message must reach the log
 timeout -k 10 700 python -m pytest tests -m gpu -x -q -s > "$D/gputests.log" 2>&1; echo "tests rc=$?"; tail -6 "$D/gputests.log"
-timeout -k 10 300 python bench.py --no-cpu-baseline "$@" > "$D/bench.json" 2> "$D/bench.err"; echo "bench rc=$?"
+timeout -k 10 300 python bench.py --no-cpu-baseline --no-streamed "$@" > "$D/bench.json" 2> "$D/bench.err"; echo "bench rc=$?"
 python3 - "$D/bench.json" <<'PY'
 import json, sys
 j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

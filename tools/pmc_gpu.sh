@@ -3,7 +3,7 @@
 set -e
 tag=$1; ctrs=$2; ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; D=$ROOT/gpurun_out/pmc_$tag
 rm -rf "$D"; mkdir -p "$D"; cd /tmp && export TMPDIR=/tmp
-LOAMX_NO_AUX_STREAM=1 timeout -k 10 300 rocprofv3 --pmc $ctrs -d "$D/out" --output-format csv -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$D/log.txt" 2> "$D/err.txt"
+LOAMX_NO_AUX_STREAM=1 timeout -k 10 300 rocprofv3 --pmc $ctrs -d "$D/out" --output-format csv -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-streamed > "$D/log.txt" 2> "$D/err.txt"
 python3 - "$D" "${3:-knn|fit|select}" <<'PY'
 import csv,glob,sys,re,collections
 agg=collections.defaultdict(lambda: collections.defaultdict(lambda:[0,0.0]))

@@ -53,7 +53,7 @@ def main():
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     md = ["# rocprofv3 summary (" + os.path.basename(src) + ")", ""]
     trace_tables = {}
-    for sub, log, title in (("trace", "bench_under_rocprof.log", "`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline`"),
+    for sub, log, title in (("trace", "bench_under_rocprof.log", "`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-streamed`"),
                             ("trace_seq", "bench_under_rocprof_seq.log", "the same with `LOAMX_NO_AUX_STREAM=1` (association chains in sequence on one stream: "
                              "per-kernel durations without the inflation that concurrent kernels report)")):
         stats = one_pass(os.path.join(src, sub, "*", "*_kernel_stats.csv"))

@@ -2,7 +2,7 @@
 # on the GPU box: rocprofv3 kernel trace of bench.py (3 steps) and the timeline of the last step -> gpurun_out/<tag>/
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; D=$ROOT/gpurun_out/${1:-trace_step}; rm -rf "$D"; mkdir -p "$D"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$D/trace" --output-format csv -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-stats > "$D/bench.log" 2> "$D/trace.err"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$D/trace" --output-format csv -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-streamed --no-kernel-stats > "$D/bench.log" 2> "$D/trace.err"
 find "$D" -name "*.db" -delete 2>/dev/null || true
 python3 - "$D" <<'PY'
 import csv,glob,re,sys
