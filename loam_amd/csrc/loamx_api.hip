@@ -1733,24 +1733,32 @@ static int register_scan_pairs_host(loamx_ctx* ctx, const void* xyz, bool f32, s
   };
   // (whatever earlier calls left on the context's stream may still read the staging buffers' neighbours: nothing to wait for,
   // the buffers are this entry point's own — but a previous call of THIS entry point has synchronised before it returned)
-  HIP_TRY(ctx, upload(0));
+  // (whatever fails below: uploads in flight must not outlive the caller's buffer, nor the staging buffers a later call may grow)
+  auto drain = [&](int code) {
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    return code;
+  };
+#define STREAM_TRY(expr)                                                                                  \
+  do {                                                                                                    \
+    hipError_t e_ = (expr);                                                                               \
+    if (e_ != hipSuccess) return drain(fail(ctx, LOAMX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); \
+  } while (0)
+  STREAM_TRY(upload(0));
   int rc = LOAMX_OK;
   for (size_t k = 0; k < n_chunks && rc == LOAMX_OK; k++) {
     const int b = (int)(k & 1);
-    if (k + 1 < n_chunks) HIP_TRY(ctx, upload(k + 1));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_up[b], 0));
+    if (k + 1 < n_chunks) STREAM_TRY(upload(k + 1));
+    STREAM_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_up[b], 0));
     rc = register_scan_pairs_locked(ctx, in[b], f32, pairs_of(k), lidar, fe, reg, d_res + k * chunk, true);
     untimed(ctx);
-    if (rc == LOAMX_OK) HIP_TRY(ctx, hipEventRecord(ctx->ev_free[b], ctx->stream));
+    if (rc == LOAMX_OK) STREAM_TRY(hipEventRecord(ctx->ev_free[b], ctx->stream));
   }
-  if (rc != LOAMX_OK) {  // (uploads in flight must not outlive the caller's buffer)
-    (void)hipStreamSynchronize(ctx->copy_stream);
-    (void)hipStreamSynchronize(ctx->stream);
-    return rc;
-  }
-  HIP_TRY(ctx, hipMemcpyAsync(results, d_res, n_pairs * sizeof(loamx_reg_result), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (rc != LOAMX_OK) return drain(rc);
+  STREAM_TRY(hipMemcpyAsync(results, d_res, n_pairs * sizeof(loamx_reg_result), hipMemcpyDeviceToHost, ctx->stream));
+  STREAM_TRY(hipStreamSynchronize(ctx->stream));
   return LOAMX_OK;
+#undef STREAM_TRY
 }
 
 int loamx_register_scan_pairs(loamx_ctx* ctx, const double* xyz, size_t n_pairs, const loamx_lidar_params* lidar,
